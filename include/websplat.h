@@ -1,0 +1,260 @@
+/*
+ * websplat.h -- C ABI of libwebsplat_hip.so, the MI355X (gfx950) drop-in for
+ * web-splat's render hot path (GaussianRenderer::prepare + render and the
+ * GPURSSorter they drive).
+ *
+ * Every entry point names the reference interface it replaces (file:line under
+ * /root/reference).  Plain pointers and sizes only; no C++ / torch types.
+ * All functions return WS_OK (0) or a negative ws_status; the message of the
+ * last failure on the calling thread is available from ws_last_error().
+ * Nothing throws across this boundary.
+ *
+ * Threading: handles are not thread-safe; use one context / renderer per host
+ * thread (the reference records single-threaded, renderer.rs:191-260).
+ * Async: prepare/render/sort only ENQUEUE work on the given HIP stream
+ * (hipStream_t passed as void*; NULL = the default stream) and return; the
+ * caller observes completion with ws_sync() -- the analogue of
+ * queue.submit + device.poll(Wait) (bin/measure.rs:147).
+ */
+#ifndef WEBSPLAT_H
+#define WEBSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WS_ABI_VERSION 1
+
+typedef enum ws_status {
+    WS_OK = 0,
+    WS_ERR_INVALID = -1,     /* bad argument / layout mismatch */
+    WS_ERR_HIP = -2,         /* a HIP runtime call failed (text in ws_last_error) */
+    WS_ERR_OOM = -3,
+    WS_ERR_UNSUPPORTED = -4, /* e.g. sh_deg > 3 */
+    WS_ERR_STATE = -5,       /* e.g. render() before prepare() */
+    WS_ERR_IO = -6,          /* loaders */
+    WS_ERR_OVERFLOW = -7     /* device-side capacity exceeded (tile entries) */
+} ws_status;
+
+/* wgpu::TextureFormat choices the reference's front-ends use for the splat target:
+ * Rgba8Unorm (lib.rs / bin/measure.rs), Rgba16Float (bin/render.rs:140), Rgba32Float (bin/video.rs). */
+typedef enum ws_color_format {
+    WS_FORMAT_RGBA8_UNORM = 0,
+    WS_FORMAT_RGBA16_FLOAT = 1,
+    WS_FORMAT_RGBA32_FLOAT = 2
+} ws_color_format;
+
+typedef struct ws_context ws_context;       /* wgpu Device+Queue      (lib.rs:57-125 WGPUContext) */
+typedef struct ws_pointcloud ws_pointcloud; /* pointcloud.rs:72-88    PointCloud */
+typedef struct ws_renderer ws_renderer;     /* renderer.rs:17-30      GaussianRenderer */
+typedef struct ws_sorter ws_sorter;         /* gpu_rs.rs:23-42        GPURSSorter + PointCloudSortStuff */
+
+/* pointcloud.rs:398-403 Aabb<f32> */
+typedef struct ws_aabb {
+    float min[3];
+    float max[3];
+} ws_aabb;
+
+/* pointcloud.rs:360-396 Quantization / GaussianQuantization (64 B, uniform layout) */
+typedef struct ws_quantization {
+    int32_t zero_point;
+    float scale;
+    uint32_t _pad[2];
+} ws_quantization;
+typedef struct ws_gaussian_quantization {
+    ws_quantization color_dc, color_rest, opacity, scaling_factor;
+} ws_gaussian_quantization;
+
+/* What io/mod.rs:27-43 GenericGaussianPointCloud hands to PointCloud::new (pointcloud.rs:99-199):
+ * the loader's byte blobs, verbatim, in HOST memory.
+ *   uncompressed: gaussians = num_points x 28 B  (pointcloud.rs:38-45 Gaussian)
+ *                 sh_coefs  = num_points x 96 B  ([[f16;3];16], io/mod.rs:65)
+ *   compressed:   gaussians = num_points x 24 B  (pointcloud.rs:14-22 GaussianCompressed)
+ *                 sh_coefs  = packed int8, 3*(sh_deg+1)^2 B per SH entry (io/npz.rs:183-196)
+ *                 covars    = n_covars x 12 B (pointcloud.rs:61-63 Covariance3D)
+ *                 quantization = 64 B block */
+typedef struct ws_pointcloud_desc {
+    uint32_t num_points;
+    uint32_t sh_deg;
+    int32_t compressed;
+    const void* gaussians;
+    size_t gaussians_bytes;
+    const void* sh_coefs;
+    size_t sh_coefs_bytes;
+    const void* covars; /* compressed only */
+    size_t covars_bytes;
+    const ws_gaussian_quantization* quantization; /* compressed only */
+    ws_aabb bbox;
+    float center[3];
+    int32_t has_up;
+    float up[3];
+    int32_t has_mip_splatting;
+    int32_t mip_splatting;
+    int32_t has_kernel_size;
+    float kernel_size;
+    int32_t has_background_color;
+    float background_color[3];
+} ws_pointcloud_desc;
+
+/* camera.rs:6-11 PerspectiveCamera + camera.rs:85-94 PerspectiveProjection */
+typedef struct ws_camera {
+    float position[3];
+    float rotation[4]; /* cgmath Quaternion (s, x, y, z) */
+    float fovx, fovy;  /* radians */
+    float znear, zfar;
+    float fov2view_ratio;
+} ws_camera;
+
+/* renderer.rs:585-599 SplattingArgs; Option<T> fields carry explicit has_* flags */
+typedef struct ws_splatting_args {
+    ws_camera camera;
+    uint32_t viewport[2];
+    float gaussian_scaling;
+    uint32_t max_sh_deg;
+    int32_t has_mip_splatting;
+    int32_t mip_splatting;
+    int32_t has_kernel_size;
+    float kernel_size;
+    int32_t has_clipping_box;
+    ws_aabb clipping_box;
+    double walltime_secs; /* Duration */
+    int32_t has_scene_center;
+    float scene_center[3]; /* ignored, like the reference (renderer.rs:644) */
+    int32_t has_scene_extend;
+    float scene_extend;
+    double background_color[4]; /* wgpu::Color; used by callers for the clear only */
+} ws_splatting_args;
+
+/* renderer.rs:290-306 CameraUniform (272 B) and renderer.rs:602-618 SplattingArgsUniform (80 B) */
+typedef struct ws_camera_uniform {
+    float view[16], view_inv[16], proj[16], proj_inv[16];
+    float viewport[2], focal[2];
+} ws_camera_uniform;
+typedef struct ws_settings_uniform {
+    float clip_min[4], clip_max[4];
+    float gaussian_scaling;
+    uint32_t max_sh_deg;
+    uint32_t mip_splatting;
+    float kernel_size;
+    float walltime;
+    float scene_extend;
+    uint32_t _pad[2];
+    float scene_center[4];
+} ws_settings_uniform;
+
+/* per-stage GPU time, the reference's GPUStopwatch labels (renderer.rs:221,230; lib.rs:448) plus binning */
+typedef struct ws_stage_times {
+    float preprocess_ms;
+    float sorting_ms;
+    float binning_ms;
+    float rasterization_ms;
+} ws_stage_times;
+
+/* device-side statistics of the last prepared frame (forces a sync) */
+typedef struct ws_frame_stats {
+    uint32_t num_visible;      /* V: renderer.rs:170-189 num_visible_points */
+    uint32_t num_tile_entries; /* D: sum over visible splats of 16x16 tiles touched */
+    uint32_t tile_entries_capacity;
+    uint32_t overflow;         /* 1 if D exceeded the capacity (entries dropped) */
+} ws_frame_stats;
+
+const char* ws_last_error(void);
+uint32_t ws_abi_version(void);
+
+/* ---- context: lib.rs:68-125 WGPUContext::new_instance / new --------------------------------- */
+int ws_context_create(int hip_device, ws_context** out);
+void ws_context_destroy(ws_context* ctx);
+int ws_sync(ws_context* ctx, void* stream); /* device.poll(Wait) */
+int ws_device_info(ws_context* ctx, char* name, size_t name_len, uint32_t* num_cus, uint64_t* hbm_bytes);
+/* plain device buffers for callers without their own allocator (tests, C++ drivers);
+ * the analogue of device.create_buffer + queue.write_buffer + DownloadBuffer */
+int ws_device_malloc(ws_context* ctx, size_t bytes, void** d_ptr);
+int ws_device_free(ws_context* ctx, void* d_ptr);
+int ws_memcpy_h2d(ws_context* ctx, void* d_dst, const void* h_src, size_t bytes, void* stream);
+int ws_memcpy_d2h(ws_context* ctx, void* h_dst, const void* d_src, size_t bytes, void* stream);
+
+/* ---- host-side boundary math (no GPU needed) ------------------------------------------------- */
+/* camera.rs:26-35 PerspectiveCamera::fit_near_far */
+int ws_camera_fit_near_far(ws_camera* cam, const ws_aabb* bbox);
+/* scene.rs:85-108 impl Into<PerspectiveCamera> for SceneCamera (rotation = 3 rows of 3, as in cameras.json) */
+int ws_camera_from_scene(const float position[3], const float rotation[9], float fx, float fy, uint32_t width,
+                         uint32_t height, ws_camera* out);
+/* renderer.rs:136-141 + 321-343 CameraUniform::set_camera / set_viewport / set_focal */
+int ws_build_camera_uniform(const ws_camera* cam, const uint32_t viewport[2], ws_camera_uniform* out);
+/* renderer.rs:620-651 SplattingArgsUniform::from_args_and_pc */
+int ws_build_settings_uniform(const ws_splatting_args* args, const ws_pointcloud* pc, ws_settings_uniform* out);
+/* pointcloud.rs:444-452 Aabb::center / radius */
+float ws_aabb_radius(const ws_aabb* b);
+
+/* ---- loaders' data prep (io/ply.rs:50-100, io/mod.rs:63-105, utils.rs:194-212) ---------------- */
+/* Convert INRIA-layout PLY vertex rows (f32, little-endian, property order of io/ply.rs:54-88;
+ * row length 3+3+3*(sh_deg+1)^2+1+3+4) into Gaussian (28 B) + SH (96 B) records. */
+int ws_ply_rows_convert(const float* rows, uint32_t n, uint32_t sh_deg, void* gaussians_out, void* sh_out);
+/* bbox (grown from `start`: Aabb::zeroed() for PLY io/mod.rs:74, Aabb::unit() for NPZ io/mod.rs:119),
+ * centroid and plane-fit up vector.  stride = 28 or 24. */
+int ws_pointcloud_stats(const void* gaussians, uint32_t n, uint32_t stride, const ws_aabb* start, ws_aabb* bbox,
+                        float center[3], int32_t* has_up, float up[3]);
+/* io/mod.rs:45-61 GenericGaussianPointCloud::load for a binary PLY file, then PointCloud::new */
+int ws_pointcloud_load_ply(ws_context* ctx, const char* path, ws_pointcloud** out);
+
+/* ---- PointCloud: pointcloud.rs:99-222, 336-349 ------------------------------------------------ */
+int ws_pointcloud_create(ws_context* ctx, const ws_pointcloud_desc* desc, ws_pointcloud** out);
+void ws_pointcloud_destroy(ws_pointcloud* pc);
+uint32_t ws_pointcloud_num_points(const ws_pointcloud* pc);
+uint32_t ws_pointcloud_sh_deg(const ws_pointcloud* pc);
+int ws_pointcloud_compressed(const ws_pointcloud* pc);
+int ws_pointcloud_bbox(const ws_pointcloud* pc, ws_aabb* out);
+int ws_pointcloud_center(const ws_pointcloud* pc, float out[3]);
+int ws_pointcloud_up(const ws_pointcloud* pc, float out[3]);                   /* returns 1 if Some */
+int ws_pointcloud_mip_splatting(const ws_pointcloud* pc, int32_t* out);        /* returns 1 if Some */
+int ws_pointcloud_kernel_size(const ws_pointcloud* pc, float* out);            /* returns 1 if Some */
+int ws_pointcloud_background_color(const ws_pointcloud* pc, float out[3]);     /* returns 1 if Some */
+
+/* ---- GaussianRenderer: renderer.rs:33-123, 170-260, 281 --------------------------------------- */
+/* GaussianRenderer::new(device, queue, color_format, sh_deg, compressed) */
+int ws_renderer_create(ws_context* ctx, ws_color_format format, uint32_t sh_deg, int compressed, ws_renderer** out);
+void ws_renderer_destroy(ws_renderer* r);
+ws_color_format ws_renderer_color_format(const ws_renderer* r);
+/* GaussianRenderer::prepare: reset counters -> preprocess (K1/K1c) -> depth radix sort -> tile binning.
+ * (Re)allocates per-renderer scratch when pc.num_points or the viewport changes (renderer.rs:200-211). */
+int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatting_args* args, void* stream);
+/* begin_render_pass(clear = background) + GaussianRenderer::render: composites the prepared frame into
+ * d_rgba_out (device memory, viewport.y rows of row_pitch_bytes; texel = 4 x {u8 | f16 | f32} by format),
+ * premultiplied RGBA over `background` (the clear colour, bin/render.rs:113-116). */
+int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float background[4], void* d_rgba_out,
+                       size_t row_pitch_bytes, void* stream);
+/* GaussianRenderer::num_visible_points (syncs) */
+int ws_renderer_num_visible(ws_renderer* r, uint32_t* out);
+int ws_renderer_frame_stats(ws_renderer* r, ws_frame_stats* out); /* syncs */
+/* GPUStopwatch::take_measurements for the last frame (syncs); needs ws_renderer_enable_timers(r,1) */
+int ws_renderer_enable_timers(ws_renderer* r, int enable);
+int ws_renderer_stage_times(ws_renderer* r, ws_stage_times* out);
+/* parity tooling: also record the original Gaussian index of every store slot (costs 4 B per visible splat) */
+int ws_renderer_enable_capture(ws_renderer* r, int enable);
+/* tuning: capacity of the (tile, splat) entry list; 0 = automatic. Takes effect at the next prepare. */
+int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries);
+/* parity read-back of the prepared frame (the reference's test tooling reads buffers back the same way,
+ * gpu_rs.rs:900-941 download_buffer): splats = V x 20 B in store order, keys/src_index = V u32 in store
+ * order (src_index = original Gaussian index of each slot), sorted = V u32 store indices in draw order
+ * (far -> near).  Any pointer may be NULL.  capacity = number of elements each array can hold. Syncs. */
+int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, uint32_t* keys,
+                               uint32_t* src_index, uint32_t* sorted, uint32_t* num_visible);
+
+/* ---- GPURSSorter: gpu_rs.rs:65-175, 720-727, 865-884 ------------------------------------------ */
+/* GPURSSorter::new + create_sort_stuff(device, max_n): scratch for sorting up to max_n pairs */
+int ws_sorter_create(ws_context* ctx, uint32_t max_n, ws_sorter** out);
+void ws_sorter_destroy(ws_sorter* s);
+/* record_sort (d_count == NULL, sorts n pairs) / record_sort_indirect (count read from device memory,
+ * clamped to n): ascending, stable, in place in d_keys / d_payload (gpu_rs.rs:865-884). */
+int ws_sorter_sort(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, const uint32_t* d_count, uint32_t n,
+                   void* stream);
+/* GPURSSorter::test_sort (gpu_rs.rs:295-331): 8192 reversed f32 keys must come out ascending. 1 = pass */
+int ws_sort_selftest(ws_context* ctx, int* passed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WEBSPLAT_H */

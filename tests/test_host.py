@@ -1,0 +1,126 @@
+"""CPU tests of the product's host side (no GPU needed): the C-ABI library loads and exports every symbol
+include/websplat.h declares; camera / uniform / loader-prep code agrees with the oracle's restatement of
+camera.rs, renderer.rs:321-343,620-651, io/ply.rs:50-100, io/mod.rs:63-105."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from websplat import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol(ws):
+    header = open(os.path.join(ROOT, "include", "websplat.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(ws_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 40
+    from websplat import _lib
+    raw = C.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(raw, s)]
+    assert not missing, f"declared in websplat.h but not exported: {missing}"
+    unbound = sorted(declared - set(_lib.SIGNATURES))
+    assert not unbound, f"declared in websplat.h but not bound by the Python stub: {unbound}"
+    assert ws.lib.ws_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure(ws):
+    """No CPU fallback: without a device, context creation must fail with a HIP error, not emulate."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ws.WebSplatError) as e:
+        ws.Context(0)
+    assert "no HIP device" in str(e.value)
+
+
+def _uniform_arrays(u):
+    return {k: np.array(list(getattr(u, k)), dtype=np.float32) for k in ("view", "view_inv", "proj", "proj_inv", "viewport", "focal")}
+
+
+@pytest.mark.parametrize("cam_idx", [0, 5, 11])
+def test_camera_uniform_matches_oracle(ws, oracle, cam_idx):
+    cj = synth.orbit_cameras(16, 1200, 799, 1200.0, 1150.0)[cam_idx]
+    cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, cj.width, cj.height)
+    ocam = oracle.scene_camera_to_perspective(cj.position, cj.rotation, cj.fx, cj.fy, cj.width, cj.height)
+    assert np.array_equal(np.array(cam.rotation, np.float32), np.array(list(ocam.rotation), np.float32))
+    assert (cam.fovx, cam.fovy, cam.fov2view_ratio) == (ocam.fovx, ocam.fovy, ocam.fov2view_ratio)
+    bbox = ws.Aabb([-6, -6, -6], [6, 6, 6])
+    cam.fit_near_far(bbox)
+    oracle.fit_near_far(ocam, oracle.make_aabb(bbox.min, bbox.max))
+    assert (cam.znear, cam.zfar) == (ocam.znear, ocam.zfar)
+    u = _uniform_arrays(cam.uniform((1200, 799)))
+    o = _uniform_arrays(oracle.camera_uniform(ocam, 1200, 799))
+    for k in u:  # same f32 operation sequence on both sides -> bit-identical
+        assert np.array_equal(u[k].view(np.uint32), o[k].view(np.uint32)), k
+
+
+def test_negative_determinant_rotation_is_flipped(ws, oracle):
+    rot = [[1.0, 0.0, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, 1.0]]  # det = -1 (scene.rs:90-96)
+    cam = ws.PerspectiveCamera.from_scene_camera([0, 0, -3], rot, 500, 500, 640, 480)
+    ocam = oracle.scene_camera_to_perspective([0, 0, -3], rot, 500, 500, 640, 480)
+    assert np.allclose(cam.rotation, list(ocam.rotation))
+    assert np.allclose(cam.rotation, [1, 0, 0, 0])
+
+
+def test_ply_rows_convert_matches_oracle(ws, oracle):
+    rows = synth.scene_c1(n=5000, seed=11)
+    rows[0, 54] = 40.0    # sigmoid saturation
+    rows[1, 54] = -40.0
+    rows[2, 55:58] = [3.0, -9.0, 0.0]  # extreme scales (f16 overflow / underflow of the covariance)
+    pc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
+    g, sh = oracle.ply_rows_convert(rows, 3)
+    assert np.array_equal(pc.gaussians, g)
+    assert np.array_equal(pc.sh_coefs, sh)
+    # spot-check the record layout (pointcloud.rs:38-45, io/mod.rs:65)
+    assert np.array_equal(g[7, :12].view(np.float32), rows[7, :3])
+    op = 1.0 / (1.0 + np.exp(-np.float64(rows[7, 54])))
+    assert np.isclose(g[7, 12:14].view(np.float16)[0], op, atol=1e-3)
+    assert g[7, 14] == 0 and g[7, 15] == 0
+    sh16 = sh[7].view(np.float16).reshape(16, 3)
+    assert np.allclose(sh16[0], rows[7, 6:9], atol=2e-3)
+    rest = rows[7, 9:54].reshape(3, 15)  # channel-major in the file
+    assert np.allclose(sh16[1:], rest.T, atol=1e-3)
+    bbox, center, up = oracle.pointcloud_stats(g, 28, oracle.make_aabb([0, 0, 0], [0, 0, 0]))
+    assert np.array_equal(np.array(pc.aabb.min, np.float32), np.array(list(bbox.min), np.float32))
+    assert np.array_equal(np.array(pc.aabb.max, np.float32), np.array(list(bbox.max), np.float32))
+    assert np.array_equal(np.array(pc.center, np.float32), np.array(center, np.float32))
+    assert pc.up is None and up is None  # bbox radius < 10 -> up dropped (io/mod.rs:88-90)
+
+
+@pytest.mark.parametrize("sh_deg", [0, 1, 2])
+def test_ply_rows_convert_lower_degrees(ws, oracle, sh_deg):
+    full = synth.scene_c1(n=300, seed=3, sh_deg=sh_deg)
+    assert full.shape[1] == synth.PLY_ROW_LEN[sh_deg]
+    pc = ws.GenericGaussianPointCloud.from_ply_rows(full, sh_deg)
+    g, sh = oracle.ply_rows_convert(full, sh_deg)
+    assert np.array_equal(pc.gaussians, g) and np.array_equal(pc.sh_coefs, sh)
+    ncoef = (sh_deg + 1) ** 2
+    assert not sh.view(np.float16).reshape(-1, 16, 3)[:, ncoef:].any()  # unused coefficients are zero
+
+
+def test_up_vector_large_scene(ws, oracle):
+    rng = np.random.default_rng(2)
+    rows = synth.scene_c1(n=4000, seed=2)
+    rows[:, 0] = rng.uniform(-30, 30, 4000)   # wide slab in x/z, thin in y -> plane normal ~ +-y
+    rows[:, 2] = rng.uniform(-30, 30, 4000)
+    rows[:, 1] = rng.uniform(-0.2, 0.2, 4000)
+    pc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
+    g, _ = oracle.ply_rows_convert(rows, 3)
+    _, _, up = oracle.pointcloud_stats(g, 28, oracle.make_aabb([0, 0, 0], [0, 0, 0]))
+    assert pc.up is not None and up is not None
+    assert np.allclose(pc.up, up, atol=1e-6)
+    assert pc.up[1] > 0.99
+
+
+def test_write_ply_layout(tmp_path):
+    rows = synth.scene_c1(n=10, seed=1)
+    p = tmp_path / "a.ply"
+    synth.write_ply(str(p), rows, 3, comments=["mip=true", "kernel_size=0.1"])
+    raw = p.read_bytes()
+    head, body = raw.split(b"end_header\n", 1)
+    assert head.startswith(b"ply\nformat binary_little_endian 1.0\n")
+    assert head.count(b"property float") == 62 and len(body) == 10 * 248

@@ -1,0 +1,163 @@
+// host_ply.cpp -- INRIA 3D-Gaussian-Splatting PLY loader on the host (the step in front of the hot path).
+//
+// Mirrors src/io/ply.rs:28-48 (header: sh degree from the number of f_* properties, vertex count,
+// comments `mip=..`, `kernel_size=..`, `background_color=r,g,b`), :164-196 (binary little/big endian
+// bodies, ascii unsupported like the reference's todo!()), and io/mod.rs:45-105 (magic-byte sniffing,
+// bbox grown from Aabb::zeroed(), centroid, plane fit).  ply-rs 0.1.3 (header parser) is not vendored in
+// the reference; the PLY header grammar is written out here.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ws_internal.h"
+
+using namespace ws;
+
+namespace {
+
+struct PlyHeader {
+    bool little_endian = true;
+    uint32_t num_vertices = 0;
+    uint32_t num_props = 0;
+    uint32_t num_f_props = 0;
+    bool all_float = true;
+    std::vector<std::string> comments;
+    long body_offset = 0;
+};
+
+bool read_line(FILE* f, std::string* out) {
+    out->clear();
+    int c;
+    while ((c = std::fgetc(f)) != EOF) {
+        if (c == '\n') return true;
+        if (c != '\r') out->push_back((char)c);
+    }
+    return !out->empty();
+}
+
+int parse_header(FILE* f, PlyHeader* h) {
+    std::string line;
+    if (!read_line(f, &line) || line != "ply") return fail(WS_ERR_IO, "ply: missing magic");
+    bool in_vertex = false, have_format = false;
+    while (read_line(f, &line)) {
+        if (line == "end_header") {
+            h->body_offset = std::ftell(f);
+            if (!have_format) return fail(WS_ERR_IO, "ply: missing format line");
+            return WS_OK;
+        }
+        if (line.rfind("format ", 0) == 0) {
+            have_format = true;
+            if (line.find("binary_little_endian") != std::string::npos)
+                h->little_endian = true;
+            else if (line.find("binary_big_endian") != std::string::npos)
+                h->little_endian = false;
+            else
+                return fail(WS_ERR_UNSUPPORTED, "ply: ascii format not supported (as in the reference)");
+        } else if (line.rfind("comment ", 0) == 0) {
+            h->comments.push_back(line.substr(8));
+        } else if (line.rfind("element ", 0) == 0) {
+            char name[64];
+            unsigned long cnt = 0;
+            if (std::sscanf(line.c_str(), "element %63s %lu", name, &cnt) != 2) return fail(WS_ERR_IO, "ply: bad element line");
+            in_vertex = std::strcmp(name, "vertex") == 0;
+            if (in_vertex) h->num_vertices = (uint32_t)cnt;
+        } else if (line.rfind("property ", 0) == 0 && in_vertex) {
+            char type[32], name[64];
+            if (std::sscanf(line.c_str(), "property %31s %63s", type, name) != 2) return fail(WS_ERR_IO, "ply: bad property line");
+            if (std::strcmp(type, "float") != 0 && std::strcmp(type, "float32") != 0) h->all_float = false;
+            h->num_props++;
+            if (std::strncmp(name, "f_", 2) == 0) h->num_f_props++;
+        }
+    }
+    return fail(WS_ERR_IO, "ply: end_header not found");
+}
+
+bool comment_value(const PlyHeader& h, const char* key, std::string* value) {
+    for (const std::string& c : h.comments)
+        if (c.find(key) != std::string::npos) {
+            const size_t eq = c.rfind('=');
+            *value = eq == std::string::npos ? c : c.substr(eq + 1);
+            return true;
+        }
+    return false;
+}
+
+}  // namespace
+
+extern "C" int ws_pointcloud_load_ply(ws_context* ctx, const char* path, ws_pointcloud** out) {
+    if (!ctx || !path || !out) return fail(WS_ERR_INVALID, "ws_pointcloud_load_ply: null argument");
+    *out = nullptr;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(WS_ERR_IO, std::string("ws_pointcloud_load_ply: cannot open ") + path);
+    PlyHeader h;
+    int rc = parse_header(f, &h);
+    if (rc) {
+        std::fclose(f);
+        return rc;
+    }
+    // io/ply.rs:102-113: sh degree from the number of f_* properties / 3
+    const uint32_t ncoef = h.num_f_props / 3;
+    const uint32_t root = (uint32_t)std::lround(std::sqrt((double)ncoef));
+    if (h.num_f_props % 3 != 0 || root * root != ncoef || root == 0 || root > 4 || !h.all_float) {
+        std::fclose(f);
+        return fail(WS_ERR_IO, "ply: number of sh coefficients cannot be mapped to an sh degree <= 3");
+    }
+    const uint32_t sh_deg = root - 1;
+    const uint32_t row_len = 3 + 3 + 3 * ncoef + 1 + 3 + 4;
+    if (h.num_props != row_len || h.num_vertices == 0) {
+        std::fclose(f);
+        return fail(WS_ERR_IO, "ply: vertex layout is not the INRIA 3DGS layout (x,y,z,n*,f_dc*,f_rest*,opacity,scale*,rot*)");
+    }
+    std::vector<float> rows;
+    try {
+        rows.resize((size_t)h.num_vertices * row_len);
+    } catch (...) {
+        std::fclose(f);
+        return fail(WS_ERR_OOM, "ply: host allocation failed");
+    }
+    std::fseek(f, h.body_offset, SEEK_SET);
+    const size_t got = std::fread(rows.data(), sizeof(float), rows.size(), f);
+    std::fclose(f);
+    if (got != rows.size()) return fail(WS_ERR_IO, "ply: truncated vertex data");
+    if (!h.little_endian) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(rows.data());
+        for (size_t i = 0; i < rows.size(); ++i) w[i] = __builtin_bswap32(w[i]);
+    }
+    std::vector<uint8_t> gaussians((size_t)h.num_vertices * 28), sh((size_t)h.num_vertices * 96);
+    if ((rc = ws_ply_rows_convert(rows.data(), h.num_vertices, sh_deg, gaussians.data(), sh.data()))) return rc;
+    rows.clear();
+    rows.shrink_to_fit();
+
+    ws_pointcloud_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.num_points = h.num_vertices;
+    d.sh_deg = sh_deg;
+    d.compressed = 0;
+    d.gaussians = gaussians.data();
+    d.gaussians_bytes = gaussians.size();
+    d.sh_coefs = sh.data();
+    d.sh_coefs_bytes = sh.size();
+    ws_aabb zero;  // Aabb::zeroed(), io/mod.rs:74
+    std::memset(&zero, 0, sizeof zero);
+    if ((rc = ws_pointcloud_stats(gaussians.data(), h.num_vertices, 28, &zero, &d.bbox, d.center, &d.has_up, d.up))) return rc;
+    std::string v;
+    if (comment_value(h, "mip", &v)) {  // io/ply.rs:123-130 (parse::<bool>)
+        d.has_mip_splatting = 1;
+        d.mip_splatting = (v == "true") ? 1 : 0;
+        if (v != "true" && v != "false") return fail(WS_ERR_IO, "ply: bad mip comment");
+    }
+    if (comment_value(h, "kernel_size", &v)) {
+        d.has_kernel_size = 1;
+        d.kernel_size = std::strtof(v.c_str(), nullptr);
+    }
+    if (comment_value(h, "background_color", &v)) {
+        float c[3];
+        if (std::sscanf(v.c_str(), "%f,%f,%f", &c[0], &c[1], &c[2]) == 3) {
+            d.has_background_color = 1;
+            std::memcpy(d.background_color, c, sizeof c);
+        }  // parse failures are only warned about in the reference (io/ply.rs:36-38)
+    }
+    return ws_pointcloud_create(ctx, &d, out);
+}

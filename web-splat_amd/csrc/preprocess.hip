@@ -1,0 +1,493 @@
+// preprocess.hip -- K1 / K1c for gfx950: per-Gaussian cull, EWA projection, SH colour, ordered compaction.
+//
+// Replaces src/shaders/preprocess.wgsl:163-280 (uncompressed) and
+// src/shaders/preprocess_compressed.wgsl:206-332 (c3dgs) of the reference.
+//
+// MI355X design (not a translation of the WGSL):
+//   * The point cloud lives in HBM as eight planes of 16-B chunks (ws_internal.h), so every load
+//     instruction of a wave is one fully coalesced 1-KiB read, and a culled Gaussian costs 16 B
+//     instead of 124 B: SH / covariance planes are only touched by lanes that survive the cull.
+//   * Compaction is ORDERED (store order == Gaussian index order) through a ticketed, wave-parallel
+//     decoupled look-back over 256-Gaussian blocks: one 32-bit {flag,count} word per block, no fence
+//     needed because the word is its own payload.  The reference's atomicAdd(keys_size) order is
+//     nondeterministic (preprocess.wgsl:262); ordered compaction makes equal-depth ties, and hence the
+//     image, reproducible across runs and ranks.
+//   * Besides the reference's outputs (Splat 20 B, depth key) the kernel emits the splat's 16x16-tile
+//     rectangle (8 B) for the binning stage that replaces the hardware rasteriser.
+//
+// This file is compiled with -ffp-contract=off: f32 operations happen in source order, which is the
+// WGSL expression order, so results can be compared with the CPU restatement at the f16-ulp level.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "ws_internal.h"
+
+namespace ws {
+
+namespace {
+
+constexpr int K1_THREADS = 256;
+constexpr uint32_t LB_FLAG_AGG = 1u << 30;   // block aggregate available
+constexpr uint32_t LB_FLAG_INCL = 2u << 30;  // inclusive prefix available
+constexpr uint32_t LB_VALUE_MASK = (1u << 30) - 1u;
+constexpr uint32_t LB_SPIN_LIMIT = 1u << 24;
+
+__device__ __forceinline__ float h2f(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)(h & 0xFFFFu))); }
+__device__ __forceinline__ uint32_t f2h(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Exclusive prefix of the per-block visible counts, for block `bid`, computed by ONE wave.
+// Lane l inspects predecessor bid-1-l; the window slides back by 64 until an inclusive prefix is met.
+__device__ uint32_t lookback_exclusive(const uint32_t* status, uint32_t bid, int lane, uint32_t* error_word) {
+    uint32_t sum = 0;
+    int64_t base = (int64_t)bid - 1;
+    uint32_t spins = 0;
+    while (true) {
+        const int64_t i = base - lane;
+        uint32_t w = LB_FLAG_INCL;  // virtual predecessor of block 0: inclusive prefix 0
+        if (i >= 0) w = ld_agent(status + i);
+        // all lanes up to the first INCL lane must be published
+        const unsigned long long incl = __ballot((w >> 30) == 2u);
+        const int first = incl ? (__ffsll((long long)incl) - 1) : 64;
+        const unsigned long long pending = __ballot((w >> 30) == 0u && lane <= first);
+        if (pending) {
+            if (++spins > LB_SPIN_LIMIT) {
+                if (lane == 0) atomicOr(error_word, 2u);
+                return sum;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        sum += wave_sum(lane <= first ? (w & LB_VALUE_MASK) : 0u);
+        if (incl) return sum;
+        base -= 64;
+    }
+}
+
+// SH basis constants: preprocess.wgsl:4-23
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f,
+                           SH_C2_2 = 0.31539156525252005f, SH_C2_3 = -1.0925484305920792f,
+                           SH_C2_4 = 0.5462742152960396f;
+__device__ constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f,
+                           SH_C3_2 = -0.4570457994644658f, SH_C3_3 = 0.3731763325901154f,
+                           SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
+                           SH_C3_6 = -0.5900435899266435f;
+
+struct Sh16 {
+    float c[16][3];
+};
+
+// preprocess.wgsl:124-154 evaluate_sh, one channel
+__device__ __forceinline__ float eval_sh_channel(const Sh16& sh, int ch, float x, float y, float z, uint32_t deg) {
+    float result = SH_C0 * sh.c[0][ch];
+    if (deg > 0u) {
+        result += -SH_C1 * y * sh.c[1][ch] + SH_C1 * z * sh.c[2][ch] - SH_C1 * x * sh.c[3][ch];
+        if (deg > 1u) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            const float xy = x * y, yz = y * z, xz = x * z;
+            result += SH_C2_0 * xy * sh.c[4][ch] + SH_C2_1 * yz * sh.c[5][ch] +
+                      SH_C2_2 * (2.0f * zz - xx - yy) * sh.c[6][ch] + SH_C2_3 * xz * sh.c[7][ch] +
+                      SH_C2_4 * (xx - yy) * sh.c[8][ch];
+            if (deg > 2u) {
+                result += SH_C3_0 * y * (3.0f * xx - yy) * sh.c[9][ch] + SH_C3_1 * xy * z * sh.c[10][ch] +
+                          SH_C3_2 * y * (4.0f * zz - xx - yy) * sh.c[11][ch] +
+                          SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh.c[12][ch] +
+                          SH_C3_4 * x * (4.0f * zz - xx - yy) * sh.c[13][ch] + SH_C3_5 * z * (xx - yy) * sh.c[14][ch] +
+                          SH_C3_6 * x * (xx - 3.0f * yy) * sh.c[15][ch];
+            }
+        }
+    }
+    result += 0.5f;
+    return result;
+}
+
+struct SplatOut {
+    uint32_t w[5];  // Splat: v(4 x f16) pos(2 x f16) color(4 x f16)
+    uint32_t key;
+    uint2 rect;
+};
+
+#define VM(c, r) (p.cam.view[(c)*4 + (r)])
+#define PM(c, r) (p.cam.proj[(c)*4 + (r)])
+
+// From the frustum test onward: preprocess.wgsl:194-273 / preprocess_compressed.wgsl:234-325.
+template <bool COMPRESSED>
+__device__ void k1_math(const K1Params& p, const float xyz[3], const float camspace[4], const float pos2d[4],
+                        float opacity, const float cov6[6], const Sh16& sh, SplatOut* out) {
+    // fade-in (preprocess.wgsl:196-203)
+    const float walltime = p.rs.walltime;
+    float scale_mod = 0.0f;
+    const float ddx = p.rs.scene_center[0] - xyz[0], ddy = p.rs.scene_center[1] - xyz[1],
+                ddz = p.rs.scene_center[2] - xyz[2];
+    const float dd = 5.0f * sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) / p.rs.scene_extend;
+    if (walltime > dd) {
+        float t = (walltime - dd - 0.0f) / (1.0f - 0.0f);
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        scale_mod = t * t * (3.0f - 2.0f * t);
+    }
+    const float scaling = p.rs.gaussian_scaling * scale_mod;
+
+    // Vrk = sym(cov6) * scaling * scaling
+    float V[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) V[i] = cov6[i] * scaling * scaling;
+    const float v00 = V[0], v01 = V[1], v02 = V[2], v11 = V[3], v12 = V[4], v22 = V[5];
+
+    const float fx = p.cam.focal[0], fy = p.cam.focal[1];
+    const float cz = camspace[2];
+    const float j00 = fx / cz;
+    const float j02 = -(fx * camspace[0]) / (cz * cz);
+    const float j11 = -fy / cz;
+    const float j12 = (fy * camspace[1]) / (cz * cz);
+    // W = transpose(mat3(view)) -> column k of W is row k of the view rotation;
+    // T = W * J: T[0] = W[0]*j00 + W[1]*0 + W[2]*j02 ; T[1] = W[0]*0 + W[1]*j11 + W[2]*j12 ; T[2] = 0.
+    float t0[3], t1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        // W[k][r] = view[r][k]  (view[c][r] is column c, row r)
+        const float w0 = VM(r, 0), w1 = VM(r, 1), w2 = VM(r, 2);
+        float s0 = w0 * j00;
+        s0 += w1 * 0.0f;
+        s0 += w2 * j02;
+        t0[r] = s0;
+        float s1 = w0 * 0.0f;
+        s1 += w1 * j11;
+        s1 += w2 * j12;
+        t1[r] = s1;
+    }
+    // A = transpose(T) * Vrk : A[c][r] = sum_k Tt[k][r] * Vrk[c][k] = sum_k T[r][k] * Vrk[c][k]
+    // rows r = 0,1 matter; Vrk symmetric, Vrk[c][k] = V(c,k)
+    float a0[3], a1[3];  // a0[c] = A[c][0], a1[c] = A[c][1]
+    {
+        const float Vc[3][3] = {{v00, v01, v02}, {v01, v11, v12}, {v02, v12, v22}};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s = t0[0] * Vc[c][0];
+            s += t0[1] * Vc[c][1];
+            s += t0[2] * Vc[c][2];
+            a0[c] = s;
+            float u = t1[0] * Vc[c][0];
+            u += t1[1] * Vc[c][1];
+            u += t1[2] * Vc[c][2];
+            a1[c] = u;
+        }
+    }
+    // cov = A * T : cov[c][r] = sum_k A[k][r] * T[c][k]
+    float cov00 = a0[0] * t0[0];
+    cov00 += a0[1] * t0[1];
+    cov00 += a0[2] * t0[2];
+    float cov01 = a1[0] * t0[0];  // cov[0][1]: column 0, row 1
+    cov01 += a1[1] * t0[1];
+    cov01 += a1[2] * t0[2];
+    float cov11 = a1[0] * t1[0];
+    cov11 += a1[1] * t1[1];
+    cov11 += a1[2] * t1[2];
+
+    const float kernel_size = p.rs.kernel_size;
+    if (p.rs.mip_splatting != 0u) {  // preprocess.wgsl:225-236
+        const float det_0 = fmaxf(1e-6f, cov00 * cov11 - cov01 * cov01);
+        const float det_1 = fmaxf(1e-6f, (cov00 + kernel_size) * (cov11 + kernel_size) - cov01 * cov01);
+        float coef = sqrtf(det_0 / (det_1 + 1e-6f) + 1e-6f);
+        if (det_0 <= 1e-6f || det_1 <= 1e-6f) coef = 0.0f;
+        opacity *= coef;
+    }
+    const float diagonal1 = cov00 + kernel_size;
+    const float offDiagonal = cov01;
+    const float diagonal2 = cov11 + kernel_size;
+    const float mid = 0.5f * (diagonal1 + diagonal2);
+    const float hx = (diagonal1 - diagonal2) / 2.0f;
+    const float radius = sqrtf(hx * hx + offDiagonal * offDiagonal);
+    float lambda1, lambda2;
+    if (!COMPRESSED) {
+        lambda1 = mid + radius;
+        lambda2 = fmaxf(mid - radius, 0.1f);
+    } else {
+        lambda1 = mid + fmaxf(radius, 0.1f);
+        lambda2 = mid - fmaxf(radius, 0.1f);
+    }
+    const float dvx = offDiagonal, dvy = lambda1 - diagonal1;
+    const float dlen = sqrtf(dvx * dvx + dvy * dvy);
+    float ex = 1.0f, ey = 0.0f;  // normalize((0,0)) is undefined in WGSL; defined as (1,0) here
+    if (dlen > 0.0f) {
+        ex = dvx / dlen;
+        ey = dvy / dlen;
+    }
+    const float s1 = sqrtf(2.0f * lambda1), s2 = sqrtf(2.0f * lambda2);
+    const float v1x = s1 * ex, v1y = s1 * ey;
+    const float v2x = s2 * ey, v2y = s2 * (-ex);
+    const float vcx = pos2d[0] / pos2d[3], vcy = pos2d[1] / pos2d[3];
+
+    // colour: preprocess.wgsl:255-260
+    const float dx = xyz[0] - p.cam.view_inv[12], dy = xyz[1] - p.cam.view_inv[13], dz = xyz[2] - p.cam.view_inv[14];
+    const float dl = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float dirx = dx / dl, diry = dy / dl, dirz = dz / dl;
+    const float cr = fmaxf(0.0f, eval_sh_channel(sh, 0, dirx, diry, dirz, p.rs.max_sh_deg));
+    const float cg = fmaxf(0.0f, eval_sh_channel(sh, 1, dirx, diry, dirz, p.rs.max_sh_deg));
+    const float cb = fmaxf(0.0f, eval_sh_channel(sh, 2, dirx, diry, dirz, p.rs.max_sh_deg));
+
+    const float vw = p.cam.viewport[0], vh = p.cam.viewport[1];
+    const uint32_t h0 = f2h(v1x / vw), h1 = f2h(v1y / vh), h2 = f2h(v2x / vw), h3 = f2h(v2y / vh);
+    const uint32_t h4 = f2h(vcx), h5 = f2h(vcy);
+    out->w[0] = h0 | (h1 << 16);
+    out->w[1] = h2 | (h3 << 16);
+    out->w[2] = h4 | (h5 << 16);
+    out->w[3] = f2h(cr) | (f2h(cg) << 16);
+    out->w[4] = f2h(cb) | (f2h(opacity) << 16);
+
+    // depth key: preprocess.wgsl:270-273 / preprocess_compressed.wgsl:322-325
+    const float znear = -PM(3, 2) / PM(2, 2);
+    const float zfar = -PM(3, 2) / (PM(2, 2) - 1.0f);
+    if (!COMPRESSED) {
+        out->key = __float_as_uint(zfar - pos2d[2]);
+    } else {
+        const float kf = 16777215.0f - (pos2d[2] - znear) / (zfar - znear) * 16777215.0f;
+        uint32_t k = 0u;
+        if (kf > 0.0f) k = (kf >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t)kf;
+        out->key = k;
+    }
+
+    // 16x16-tile rectangle of the kept ellipse a <= 2*CUTOFF (gaussian.wgsl:40-64), derived from the
+    // f16-ROUNDED splat so that binning and blending agree on coverage.
+    {
+        const float q1x = h2f(h0), q1y = h2f(h1), q2x = h2f(h2), q2y = h2f(h3);
+        const float m00 = q1x * vw, m01 = q2x * vw;
+        const float m10 = -q1y * vh, m11 = -q2y * vh;
+        const float det = m00 * m11 - m01 * m10;
+        const float cx = (h2f(h4) * 0.5f + 0.5f) * vw;
+        const float cy = (0.5f - h2f(h5) * 0.5f) * vh;
+        const float rad = 2.1697873f * 1.00001f;  // sqrt(2*CUTOFF), padded
+        const float exx = rad * sqrtf(m00 * m00 + m01 * m01) + 1e-3f;
+        const float eyy = rad * sqrtf(m10 * m10 + m11 * m11) + 1e-3f;
+        uint2 rect = make_uint2(1u, 0u);  // empty
+        const bool ok = (fabsf(det) > 0.0f) && (fabsf(det) < 3.0e38f) && (fabsf(cx) < 1.0e9f) && (fabsf(cy) < 1.0e9f) &&
+                        (exx < 1.0e9f) && (eyy < 1.0e9f);
+        if (ok) {
+            // pixel (x, y) has its centre at (x + 0.5, y + 0.5)
+            float x_lo = ceilf(cx - exx - 0.5f), x_hi = floorf(cx + exx - 0.5f);
+            float y_lo = ceilf(cy - eyy - 0.5f), y_hi = floorf(cy + eyy - 0.5f);
+            x_lo = fmaxf(x_lo, 0.0f);
+            y_lo = fmaxf(y_lo, 0.0f);
+            x_hi = fminf(x_hi, vw - 1.0f);
+            y_hi = fminf(y_hi, vh - 1.0f);
+            if (x_lo <= x_hi && y_lo <= y_hi) {
+                const uint32_t tx0 = (uint32_t)x_lo / TILE, tx1 = (uint32_t)x_hi / TILE;
+                const uint32_t ty0 = (uint32_t)y_lo / TILE, ty1 = (uint32_t)y_hi / TILE;
+                rect = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+            }
+        }
+        out->rect = rect;
+    }
+}
+
+template <bool COMPRESSED>
+__global__ __launch_bounds__(K1_THREADS) void k_preprocess(const K1Params p, const K1Buffers b) {
+    __shared__ uint32_t s_bid;
+    __shared__ uint32_t s_wave_cnt[K1_THREADS / 64];
+    __shared__ uint32_t s_base;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    if (tid == 0) s_bid = atomicAdd(&b.counters->k1_ticket, 1u);
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const uint32_t n = p.num_points;
+    const uint32_t idx = bid * K1_THREADS + tid;
+
+    float xyz[3] = {0.f, 0.f, 0.f}, camspace[4] = {0.f, 0.f, 1.f, 1.f}, pos2d[4] = {0.f, 0.f, 0.f, 1.f};
+    uint32_t w3 = 0;  // uncompressed: opacity f16 in the low half; compressed: opacity/scale int8
+    uint32_t geometry_idx = 0, sh_idx = 0;
+    bool vis = false;
+    if (idx < n) {
+        if (!COMPRESSED) {
+            const uint4 c0 = b.planes[idx];
+            xyz[0] = __uint_as_float(c0.x);
+            xyz[1] = __uint_as_float(c0.y);
+            xyz[2] = __uint_as_float(c0.z);
+            w3 = c0.w;
+        } else {
+            // GaussianCompressed, 24 B (pointcloud.rs:14-22): three 8-B loads per lane
+            const uint2* g = reinterpret_cast<const uint2*>(b.gaussians_c + (size_t)idx * 24);
+            const uint2 a = g[0], bb = g[1], cc = g[2];
+            xyz[0] = __uint_as_float(a.x);
+            xyz[1] = __uint_as_float(a.y);
+            xyz[2] = __uint_as_float(bb.x);
+            w3 = bb.y;
+            geometry_idx = cc.x;
+            sh_idx = cc.y;
+        }
+        // world-space clip box (preprocess.wgsl:177-179)
+        bool keep = !(xyz[0] < p.rs.clip_min[0] || xyz[1] < p.rs.clip_min[1] || xyz[2] < p.rs.clip_min[2] ||
+                      xyz[0] > p.rs.clip_max[0] || xyz[1] > p.rs.clip_max[1] || xyz[2] > p.rs.clip_max[2]);
+        if (keep) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = VM(0, r) * xyz[0];
+                s += VM(1, r) * xyz[1];
+                s += VM(2, r) * xyz[2];
+                s += VM(3, r) * 1.0f;
+                camspace[r] = s;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = PM(0, r) * camspace[0];
+                s += PM(1, r) * camspace[1];
+                s += PM(2, r) * camspace[2];
+                s += PM(3, r) * camspace[3];
+                pos2d[r] = s;
+            }
+            const float bounds = 1.2f * pos2d[3];
+            const float z = pos2d[2] / pos2d[3];
+            bool culled;
+            if (!COMPRESSED)  // preprocess.wgsl:190-192
+                culled = z <= 0.0f || z >= 1.0f || pos2d[0] < -bounds || pos2d[0] > bounds || pos2d[1] < -bounds ||
+                         pos2d[1] > bounds;
+            else  // preprocess_compressed.wgsl:231
+                culled = z < 0.0f || z > 1.0f || pos2d[0] < -bounds || pos2d[0] > bounds || pos2d[1] < -bounds ||
+                         pos2d[1] > bounds;
+            vis = !culled;
+        }
+    }
+
+    // ---- ordered compaction, part 1: block aggregate, published as early as possible -------------
+    const unsigned long long vmask = __ballot(vis);
+    const uint32_t lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vmask, 0u));
+    if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(vmask);
+    __syncthreads();
+    uint32_t wave_off = 0, block_cnt = 0;
+#pragma unroll
+    for (int w = 0; w < K1_THREADS / 64; ++w) {
+        const uint32_t c = s_wave_cnt[w];
+        if (w < wave) wave_off += c;
+        block_cnt += c;
+    }
+    if (tid == 0) st_agent(b.block_status + bid, (bid == 0 ? LB_FLAG_INCL : LB_FLAG_AGG) | block_cnt);
+
+    // ---- heavy part, only for survivors -----------------------------------------------------------
+    SplatOut so;
+    so.w[0] = so.w[1] = so.w[2] = so.w[3] = so.w[4] = 0u;
+    so.key = 0u;
+    so.rect = make_uint2(1u, 0u);
+    if (vis) {
+        float cov6[6];
+        float opacity;
+        Sh16 sh;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sh.c[c][0] = sh.c[c][1] = sh.c[c][2] = 0.0f;
+        if (!COMPRESSED) {
+            opacity = h2f(w3);
+            const uint4 c1 = b.planes[(size_t)1 * n + idx];
+            cov6[0] = h2f(c1.x);
+            cov6[1] = h2f(c1.x >> 16);
+            cov6[2] = h2f(c1.y);
+            cov6[3] = h2f(c1.y >> 16);
+            cov6[4] = h2f(c1.z);
+            cov6[5] = h2f(c1.z >> 16);
+            // SH planes 2..7: 48 halves, element e = 3*coef + channel.  Only the planes the active
+            // degree needs are fetched: deg0 -> 1 plane, deg1 -> 2, deg2 -> 4, deg3 -> 6.
+            const uint32_t deg = p.rs.max_sh_deg;
+            const int nplanes = deg == 0u ? 1 : (deg == 1u ? 2 : (deg == 2u ? 4 : 6));
+            uint32_t hw[24];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (q < nplanes) v = b.planes[(size_t)(2 + q) * n + idx];
+                hw[q * 4 + 0] = v.x;
+                hw[q * 4 + 1] = v.y;
+                hw[q * 4 + 2] = v.z;
+                hw[q * 4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 48; ++e) sh.c[e / 3][e % 3] = h2f(hw[e / 2] >> ((e & 1) * 16));
+        } else {
+            // preprocess_compressed.wgsl:236-242
+            const int op_i8 = (int)(signed char)(w3 & 0xFFu);
+            const int sc_i8 = (int)(signed char)((w3 >> 8) & 0xFFu);
+            opacity = ((float)op_i8 - (float)p.quant.opacity.zero_point) * p.quant.opacity.scale;
+            const float scaling_factor =
+                expf(((float)sc_i8 - (float)p.quant.scaling_factor.zero_point) * p.quant.scaling_factor.scale);
+            const float s2 = scaling_factor * scaling_factor;
+            const uint32_t* cv = reinterpret_cast<const uint32_t*>(b.covars + (size_t)geometry_idx * 12);
+            const uint32_t c0 = cv[0], c1 = cv[1], c2 = cv[2];
+            cov6[0] = h2f(c0) * s2;
+            cov6[1] = h2f(c0 >> 16) * s2;
+            cov6[2] = h2f(c1) * s2;
+            cov6[3] = h2f(c1 >> 16) * s2;
+            cov6[4] = h2f(c2) * s2;
+            cov6[5] = h2f(c2 >> 16) * s2;
+            // int8 SH record: 3*(deg_layout+1)^2 bytes, packed back to back, NOT 4-aligned
+            // (preprocess_compressed.wgsl:147-171).  unpack4x8snorm(x)*127 maps -128 to -127.
+            const uint32_t ncoef = p.sh_deg_layout;
+            uint32_t use = (p.rs.max_sh_deg + 1u) * (p.rs.max_sh_deg + 1u);
+            if (use > ncoef) use = ncoef;
+            const signed char* rec = reinterpret_cast<const signed char*>(b.sh_bytes) + (size_t)3 * ((size_t)sh_idx * ncoef);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if ((uint32_t)c < use) {
+                    const float zp = (float)(c == 0 ? p.quant.color_dc.zero_point : p.quant.color_rest.zero_point);
+                    const float sc = (c == 0 ? p.quant.color_dc.scale : p.quant.color_rest.scale);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float raw = fmaxf((float)rec[c * 3 + j] / 127.0f, -1.0f) * 127.0f;
+                        sh.c[c][j] = (raw - zp) * sc;
+                    }
+                }
+            }
+        }
+        k1_math<COMPRESSED>(p, xyz, camspace, pos2d, opacity, cov6, sh, &so);
+    }
+
+    // ---- ordered compaction, part 2: look-back (wave 0) and scatter --------------------------------
+    if (wave == 0) {
+        const uint32_t excl = lookback_exclusive(b.block_status, bid, lane, &b.counters->overflow);
+        if (lane == 0) {
+            s_base = excl;
+            if (bid != 0) st_agent(b.block_status + bid, LB_FLAG_INCL | (excl + block_cnt));
+            if (bid == gridDim.x - 1) b.counters->num_visible = excl + block_cnt;
+        }
+    }
+    __syncthreads();
+    if (vis) {
+        const uint32_t slot = s_base + wave_off + lane_rank;
+        uint32_t* sp = reinterpret_cast<uint32_t*>(b.splats + (size_t)slot * 20);
+        sp[0] = so.w[0];
+        sp[1] = so.w[1];
+        sp[2] = so.w[2];
+        sp[3] = so.w[3];
+        sp[4] = so.w[4];
+        b.keys[slot] = so.key;
+        b.rects[slot] = so.rect;
+        if (b.src_index) b.src_index[slot] = idx;
+    }
+}
+
+}  // namespace
+
+uint32_t preprocess_blocks(uint32_t n) { return (n + K1_THREADS - 1) / K1_THREADS; }
+
+int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, hipStream_t stream) {
+    const uint32_t blocks = preprocess_blocks(p.num_points);
+    if (blocks == 0) return WS_OK;
+    if (compressed)
+        hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(K1_THREADS), 0, stream, p, b);
+    else
+        hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(K1_THREADS), 0, stream, p, b);
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
+}  // namespace ws

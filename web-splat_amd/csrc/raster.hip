@@ -1,0 +1,360 @@
+// raster.hip -- tile binning and per-tile front-to-back compositing for gfx950.
+//
+// Replaces the reference's instanced-quad draw + fixed-function blending:
+//   src/shaders/gaussian.wgsl:30-67 (vs_main / fs_main), src/renderer.rs:63-67 (PREMULTIPLIED_ALPHA_BLENDING),
+//   src/renderer.rs:250-260 (draw_indirect over the depth-sorted instances).
+// The reference lets the ROPs read-modify-write the render target once per covered pixel per splat, back to
+// front.  Here every 16x16 tile gets the list of splats that touch it (in the SAME depth order, produced by a
+// stable counting sort on the tile id of depth-ordered (tile, splat) entries) and one workgroup composites the
+// list front-to-back out of LDS, keeping colour and transmittance in registers and writing each pixel once.
+//
+//   k_bin_count   : per depth-sorted splat: gather its tile rectangle, count tiles, per-block sums
+//   k_bin_scan    : exclusive scan of the block sums (single block), total D -> FrameCounters
+//   k_bin_emit    : per block: scan its counts, emit (tile id, splat) entries, load-balanced through LDS
+//   (radix sort of the entries by tile id: sort.hip, 2 passes, stable -> depth order kept inside a tile)
+//   k_tile_ranges : [begin,end) of every tile in the sorted entry list
+//   k_blend       : 16x16 pixels per workgroup, splats staged through LDS 256 at a time, early-out on T
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "ws_internal.h"
+
+namespace ws {
+
+namespace {
+
+constexpr int BIN_THREADS = 256;
+constexpr int BIN_IPT = 8;                         // sorted splats per thread
+constexpr int BIN_ITEMS = BIN_THREADS * BIN_IPT;   // 2048 per block
+
+__device__ __forceinline__ float h2f(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)(h & 0xFFFFu))); }
+
+__device__ __forceinline__ uint32_t rect_count(uint2 r) {
+    const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu, y1 = r.y >> 16;
+    if (x0 > x1 || y0 > y1) return 0u;
+    return (x1 - x0 + 1u) * (y1 - y0 + 1u);
+}
+
+__device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v, uint32_t* s_tmp) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < BIN_THREADS / 64; ++w) t += s_tmp[w];
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t* s_tmp, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BIN_THREADS / 64; ++w) {
+        const uint32_t c = s_tmp[w];
+        if (w < wave) wave_off += c;
+        tot += c;
+    }
+    __syncthreads();
+    if (total) *total = tot;
+    return wave_off + incl - v;
+}
+
+// ---- k_bin_count: gather rects in draw order, write them contiguously, per-block tile totals ------------
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ sorted_idx,
+                                                          const uint2* __restrict__ rects,
+                                                          uint2* __restrict__ rects_sorted,
+                                                          uint32_t* __restrict__ block_sums,
+                                                          const FrameCounters* __restrict__ counters) {
+    __shared__ uint32_t s_tmp[BIN_THREADS / 64];
+    const uint32_t v = counters->num_visible;
+    const uint32_t base = blockIdx.x * BIN_ITEMS;
+    uint32_t sum = 0;
+    if (base < v) {
+#pragma unroll
+        for (int k = 0; k < BIN_IPT; ++k) {
+            const uint32_t i = base + k * BIN_THREADS + threadIdx.x;  // coalesced
+            if (i < v) {
+                const uint2 r = rects[sorted_idx[i]];
+                rects_sorted[i] = r;
+                sum += rect_count(r);
+            }
+        }
+    }
+    const uint32_t tot = block_reduce_sum(sum, s_tmp);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// ---- k_bin_scan: exclusive scan of block sums (one block), D -> counters -------------------------------
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__ block_sums, uint32_t nblocks,
+                                                         FrameCounters* __restrict__ counters, uint32_t entry_cap) {
+    __shared__ uint32_t s_tmp[BIN_THREADS / 64];
+    uint32_t running = 0;  // block-uniform
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += BIN_THREADS) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t c = b < nblocks ? block_sums[b] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan256(c, s_tmp, &tot);
+        if (b < nblocks) block_sums[b] = running + ex;
+        running += tot;
+        // NOTE: 32-bit totals; D above 2^32 is out of scope (capacity is a u32)
+    }
+    if (threadIdx.x == 0) {
+        if (running > entry_cap) {
+            counters->overflow |= 1u;
+            running = entry_cap;
+        }
+        counters->num_entries = running;
+    }
+}
+
+// ---- k_bin_emit: (tile id, splat) entries in draw order ---------------------------------------------
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __restrict__ sorted_idx,
+                                                         const uint2* __restrict__ rects_sorted,
+                                                         const uint32_t* __restrict__ block_offsets,
+                                                         uint32_t* __restrict__ entry_keys,
+                                                         uint32_t* __restrict__ entry_vals, uint32_t entry_cap,
+                                                         const FrameCounters* __restrict__ counters,
+                                                         uint32_t tiles_x) {
+    __shared__ uint32_t s_off[BIN_ITEMS + 1];
+    __shared__ uint2 s_rect[BIN_ITEMS];
+    __shared__ uint32_t s_idx[BIN_ITEMS];
+    __shared__ uint32_t s_tmp[BIN_THREADS / 64];
+
+    const uint32_t v = counters->num_visible;
+    const uint32_t base = blockIdx.x * BIN_ITEMS;
+    if (base >= v) return;
+    const uint32_t out_base = block_offsets[blockIdx.x];
+
+    // blocked arrangement: thread t owns items [t*IPT, t*IPT + IPT)
+    uint32_t cnt[BIN_IPT];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < BIN_IPT; ++k) {
+        const uint32_t li = threadIdx.x * BIN_IPT + k;
+        const uint32_t i = base + li;
+        uint2 r = make_uint2(1u, 0u);
+        uint32_t id = 0u;
+        if (i < v) {
+            r = rects_sorted[i];
+            id = sorted_idx[i];
+        }
+        s_rect[li] = r;
+        s_idx[li] = id;
+        cnt[k] = rect_count(r);
+        tsum += cnt[k];
+    }
+    uint32_t block_total;
+    uint32_t ex = block_exclusive_scan256(tsum, s_tmp, &block_total);
+#pragma unroll
+    for (int k = 0; k < BIN_IPT; ++k) {
+        s_off[threadIdx.x * BIN_IPT + k] = ex;
+        ex += cnt[k];
+    }
+    if (threadIdx.x == 0) s_off[BIN_ITEMS] = block_total;
+    __syncthreads();
+
+    // every thread produces entries e, e + 256, ...: find the owning item by binary search in LDS
+    for (uint32_t e = threadIdx.x; e < block_total; e += BIN_THREADS) {
+        uint32_t lo = 0, hi = BIN_ITEMS;  // largest item with s_off[item] <= e
+#pragma unroll
+        for (int step = 0; step < 11; ++step) {  // log2(2048)
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_off[mid] <= e) lo = mid; else hi = mid;
+        }
+        const uint2 r = s_rect[lo];
+        const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu;
+        const uint32_t w = x1 - x0 + 1u;
+        const uint32_t k = e - s_off[lo];
+        const uint32_t ty = y0 + k / w, tx = x0 + k % w;
+        const uint64_t g = (uint64_t)out_base + e;
+        if (g < entry_cap) {
+            entry_keys[g] = ty * tiles_x + tx;
+            entry_vals[g] = s_idx[lo];
+        }
+    }
+}
+
+// ---- k_tile_ranges ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict__ keys, uint2* __restrict__ ranges,
+                                                    const FrameCounters* __restrict__ counters, uint32_t ntiles) {
+    const uint32_t d = counters->num_entries;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < d; i += gridDim.x * 256) {
+        const uint32_t k = keys[i];
+        if (k >= ntiles) continue;  // cannot happen; guards the store
+        if (i == 0 || keys[i - 1] != k) ranges[k].x = i;
+        if (i == d - 1 || keys[i + 1] != k) ranges[k].y = i + 1;
+    }
+}
+
+// ---- k_blend ---------------------------------------------------------------------------------------
+// One workgroup = one 16x16 tile, one pixel per thread; wave w owns the 8x8 quadrant (w&1, w>>1).
+// Splats are staged through LDS 256 at a time in NEAR -> FAR order; a staged record carries the inverse of the
+// 2x2 screen-axes matrix so that a = |M^-1 (pixel - centre)|^2 is exactly gaussian.wgsl:60's
+// dot(screen_pos, screen_pos) with affinely interpolated screen_pos.
+template <int FORMAT>
+__global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
+    __shared__ float4 s_a[256];  // cx, cy, i00, i01
+    __shared__ float4 s_b[256];  // i10, i11, alpha, quadrant mask (bits)
+    __shared__ float4 s_c[256];  // r, g, b, -
+
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int qx = wave & 1, qy = wave >> 1;
+    const uint32_t px = tx * TILE + qx * 8 + (lane & 7);
+    const uint32_t py = ty * TILE + qy * 8 + (lane >> 3);
+    const bool inside = px < p.width && py < p.height;
+    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    const uint32_t qbit = 1u << wave;
+
+    const uint2 range = p.tile_ranges[tile];
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    bool done = !inside;
+    const float W = (float)p.width, H = (float)p.height;
+    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
+
+    for (uint32_t hi = range.y; hi > range.x;) {
+        const uint32_t nb = (hi - range.x) < 256u ? (hi - range.x) : 256u;
+        if ((uint32_t)tid < nb) {
+            const uint32_t idx = p.entry_vals[hi - 1u - (uint32_t)tid];  // staged slot 0 = nearest
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx * 20);
+            const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3], w4 = sp[4];
+            const float v1x = h2f(w0), v1y = h2f(w0 >> 16), v2x = h2f(w1), v2y = h2f(w1 >> 16);
+            const float m00 = v1x * W, m01 = v2x * W;
+            const float m10 = -v1y * H, m11 = -v2y * H;
+            const float det = m00 * m11 - m01 * m10;
+            const float inv = 1.0f / det;
+            const float cx = (h2f(w2) * 0.5f + 0.5f) * W;
+            const float cy = (0.5f - h2f(w2 >> 16) * 0.5f) * H;
+            // quadrant mask from the padded bounding box of the kept ellipse (same padding as K1's rect)
+            const float rad = 2.1697873f * 1.00001f;
+            const float exx = rad * sqrtf(m00 * m00 + m01 * m01) + 1e-3f;
+            const float eyy = rad * sqrtf(m10 * m10 + m11 * m11) + 1e-3f;
+            uint32_t mask = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x_lo = tile_x0 + (float)((q & 1) * 8) + 0.5f, x_hi = x_lo + 7.0f;
+                const float y_lo = tile_y0 + (float)((q >> 1) * 8) + 0.5f, y_hi = y_lo + 7.0f;
+                if (cx + exx >= x_lo && cx - exx <= x_hi && cy + eyy >= y_lo && cy - eyy <= y_hi) mask |= 1u << q;
+            }
+            s_a[tid] = make_float4(cx, cy, m11 * inv, -m01 * inv);
+            s_b[tid] = make_float4(-m10 * inv, m00 * inv, h2f(w4 >> 16), __uint_as_float(mask));
+            s_c[tid] = make_float4(h2f(w3), h2f(w3 >> 16), h2f(w4), 0.0f);
+        }
+        __syncthreads();
+        for (uint32_t k = 0; k < nb; ++k) {
+            const float4 b4 = s_b[k];
+            if (!(__float_as_uint(b4.w) & qbit)) continue;  // wave-uniform
+            const float4 a4 = s_a[k];
+            const float dx = fx - a4.x, dy = fy - a4.y;
+            const float p0 = a4.z * dx + a4.w * dy;
+            const float p1 = b4.x * dx + b4.y * dy;
+            const float a = p0 * p0 + p1 * p1;
+            if (a <= CUT_A && !done) {
+                const float4 c4 = s_c[k];
+                const float b = fminf(0.99f, __expf(-a) * b4.z);
+                const float wgt = b * T;
+                cr += wgt * c4.x;
+                cg += wgt * c4.y;
+                cb += wgt * c4.z;
+                T *= (1.0f - b);
+                if (T < T_MIN) done = true;
+            }
+        }
+        hi -= nb;
+        if (__syncthreads_and(done ? 1 : 0)) break;
+    }
+
+    if (inside) {
+        // begin_render_pass(clear = background) then "over": dst = src + dst * (1 - src.a), all four channels
+        const float r = cr + p.background[0] * T;
+        const float g = cg + p.background[1] * T;
+        const float b = cb + p.background[2] * T;
+        const float al = (1.0f - T) + p.background[3] * T;
+        char* row = reinterpret_cast<char*>(p.out) + (size_t)py * p.pitch;
+        if (FORMAT == WS_FORMAT_RGBA32_FLOAT) {
+            reinterpret_cast<float4*>(row)[px] = make_float4(r, g, b, al);
+        } else if (FORMAT == WS_FORMAT_RGBA16_FLOAT) {
+            const uint32_t lo = (uint32_t)__half_as_ushort(__float2half_rn(r)) | ((uint32_t)__half_as_ushort(__float2half_rn(g)) << 16);
+            const uint32_t hi2 = (uint32_t)__half_as_ushort(__float2half_rn(b)) | ((uint32_t)__half_as_ushort(__float2half_rn(al)) << 16);
+            reinterpret_cast<uint2*>(row)[px] = make_uint2(lo, hi2);
+        } else {
+            auto q8 = [](float v) -> uint32_t {
+                v = fminf(fmaxf(v, 0.0f), 1.0f);
+                return (uint32_t)__float2int_rn(v * 255.0f);
+            };
+            reinterpret_cast<uint32_t*>(row)[px] = q8(r) | (q8(g) << 8) | (q8(b) << 16) | (q8(al) << 24);
+        }
+    }
+}
+
+}  // namespace
+
+static uint32_t bin_blocks(uint32_t max_points) { return (max_points + BIN_ITEMS - 1) / BIN_ITEMS; }
+
+// counts buffer doubles as the depth-ordered rect list (uint2 per sorted position): see ws_api.cpp
+int launch_bin_count_scan(const BinBuffers& b, hipStream_t stream) {
+    const uint32_t blocks = bin_blocks(b.max_points);
+    if (blocks == 0) return WS_OK;
+    hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx, b.rects,
+                       reinterpret_cast<uint2*>(b.counts), b.block_sums, b.counters);
+    WS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(BIN_THREADS), 0, stream, b.block_sums, blocks, b.counters, b.entry_cap);
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
+int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
+    const uint32_t blocks = bin_blocks(b.max_points);
+    if (blocks == 0) return WS_OK;
+    hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx,
+                       reinterpret_cast<const uint2*>(b.counts), b.block_sums, b.entry_keys, b.entry_vals, b.entry_cap,
+                       b.counters, b.tiles_x);
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
+int launch_tile_ranges(const uint32_t* sorted_keys, const BinBuffers& b, hipStream_t stream) {
+    const uint32_t ntiles = b.tiles_x * b.tiles_y;
+    WS_HIP(hipMemsetAsync(b.tile_ranges, 0, (size_t)ntiles * sizeof(uint2), stream));
+    uint32_t blocks = (b.entry_cap + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_tile_ranges, dim3(blocks), dim3(256), 0, stream, sorted_keys, b.tile_ranges, b.counters, ntiles);
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
+int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
+    (void)variant;
+    const uint32_t ntiles = p.tiles_x * p.tiles_y;
+    if (ntiles == 0) return WS_OK;
+    switch (p.format) {
+        case WS_FORMAT_RGBA32_FLOAT:
+            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA32_FLOAT>, dim3(ntiles), dim3(256), 0, stream, p);
+            break;
+        case WS_FORMAT_RGBA16_FLOAT:
+            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA16_FLOAT>, dim3(ntiles), dim3(256), 0, stream, p);
+            break;
+        case WS_FORMAT_RGBA8_UNORM:
+            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA8_UNORM>, dim3(ntiles), dim3(256), 0, stream, p);
+            break;
+        default:
+            return fail(WS_ERR_INVALID, "blend: unknown colour format");
+    }
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
+}  // namespace ws

@@ -1,0 +1,356 @@
+// sort.hip -- stable ascending LSD radix sort of (u32 key, u32 value) pairs for gfx950.
+//
+// Replaces GPURSSorter (src/gpu_rs.rs:63-885) and src/shaders/radix_sort.wgsl:48-512 of the reference:
+// same contract (ascending, stable, 8-bit digits, key count read from device memory), new design:
+//
+//   * one-sweep: one histogram pass over the keys for ALL digits, then one pass per digit that reads
+//     and writes every pair exactly once; the cross-tile prefix comes from a decoupled look-back over
+//     32-bit {flag,count} words (one per tile and digit) read/written with agent-scope atomics, so it
+//     is correct for any placement of tiles on the 8 XCDs (each XCD has its own L2).
+//   * work tiles are handed out by an atomic ticket, so a tile only ever waits on tiles that have
+//     already started -- no dependence on dispatch order.
+//   * ranking inside a wave uses wave64 ballots (8 per key) instead of the reference's O(subgroup)
+//     shared-memory match loop (radix_sort.wgsl:279-302), plus per-wave LDS digit counters.
+//   * keys and values are reordered through LDS so that global writes are contiguous per digit run.
+//   * tile = 256 threads x 16 keys = 4096 pairs (the reference uses 3840, gpu_rs.rs:14-21).
+//
+// A second, look-back-free path (per-tile histograms -> column scan -> scatter) is kept selectable
+// (algo 0) as an independent cross-check of the one-sweep path.
+#include <hip/hip_runtime.h>
+
+#include "ws_internal.h"
+
+namespace ws {
+
+namespace {
+
+constexpr uint32_t FLAG_AGG = 1u << 30;
+constexpr uint32_t FLAG_INCL = 2u << 30;
+constexpr uint32_t VALUE_MASK = (1u << 30) - 1u;
+constexpr uint32_t SPIN_LIMIT = 1u << 24;
+constexpr int WAVES = SORT_THREADS / 64;
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t device_count(const uint32_t* d_count, uint32_t n) {
+    if (!d_count) return n;
+    const uint32_t c = *d_count;
+    return c < n ? c : n;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; `total` optional
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_tmp /*[WAVES]*/, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = s_tmp[w];
+        if (w < wave) wave_off += c;
+        tot += c;
+    }
+    __syncthreads();  // s_tmp reusable
+    if (total) *total = tot;
+    return wave_off + incl - v;
+}
+
+// ---- histogram of every participating digit in one read of the keys -----------------------------
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys,
+                                                           const uint32_t* __restrict__ d_count, uint32_t n,
+                                                           int begin_bit, int npass, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t sh[4 * RADIX];
+    for (int i = threadIdx.x; i < 4 * RADIX; i += SORT_THREADS) sh[i] = 0u;
+    __syncthreads();
+    const uint32_t count = device_count(d_count, n);
+    const uint32_t count4 = count >> 2;
+    const uint4* keys4 = reinterpret_cast<const uint4*>(keys);
+    for (uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x; i < count4; i += gridDim.x * SORT_THREADS) {
+        const uint4 k = keys4[i];
+        for (int p = 0; p < npass; ++p) {
+            const int sft = begin_bit + p * RADIX_BITS;
+            atomicAdd(&sh[p * RADIX + ((k.x >> sft) & (RADIX - 1))], 1u);
+            atomicAdd(&sh[p * RADIX + ((k.y >> sft) & (RADIX - 1))], 1u);
+            atomicAdd(&sh[p * RADIX + ((k.z >> sft) & (RADIX - 1))], 1u);
+            atomicAdd(&sh[p * RADIX + ((k.w >> sft) & (RADIX - 1))], 1u);
+        }
+    }
+    if (blockIdx.x == 0) {
+        const uint32_t i = (count4 << 2) + threadIdx.x;
+        if (i < count) {
+            const uint32_t k = keys[i];
+            for (int p = 0; p < npass; ++p) atomicAdd(&sh[p * RADIX + ((k >> (begin_bit + p * RADIX_BITS)) & (RADIX - 1))], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < npass * RADIX; i += SORT_THREADS) {
+        const uint32_t c = sh[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
+}
+
+// ---- per-tile digit histogram (algo 0) ------------------------------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ d_count, uint32_t n,
+                                                                int shift, uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t sh[RADIX];
+    const uint32_t count = device_count(d_count, n);
+    const uint32_t t = blockIdx.x;
+    if ((uint64_t)t * SORT_TILE >= count) return;
+    sh[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = t * SORT_TILE;
+#pragma unroll 4
+    for (int j = 0; j < SORT_KPT; ++j) {
+        const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
+        if (pos < count) atomicAdd(&sh[(keys[pos] >> shift) & (RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    tile_sums[(size_t)t * RADIX + threadIdx.x] = sh[threadIdx.x];
+}
+
+// column scan: tile_sums[t][d] -> global exclusive offset of (tile t, digit d)   (algo 0, one block)
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_scan(const uint32_t* __restrict__ d_count, uint32_t n,
+                                                                uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t s_tmp[WAVES];
+    const uint32_t count = device_count(d_count, n);
+    const uint32_t ntiles = (count + SORT_TILE - 1) / SORT_TILE;
+    const uint32_t d = threadIdx.x;
+    uint32_t total = 0;
+    for (uint32_t t = 0; t < ntiles; ++t) total += tile_sums[(size_t)t * RADIX + d];
+    uint32_t running = block_exclusive_scan(total, s_tmp, nullptr);
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const uint32_t c = tile_sums[(size_t)t * RADIX + d];
+        tile_sums[(size_t)t * RADIX + d] = running;
+        running += c;
+    }
+}
+
+// ---- one digit pass: rank, look-back (or precomputed offsets), LDS reorder, scatter ----------------
+template <bool LOOKBACK>
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ d_count, uint32_t n, int shift, int iota,
+    const uint32_t* __restrict__ hist,     // [256] global digit histogram of this pass      (LOOKBACK)
+    uint32_t* __restrict__ status,         // [tiles][256] look-back words, zeroed           (LOOKBACK)
+    uint32_t* __restrict__ ticket,         // tile dispenser, zeroed                         (LOOKBACK)
+    const uint32_t* __restrict__ tile_off, // [tiles][256] global exclusive offsets          (!LOOKBACK)
+    uint32_t* __restrict__ error_word) {
+    __shared__ uint32_t s_wave_hist[WAVES][RADIX];
+    __shared__ uint32_t s_local_excl[RADIX];
+    __shared__ uint32_t s_global_base[RADIX];
+    __shared__ uint32_t s_data[SORT_TILE];
+    __shared__ uint32_t s_tmp[WAVES];
+    __shared__ uint32_t s_tile;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    if (LOOKBACK) {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+        __syncthreads();
+    }
+    const uint32_t t = LOOKBACK ? s_tile : blockIdx.x;
+    const uint32_t count = device_count(d_count, n);
+    if ((uint64_t)t * SORT_TILE >= count) return;  // block-uniform
+    const uint32_t tile_base = t * SORT_TILE;
+    const uint32_t valid = (count - tile_base) < (uint32_t)SORT_TILE ? (count - tile_base) : (uint32_t)SORT_TILE;
+
+    // ---- load (wave-striped: consecutive lanes read consecutive keys; order = (wave, j, lane)) ------
+    uint32_t key[SORT_KPT];
+    uint32_t val[SORT_KPT];
+    const uint32_t wave_base = tile_base + wave * (64 * SORT_KPT) + lane;
+#pragma unroll
+    for (int j = 0; j < SORT_KPT; ++j) {
+        const uint32_t pos = wave_base + j * 64;
+        key[j] = pos < count ? keys_in[pos] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int j = 0; j < SORT_KPT; ++j) {
+        const uint32_t pos = wave_base + j * 64;
+        val[j] = iota ? pos : (pos < count ? vals_in[pos] : 0u);
+    }
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) s_wave_hist[w][tid] = 0u;
+    __syncthreads();
+
+    // ---- rank inside the wave with ballots; per-wave digit counters live in LDS ---------------------
+    uint32_t rank[SORT_KPT];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < SORT_KPT; ++j) {
+        const uint32_t d = (key[j] >> shift) & (RADIX - 1);
+        unsigned long long m = ~0ull;
+#pragma unroll
+        for (int bit = 0; bit < RADIX_BITS; ++bit) {
+            const bool b = (d >> bit) & 1u;
+            const unsigned long long bal = __ballot(b);
+            m &= b ? bal : ~bal;
+        }
+        const uint32_t below = (uint32_t)__popcll(m & lt_mask);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t prev = 0u;
+        if (lane == leader) {
+            prev = s_wave_hist[wave][d];
+            s_wave_hist[wave][d] = prev + cnt;
+        }
+        prev = __shfl(prev, leader, 64);
+        rank[j] = prev + below;
+    }
+    __syncthreads();
+
+    // ---- per digit (thread d = digit d): prefix over waves, tile count --------------------------------
+    uint32_t tile_cnt = 0;
+    {
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t c = s_wave_hist[w][tid];
+            s_wave_hist[w][tid] = tile_cnt;
+            tile_cnt += c;
+        }
+    }
+    const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp, nullptr);
+    s_local_excl[tid] = local_excl;
+
+    uint32_t global_base;  // global position of the first key of digit `tid` coming from this tile
+    if (LOOKBACK) {
+        const uint32_t digit_base = block_exclusive_scan(hist[tid], s_tmp, nullptr);
+        // padding keys (0xFFFFFFFF, digit 255 in every pass) are ranked last and never published
+        const uint32_t pub_cnt = tile_cnt - ((tid == RADIX - 1) ? ((uint32_t)SORT_TILE - valid) : 0u);
+        uint32_t* my_status = status + (size_t)t * RADIX + tid;
+        st_agent(my_status, (t == 0 ? FLAG_INCL : FLAG_AGG) | pub_cnt);
+        uint32_t prev_sum = 0;
+        if (t > 0) {
+            int64_t i = (int64_t)t - 1;
+            uint32_t spins = 0;
+            while (true) {
+                const uint32_t w = ld_agent(status + (size_t)i * RADIX + tid);
+                const uint32_t flag = w >> 30;
+                if (flag == 0u) {
+                    if (++spins > SPIN_LIMIT) {
+                        if (error_word) atomicOr(error_word, 4u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                prev_sum += w & VALUE_MASK;
+                if (flag == 2u) break;
+                --i;
+            }
+            st_agent(my_status, FLAG_INCL | (prev_sum + pub_cnt));
+        }
+        global_base = digit_base + prev_sum;
+    } else {
+        global_base = tile_off[(size_t)t * RADIX + tid];
+    }
+    s_global_base[tid] = global_base - local_excl;  // add the tile-local position to get the address
+    __syncthreads();
+
+    // ---- reorder keys through LDS, write contiguous digit runs ----------------------------------------
+    uint32_t lpos[SORT_KPT];
+#pragma unroll
+    for (int j = 0; j < SORT_KPT; ++j) {
+        const uint32_t d = (key[j] >> shift) & (RADIX - 1);
+        lpos[j] = s_local_excl[d] + s_wave_hist[wave][d] + rank[j];
+        s_data[lpos[j]] = key[j];
+    }
+    __syncthreads();
+    uint32_t gpos[SORT_KPT];
+#pragma unroll
+    for (int k = 0; k < SORT_KPT; ++k) {
+        const uint32_t lp = k * SORT_THREADS + tid;
+        const uint32_t kk = s_data[lp];
+        const uint32_t d = (kk >> shift) & (RADIX - 1);
+        gpos[k] = s_global_base[d] + lp;
+        if (lp < valid) keys_out[gpos[k]] = kk;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SORT_KPT; ++j) s_data[lpos[j]] = val[j];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SORT_KPT; ++k) {
+        const uint32_t lp = k * SORT_THREADS + tid;
+        if (lp < valid) vals_out[gpos[k]] = s_data[lp];
+    }
+}
+
+}  // namespace
+
+size_t sort_status_words(uint32_t cap) {
+    const size_t tiles = ((size_t)cap + SORT_TILE - 1) / SORT_TILE;
+    return 4 * (tiles ? tiles : 1) * RADIX;
+}
+
+int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
+                      int begin_bit, int end_bit, bool implicit_iota, int algo, hipStream_t stream,
+                      uint32_t** out_keys, uint32_t** out_vals) {
+    if (out_keys) *out_keys = keys;
+    if (out_vals) *out_vals = vals;
+    if (n == 0) return WS_OK;
+    if (n > sc.cap) return fail(WS_ERR_INVALID, "sort: n exceeds the scratch capacity");
+    if ((begin_bit % RADIX_BITS) || (end_bit % RADIX_BITS) || begin_bit < 0 || end_bit > 32 || begin_bit >= end_bit)
+        return fail(WS_ERR_INVALID, "sort: bit range must be non-empty multiples of 8 within [0,32]");
+    if ((reinterpret_cast<uintptr_t>(keys) & 15u) != 0) return fail(WS_ERR_INVALID, "sort: keys must be 16-byte aligned");
+    const int npass = (end_bit - begin_bit) / RADIX_BITS;
+    const uint32_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
+
+    uint32_t* kin = keys;
+    uint32_t* vin = vals;
+    uint32_t* kout = sc.keys_alt;
+    uint32_t* vout = sc.vals_alt;
+
+    if (algo == 1) {
+        WS_HIP(hipMemsetAsync(sc.hist, 0, 4 * RADIX * sizeof(uint32_t), stream));
+        WS_HIP(hipMemsetAsync(sc.status, 0, (size_t)npass * sc.tiles * RADIX * sizeof(uint32_t), stream));
+        WS_HIP(hipMemsetAsync(sc.tickets, 0, 4 * sizeof(uint32_t), stream));
+        uint32_t hist_blocks = (n / 4 + SORT_THREADS * 8 - 1) / (SORT_THREADS * 8);
+        if (hist_blocks < 1) hist_blocks = 1;
+        if (hist_blocks > 2048) hist_blocks = 2048;
+        hipLaunchKernelGGL(k_sort_hist, dim3(hist_blocks), dim3(SORT_THREADS), 0, stream, kin, d_count, n, begin_bit,
+                           npass, sc.hist);
+        WS_HIP(hipGetLastError());
+    }
+    for (int p = 0; p < npass; ++p) {
+        const int shift = begin_bit + p * RADIX_BITS;
+        const int iota = (implicit_iota && p == 0) ? 1 : 0;
+        if (algo == 1) {
+            hipLaunchKernelGGL(k_sort_scatter<true>, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout,
+                               d_count, n, shift, iota, sc.hist + p * RADIX, sc.status + (size_t)p * sc.tiles * RADIX,
+                               sc.tickets + p, (const uint32_t*)nullptr, sc.error);
+        } else {
+            hipLaunchKernelGGL(k_sort_tile_hist, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift,
+                               sc.tile_sums);
+            hipLaunchKernelGGL(k_sort_tile_scan, dim3(1), dim3(SORT_THREADS), 0, stream, d_count, n, sc.tile_sums);
+            hipLaunchKernelGGL(k_sort_scatter<false>, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout,
+                               d_count, n, shift, iota, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                               (uint32_t*)nullptr, sc.tile_sums, (uint32_t*)nullptr);
+        }
+        WS_HIP(hipGetLastError());
+        uint32_t* tk = kin;
+        kin = kout;
+        kout = tk;
+        uint32_t* tv = vin;
+        vin = vout;
+        vout = tv;
+    }
+    if (out_keys) *out_keys = kin;
+    if (out_vals) *out_vals = vin;
+    return WS_OK;
+}
+
+}  // namespace ws

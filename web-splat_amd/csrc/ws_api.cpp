@@ -1,0 +1,725 @@
+// ws_api.cpp -- the C ABI (include/websplat.h): handles, device memory, frame orchestration.
+//
+// Mirrors the reference's object model: WGPUContext (lib.rs:57-125) -> ws_context,
+// PointCloud (pointcloud.rs:72-222) -> ws_pointcloud, GaussianRenderer (renderer.rs:17-283) -> ws_renderer,
+// GPURSSorter + PointCloudSortStuff (gpu_rs.rs:23-175, 865-884) -> ws_sorter.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ws_internal.h"
+
+namespace ws {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? WS_ERR_OOM : WS_ERR_HIP;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
+
+template <typename T>
+static int dmalloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    WS_HIP(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return WS_OK;
+}
+template <typename T>
+static void dfree(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+}  // namespace ws
+
+using namespace ws;
+
+struct ws_sorter {
+    ws_context* ctx = nullptr;
+    SortScratch sc;
+    uint32_t* error = nullptr;
+};
+
+struct ws_renderer {
+    ws_context* ctx = nullptr;
+    ws_color_format format = WS_FORMAT_RGBA32_FLOAT;
+    uint32_t sh_deg = 3;
+    bool compressed = false;
+
+    // scratch, (re)created when num_points or the viewport changes (renderer.rs:200-211)
+    uint32_t cap_points = 0;
+    uint32_t vw = 0, vh = 0, tiles_x = 0, tiles_y = 0;
+    uint64_t entry_cap_request = 0;
+    uint32_t entry_cap = 0;
+    uint8_t* splats = nullptr;      // Splat[N], 20 B each (pointcloud.rs:103-108 allocates it in PointCloud;
+                                    // here it is per renderer so that renderers never share scratch)
+    uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
+    uint2* rects = nullptr;
+    uint2* rects_sorted = nullptr;
+    uint32_t* src_index = nullptr;
+    uint32_t* block_status = nullptr;
+    uint32_t* bin_block_sums = nullptr;
+    uint32_t *ekeys_a = nullptr, *ekeys_b = nullptr, *evals_a = nullptr, *evals_b = nullptr;
+    uint2* tile_ranges = nullptr;
+    FrameCounters* counters = nullptr;
+    SortScratch sort_depth, sort_tiles;
+
+    // last prepared frame
+    bool prepared = false;
+    const ws_pointcloud* prepared_pc = nullptr;
+    uint32_t* sorted_idx = nullptr;
+    uint32_t* entries_sorted = nullptr;
+    hipStream_t last_stream = nullptr;
+
+    bool capture = false;
+    bool timers = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_prepare_valid = false, ev_render_valid = false;
+};
+
+static void free_sort_scratch(SortScratch& sc, bool own_alt) {
+    if (own_alt) {
+        dfree(sc.keys_alt);
+        dfree(sc.vals_alt);
+    }
+    dfree(sc.hist);
+    dfree(sc.status);
+    dfree(sc.tile_sums);
+    sc = SortScratch();
+}
+
+static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, uint32_t* tickets) {
+    sc.cap = cap;
+    sc.tiles = (cap + SORT_TILE - 1) / SORT_TILE;
+    if (sc.tiles == 0) sc.tiles = 1;
+    int rc;
+    if (own_alt) {
+        if ((rc = dmalloc(&sc.keys_alt, (size_t)cap + 4))) return rc;
+        if ((rc = dmalloc(&sc.vals_alt, (size_t)cap + 4))) return rc;
+    }
+    if ((rc = dmalloc(&sc.hist, 4 * RADIX))) return rc;
+    if ((rc = dmalloc(&sc.status, 4 * (size_t)sc.tiles * RADIX))) return rc;
+    if ((rc = dmalloc(&sc.tile_sums, (size_t)sc.tiles * RADIX))) return rc;
+    sc.tickets = tickets;
+    return WS_OK;
+}
+
+static void renderer_free_scratch(ws_renderer* r) {
+    dfree(r->splats);
+    dfree(r->keys_a);
+    dfree(r->keys_b);
+    dfree(r->vals_a);
+    dfree(r->vals_b);
+    dfree(r->rects);
+    dfree(r->rects_sorted);
+    dfree(r->src_index);
+    dfree(r->block_status);
+    dfree(r->bin_block_sums);
+    dfree(r->ekeys_a);
+    dfree(r->ekeys_b);
+    dfree(r->evals_a);
+    dfree(r->evals_b);
+    dfree(r->tile_ranges);
+    dfree(r->counters);
+    free_sort_scratch(r->sort_depth, false);
+    free_sort_scratch(r->sort_tiles, false);
+    r->cap_points = 0;
+    r->vw = r->vh = 0;
+    r->prepared = false;
+}
+
+static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint32_t vh) {
+    uint64_t want_cap = r->entry_cap_request;
+    if (want_cap == 0) {
+        // automatic: 24 tile entries per Gaussian, at least 8 M -- 288 GB of HBM make this a non-issue
+        // (16 B per entry: 1.2 M Gaussians -> 0.46 GB, 5 M -> 1.9 GB)
+        want_cap = std::max<uint64_t>(8ull << 20, 24ull * n);
+    }
+    want_cap = std::min<uint64_t>(want_cap, 0xFFFFF000ull);
+    if (r->cap_points == n && r->vw == vw && r->vh == vh && r->entry_cap == (uint32_t)want_cap && r->counters) return WS_OK;
+    WS_HIP(hipDeviceSynchronize());
+    renderer_free_scratch(r);
+    int rc;
+    const size_t np = (size_t)n + 4;
+    if ((rc = dmalloc(&r->splats, np * 20))) return rc;
+    if ((rc = dmalloc(&r->keys_a, np))) return rc;
+    if ((rc = dmalloc(&r->keys_b, np))) return rc;
+    if ((rc = dmalloc(&r->vals_a, np))) return rc;
+    if ((rc = dmalloc(&r->vals_b, np))) return rc;
+    if ((rc = dmalloc(&r->rects, np))) return rc;
+    if ((rc = dmalloc(&r->rects_sorted, np))) return rc;
+    if ((rc = dmalloc(&r->src_index, np))) return rc;
+    if ((rc = dmalloc(&r->block_status, (size_t)preprocess_blocks(n) + 1))) return rc;
+    if ((rc = dmalloc(&r->bin_block_sums, (size_t)n / 2048 + 2))) return rc;
+    r->entry_cap = (uint32_t)want_cap;
+    const size_t ne = (size_t)r->entry_cap + 4;
+    if ((rc = dmalloc(&r->ekeys_a, ne))) return rc;
+    if ((rc = dmalloc(&r->ekeys_b, ne))) return rc;
+    if ((rc = dmalloc(&r->evals_a, ne))) return rc;
+    if ((rc = dmalloc(&r->evals_b, ne))) return rc;
+    r->tiles_x = (vw + TILE - 1) / TILE;
+    r->tiles_y = (vh + TILE - 1) / TILE;
+    if ((rc = dmalloc(&r->tile_ranges, (size_t)r->tiles_x * r->tiles_y))) return rc;
+    if ((rc = dmalloc(&r->counters, 1))) return rc;
+    WS_HIP(hipMemset(r->counters, 0, sizeof(FrameCounters)));
+    if ((rc = alloc_sort_scratch(r->sort_depth, n ? n : 1, false, nullptr))) return rc;
+    r->sort_depth.keys_alt = r->keys_b;
+    r->sort_depth.vals_alt = r->vals_b;
+    if ((rc = alloc_sort_scratch(r->sort_tiles, r->entry_cap, false, nullptr))) return rc;
+    r->sort_tiles.keys_alt = r->ekeys_b;
+    r->sort_tiles.vals_alt = r->evals_b;
+    r->sort_depth.tickets = r->counters->sort_ticket;
+    r->sort_tiles.tickets = r->counters->sort_ticket + 4;
+    r->sort_depth.error = &r->counters->overflow;
+    r->sort_tiles.error = &r->counters->overflow;
+    r->cap_points = n;
+    r->vw = vw;
+    r->vh = vh;
+    return WS_OK;
+}
+
+extern "C" {
+
+const char* ws_last_error(void) { return g_last_error.c_str(); }
+uint32_t ws_abi_version(void) { return WS_ABI_VERSION; }
+
+// ---- context ---------------------------------------------------------------------------------------
+int ws_context_create(int hip_device, ws_context** out) {
+    if (!out) return fail(WS_ERR_INVALID, "ws_context_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        return fail(WS_ERR_HIP, "ws_context_create: no HIP device available (this library has no CPU fallback)");
+    }
+    if (hip_device < 0 || hip_device >= count) return fail(WS_ERR_INVALID, "ws_context_create: bad device index");
+    WS_HIP(hipSetDevice(hip_device));
+    ws_context* ctx = new (std::nothrow) ws_context();
+    if (!ctx) return fail(WS_ERR_OOM, "ws_context_create: host allocation failed");
+    ctx->device = hip_device;
+    WS_HIP(hipGetDeviceProperties(&ctx->props, hip_device));
+    ctx->sort_algo = env_int("WS_SORT_ALGO", 1);
+    ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
+    *out = ctx;
+    return WS_OK;
+}
+
+void ws_context_destroy(ws_context* ctx) { delete ctx; }
+
+int ws_sync(ws_context* ctx, void* stream) {
+    if (!ctx) return fail(WS_ERR_INVALID, "ws_sync: null context");
+    WS_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return WS_OK;
+}
+
+int ws_device_info(ws_context* ctx, char* name, size_t name_len, uint32_t* num_cus, uint64_t* hbm_bytes) {
+    if (!ctx) return fail(WS_ERR_INVALID, "ws_device_info: null context");
+    if (name && name_len) {
+        std::strncpy(name, ctx->props.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (num_cus) *num_cus = (uint32_t)ctx->props.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)ctx->props.totalGlobalMem;
+    return WS_OK;
+}
+
+int ws_device_malloc(ws_context* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return fail(WS_ERR_INVALID, "ws_device_malloc: null argument");
+    WS_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return WS_OK;
+}
+int ws_device_free(ws_context* ctx, void* d_ptr) {
+    if (!ctx) return fail(WS_ERR_INVALID, "ws_device_free: null context");
+    if (d_ptr) WS_HIP(hipFree(d_ptr));
+    return WS_OK;
+}
+int ws_memcpy_h2d(ws_context* ctx, void* d_dst, const void* h_src, size_t bytes, void* stream) {
+    if (!ctx || (!d_dst && bytes) || (!h_src && bytes)) return fail(WS_ERR_INVALID, "ws_memcpy_h2d: null argument");
+    WS_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    WS_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return WS_OK;
+}
+int ws_memcpy_d2h(ws_context* ctx, void* h_dst, const void* d_src, size_t bytes, void* stream) {
+    if (!ctx || (!h_dst && bytes) || (!d_src && bytes)) return fail(WS_ERR_INVALID, "ws_memcpy_d2h: null argument");
+    WS_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    WS_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return WS_OK;
+}
+
+// ---- PointCloud --------------------------------------------------------------------------------------
+int ws_pointcloud_create(ws_context* ctx, const ws_pointcloud_desc* d, ws_pointcloud** out) {
+    if (!ctx || !d || !out) return fail(WS_ERR_INVALID, "ws_pointcloud_create: null argument");
+    *out = nullptr;
+    if (d->sh_deg > 3) return fail(WS_ERR_UNSUPPORTED, "ws_pointcloud_create: sh_deg > 3");
+    const uint32_t n = d->num_points;
+    if (n == 0) return fail(WS_ERR_INVALID, "ws_pointcloud_create: empty point cloud");
+    if (n >= (1u << 30)) return fail(WS_ERR_UNSUPPORTED, "ws_pointcloud_create: more than 2^30-1 points");
+    if (!d->gaussians || !d->sh_coefs) return fail(WS_ERR_INVALID, "ws_pointcloud_create: missing buffers");
+    ws_pointcloud* pc = new (std::nothrow) ws_pointcloud();
+    if (!pc) return fail(WS_ERR_OOM, "ws_pointcloud_create: host allocation failed");
+    pc->ctx = ctx;
+    pc->num_points = n;
+    pc->sh_deg = d->sh_deg;
+    pc->compressed = d->compressed != 0;
+    pc->bbox = d->bbox;
+    std::memcpy(pc->center, d->center, sizeof pc->center);
+    pc->has_up = d->has_up != 0;
+    std::memcpy(pc->up, d->up, sizeof pc->up);
+    pc->has_mip = d->has_mip_splatting != 0;
+    pc->mip = d->mip_splatting != 0;
+    pc->has_kernel_size = d->has_kernel_size != 0;
+    pc->kernel_size = d->kernel_size;
+    pc->has_background = d->has_background_color != 0;
+    std::memcpy(pc->background, d->background_color, sizeof pc->background);
+    int rc = WS_OK;
+    if (!pc->compressed) {
+        if (d->gaussians_bytes != (size_t)n * 28 || d->sh_coefs_bytes != (size_t)n * 96) {
+            delete pc;
+            return fail(WS_ERR_INVALID, "ws_pointcloud_create: expected 28 B Gaussians and 96 B SH records");
+        }
+        // re-lay the loader's AoS records as eight planes of 16-B chunks (ws_internal.h)
+        std::vector<uint32_t> staging;
+        try {
+            staging.resize((size_t)n * PC_PLANES * 4);
+        } catch (...) {
+            delete pc;
+            return fail(WS_ERR_OOM, "ws_pointcloud_create: host staging allocation failed");
+        }
+        const uint8_t* g = static_cast<const uint8_t*>(d->gaussians);
+        const uint8_t* s = static_cast<const uint8_t*>(d->sh_coefs);
+        uint32_t* st = staging.data();
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)n; ++i) {
+            const uint8_t* gi = g + (size_t)i * 28;
+            uint32_t* p0 = st + ((size_t)0 * n + i) * 4;
+            std::memcpy(p0, gi, 16);  // x, y, z, opacity f16 | pad
+            uint32_t* p1 = st + ((size_t)1 * n + i) * 4;
+            std::memcpy(p1, gi + 16, 12);  // cov f16 x 6
+            p1[3] = 0u;
+            const uint8_t* si = s + (size_t)i * 96;
+            for (int q = 0; q < 6; ++q) std::memcpy(st + ((size_t)(2 + q) * n + i) * 4, si + q * 16, 16);
+        }
+        pc->device_bytes = staging.size() * 4;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&pc->planes), pc->device_bytes);
+        if (e == hipSuccess) e = hipMemcpy(pc->planes, st, pc->device_bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = hip_fail(e, "ws_pointcloud_create: upload");
+    } else {
+        const uint32_t ncoef = (d->sh_deg + 1) * (d->sh_deg + 1);
+        if (d->gaussians_bytes != (size_t)n * 24 || !d->covars || !d->quantization || (d->covars_bytes % 12) != 0 ||
+            (d->sh_coefs_bytes % (3 * ncoef)) != 0) {
+            delete pc;
+            return fail(WS_ERR_INVALID, "ws_pointcloud_create: compressed layout mismatch (24 B splats, 12 B covars, "
+                                        "3*(deg+1)^2 B SH records, quantization block)");
+        }
+        // the kernel indexes covars / SH records with the per-Gaussian indices: validate them on the host,
+        // where WebGPU would have clamped out-of-bounds reads
+        const uint8_t* g = static_cast<const uint8_t*>(d->gaussians);
+        const uint32_t n_cov = (uint32_t)(d->covars_bytes / 12), n_sh = (uint32_t)(d->sh_coefs_bytes / (3 * ncoef));
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t gi, si;
+            std::memcpy(&gi, g + (size_t)i * 24 + 16, 4);
+            std::memcpy(&si, g + (size_t)i * 24 + 20, 4);
+            if (gi >= n_cov || si >= n_sh) {
+                delete pc;
+                return fail(WS_ERR_INVALID, "ws_pointcloud_create: geometry_idx / sh_idx out of range");
+            }
+        }
+        pc->quant = *d->quantization;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&pc->gaussians_c), d->gaussians_bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&pc->sh_bytes), d->sh_coefs_bytes + 16);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&pc->covars), d->covars_bytes);
+        if (e == hipSuccess) e = hipMemcpy(pc->gaussians_c, d->gaussians, d->gaussians_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(pc->sh_bytes, d->sh_coefs, d->sh_coefs_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(pc->covars, d->covars, d->covars_bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = hip_fail(e, "ws_pointcloud_create: upload (compressed)");
+        pc->device_bytes = d->gaussians_bytes + d->sh_coefs_bytes + d->covars_bytes;
+    }
+    if (rc != WS_OK) {
+        ws_pointcloud_destroy(pc);
+        return rc;
+    }
+    *out = pc;
+    return WS_OK;
+}
+
+void ws_pointcloud_destroy(ws_pointcloud* pc) {
+    if (!pc) return;
+    dfree(pc->planes);
+    dfree(pc->gaussians_c);
+    dfree(pc->sh_bytes);
+    dfree(pc->covars);
+    delete pc;
+}
+
+uint32_t ws_pointcloud_num_points(const ws_pointcloud* pc) { return pc ? pc->num_points : 0; }
+uint32_t ws_pointcloud_sh_deg(const ws_pointcloud* pc) { return pc ? pc->sh_deg : 0; }
+int ws_pointcloud_compressed(const ws_pointcloud* pc) { return pc && pc->compressed ? 1 : 0; }
+int ws_pointcloud_bbox(const ws_pointcloud* pc, ws_aabb* out) {
+    if (!pc || !out) return fail(WS_ERR_INVALID, "ws_pointcloud_bbox: null argument");
+    *out = pc->bbox;
+    return WS_OK;
+}
+int ws_pointcloud_center(const ws_pointcloud* pc, float out[3]) {
+    if (!pc || !out) return fail(WS_ERR_INVALID, "ws_pointcloud_center: null argument");
+    std::memcpy(out, pc->center, 12);
+    return WS_OK;
+}
+int ws_pointcloud_up(const ws_pointcloud* pc, float out[3]) {
+    if (!pc || !pc->has_up) return 0;
+    if (out) std::memcpy(out, pc->up, 12);
+    return 1;
+}
+int ws_pointcloud_mip_splatting(const ws_pointcloud* pc, int32_t* out) {
+    if (!pc || !pc->has_mip) return 0;
+    if (out) *out = pc->mip ? 1 : 0;
+    return 1;
+}
+int ws_pointcloud_kernel_size(const ws_pointcloud* pc, float* out) {
+    if (!pc || !pc->has_kernel_size) return 0;
+    if (out) *out = pc->kernel_size;
+    return 1;
+}
+int ws_pointcloud_background_color(const ws_pointcloud* pc, float out[3]) {
+    if (!pc || !pc->has_background) return 0;
+    if (out) std::memcpy(out, pc->background, 12);
+    return 1;
+}
+
+// ---- GaussianRenderer --------------------------------------------------------------------------------
+int ws_renderer_create(ws_context* ctx, ws_color_format format, uint32_t sh_deg, int compressed, ws_renderer** out) {
+    if (!ctx || !out) return fail(WS_ERR_INVALID, "ws_renderer_create: null argument");
+    *out = nullptr;
+    if (sh_deg > 3) return fail(WS_ERR_UNSUPPORTED, "ws_renderer_create: sh_deg > 3");
+    if (format != WS_FORMAT_RGBA8_UNORM && format != WS_FORMAT_RGBA16_FLOAT && format != WS_FORMAT_RGBA32_FLOAT)
+        return fail(WS_ERR_INVALID, "ws_renderer_create: unknown colour format");
+    ws_renderer* r = new (std::nothrow) ws_renderer();
+    if (!r) return fail(WS_ERR_OOM, "ws_renderer_create: host allocation failed");
+    r->ctx = ctx;
+    r->format = format;
+    r->sh_deg = sh_deg;
+    r->compressed = compressed != 0;
+    r->capture = env_int("WS_CAPTURE", 0) != 0;
+    for (auto& e : r->ev) {
+        if (hipEventCreate(&e) != hipSuccess) {
+            ws_renderer_destroy(r);
+            return fail(WS_ERR_HIP, "ws_renderer_create: hipEventCreate failed");
+        }
+    }
+    *out = r;
+    return WS_OK;
+}
+
+void ws_renderer_destroy(ws_renderer* r) {
+    if (!r) return;
+    (void)hipDeviceSynchronize();
+    renderer_free_scratch(r);
+    for (auto& e : r->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete r;
+}
+
+ws_color_format ws_renderer_color_format(const ws_renderer* r) { return r ? r->format : WS_FORMAT_RGBA32_FLOAT; }
+
+int ws_renderer_enable_timers(ws_renderer* r, int enable) {
+    if (!r) return fail(WS_ERR_INVALID, "ws_renderer_enable_timers: null renderer");
+    r->timers = enable != 0;
+    r->ev_prepare_valid = r->ev_render_valid = false;
+    return WS_OK;
+}
+
+int ws_renderer_enable_capture(ws_renderer* r, int enable) {
+    if (!r) return fail(WS_ERR_INVALID, "ws_renderer_enable_capture: null renderer");
+    r->capture = enable != 0;
+    return WS_OK;
+}
+
+int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries) {
+    if (!r) return fail(WS_ERR_INVALID, "ws_renderer_set_tile_entry_capacity: null renderer");
+    r->entry_cap_request = entries;
+    return WS_OK;
+}
+
+int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatting_args* args, void* stream_v) {
+    if (!r || !pc || !args) return fail(WS_ERR_INVALID, "ws_renderer_prepare: null argument");
+    if (pc->compressed != r->compressed)
+        return fail(WS_ERR_INVALID, "ws_renderer_prepare: renderer and point cloud disagree on `compressed`");
+    if (args->viewport[0] == 0 || args->viewport[1] == 0 || args->viewport[0] > 65535u * TILE ||
+        args->viewport[1] > 65535u * TILE)
+        return fail(WS_ERR_INVALID, "ws_renderer_prepare: bad viewport");
+    if (args->max_sh_deg > 3) return fail(WS_ERR_UNSUPPORTED, "ws_renderer_prepare: max_sh_deg > 3");
+    if (!pc->compressed && args->max_sh_deg > pc->sh_deg) {
+        // the 96-B record always holds 16 coefficients (zeros above the file's degree): harmless, as in the reference
+    }
+    if (pc->compressed && args->max_sh_deg > r->sh_deg)
+        return fail(WS_ERR_INVALID, "ws_renderer_prepare: max_sh_deg exceeds the renderer's SH layout degree");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    r->prepared = false;
+    int rc = renderer_ensure_scratch(r, pc->num_points, args->viewport[0], args->viewport[1]);
+    if (rc) return rc;
+
+    K1Params kp;
+    std::memset(&kp, 0, sizeof kp);
+    build_camera_uniform(args->camera, args->viewport, &kp.cam);
+    if ((rc = ws_build_settings_uniform(args, pc, &kp.rs))) return rc;
+    kp.quant = pc->quant;
+    kp.num_points = pc->num_points;
+    kp.sh_deg_layout = (r->sh_deg + 1) * (r->sh_deg + 1);
+    kp.tiles_x = r->tiles_x;
+    kp.tiles_y = r->tiles_y;
+
+    K1Buffers kb;
+    kb.planes = pc->planes;
+    kb.gaussians_c = pc->gaussians_c;
+    kb.sh_bytes = pc->sh_bytes;
+    kb.covars = pc->covars;
+    kb.splats = r->splats;
+    kb.keys = r->keys_a;
+    kb.rects = r->rects;
+    kb.src_index = r->capture ? r->src_index : nullptr;
+    kb.block_status = r->block_status;
+    kb.counters = r->counters;
+
+    // GPURSSorter::record_reset_indirect_buffer (gpu_rs.rs:720-727): keys_size = 0, dispatch = 0
+    WS_HIP(hipMemsetAsync(r->counters, 0, sizeof(FrameCounters), stream));
+    WS_HIP(hipMemsetAsync(r->block_status, 0, ((size_t)preprocess_blocks(pc->num_points) + 1) * sizeof(uint32_t), stream));
+    if (r->timers) WS_HIP(hipEventRecord(r->ev[0], stream));
+    if ((rc = launch_preprocess(kp, kb, pc->compressed, stream))) return rc;
+    if (r->timers) WS_HIP(hipEventRecord(r->ev[1], stream));
+
+    // depth sort: V (key, store index) pairs, 4 x 8 bit, values start as iota (preprocess.wgsl:274)
+    uint32_t *sk = nullptr, *sv = nullptr;
+    if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
+                                true, r->ctx->sort_algo, stream, &sk, &sv)))
+        return rc;
+    r->sorted_idx = sv;
+    if (r->timers) WS_HIP(hipEventRecord(r->ev[2], stream));
+
+    // tile binning
+    BinBuffers bb;
+    bb.sorted_idx = r->sorted_idx;
+    bb.rects = r->rects;
+    bb.counts = reinterpret_cast<uint32_t*>(r->rects_sorted);
+    bb.block_sums = r->bin_block_sums;
+    bb.entry_keys = r->ekeys_a;
+    bb.entry_vals = r->evals_a;
+    bb.entry_cap = r->entry_cap;
+    bb.tile_ranges = r->tile_ranges;
+    bb.counters = r->counters;
+    bb.max_points = pc->num_points;
+    bb.tiles_x = r->tiles_x;
+    bb.tiles_y = r->tiles_y;
+    if ((rc = launch_bin_count_scan(bb, stream))) return rc;
+    if ((rc = launch_bin_emit(bb, stream))) return rc;
+    const uint32_t ntiles = r->tiles_x * r->tiles_y;
+    int tile_bits = 8;
+    while ((1ull << tile_bits) < ntiles) tile_bits += 8;
+    uint32_t *ek = nullptr, *evv = nullptr;
+    if ((rc = launch_sort_pairs(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap, 0,
+                                tile_bits, false, r->ctx->sort_algo, stream, &ek, &evv)))
+        return rc;
+    r->entries_sorted = evv;
+    if ((rc = launch_tile_ranges(ek, bb, stream))) return rc;
+    if (r->timers) {
+        WS_HIP(hipEventRecord(r->ev[3], stream));
+        r->ev_prepare_valid = true;
+    }
+    r->prepared = true;
+    r->prepared_pc = pc;
+    r->last_stream = stream;
+    return WS_OK;
+}
+
+int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float background[4], void* d_rgba_out,
+                       size_t row_pitch_bytes, void* stream_v) {
+    if (!r || !pc || !d_rgba_out) return fail(WS_ERR_INVALID, "ws_renderer_render: null argument");
+    if (!r->prepared || r->prepared_pc != pc)
+        return fail(WS_ERR_STATE, "ws_renderer_render: prepare() was not called for this point cloud");
+    const size_t texel = r->format == WS_FORMAT_RGBA8_UNORM ? 4 : (r->format == WS_FORMAT_RGBA16_FLOAT ? 8 : 16);
+    if (row_pitch_bytes < texel * r->vw || (row_pitch_bytes % texel) != 0 ||
+        (reinterpret_cast<uintptr_t>(d_rgba_out) % texel) != 0)
+        return fail(WS_ERR_INVALID, "ws_renderer_render: row pitch / alignment does not fit the colour format");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    BlendParams bp;
+    bp.splats = r->splats;
+    bp.entry_vals = r->entries_sorted;
+    bp.tile_ranges = r->tile_ranges;
+    bp.width = r->vw;
+    bp.height = r->vh;
+    bp.tiles_x = r->tiles_x;
+    bp.tiles_y = r->tiles_y;
+    for (int i = 0; i < 4; ++i) bp.background[i] = background ? background[i] : 0.0f;
+    bp.out = d_rgba_out;
+    bp.pitch = row_pitch_bytes;
+    bp.format = (int)r->format;
+    if (r->timers) WS_HIP(hipEventRecord(r->ev[4], stream));
+    int rc = launch_blend(bp, r->ctx->blend_variant, stream);
+    if (rc) return rc;
+    if (r->timers) {
+        WS_HIP(hipEventRecord(r->ev[5], stream));
+        r->ev_render_valid = true;
+    }
+    r->last_stream = stream;
+    return WS_OK;
+}
+
+int ws_renderer_frame_stats(ws_renderer* r, ws_frame_stats* out) {
+    if (!r || !out) return fail(WS_ERR_INVALID, "ws_renderer_frame_stats: null argument");
+    if (!r->prepared) return fail(WS_ERR_STATE, "ws_renderer_frame_stats: no prepared frame");
+    WS_HIP(hipStreamSynchronize(r->last_stream));
+    FrameCounters fc;
+    WS_HIP(hipMemcpy(&fc, r->counters, sizeof fc, hipMemcpyDeviceToHost));
+    out->num_visible = fc.num_visible;
+    out->num_tile_entries = fc.num_entries;
+    out->tile_entries_capacity = r->entry_cap;
+    out->overflow = fc.overflow;
+    return WS_OK;
+}
+
+int ws_renderer_num_visible(ws_renderer* r, uint32_t* out) {
+    if (!out) return fail(WS_ERR_INVALID, "ws_renderer_num_visible: null argument");
+    ws_frame_stats st;
+    int rc = ws_renderer_frame_stats(r, &st);
+    if (rc) return rc;
+    *out = st.num_visible;
+    return WS_OK;
+}
+
+int ws_renderer_stage_times(ws_renderer* r, ws_stage_times* out) {
+    if (!r || !out) return fail(WS_ERR_INVALID, "ws_renderer_stage_times: null argument");
+    if (!r->timers || !r->ev_prepare_valid) return fail(WS_ERR_STATE, "ws_renderer_stage_times: timers not enabled");
+    std::memset(out, 0, sizeof *out);
+    WS_HIP(hipEventSynchronize(r->ev[3]));
+    WS_HIP(hipEventElapsedTime(&out->preprocess_ms, r->ev[0], r->ev[1]));
+    WS_HIP(hipEventElapsedTime(&out->sorting_ms, r->ev[1], r->ev[2]));
+    WS_HIP(hipEventElapsedTime(&out->binning_ms, r->ev[2], r->ev[3]));
+    if (r->ev_render_valid) {
+        WS_HIP(hipEventSynchronize(r->ev[5]));
+        WS_HIP(hipEventElapsedTime(&out->rasterization_ms, r->ev[4], r->ev[5]));
+    }
+    return WS_OK;
+}
+
+int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, uint32_t* keys, uint32_t* src_index,
+                               uint32_t* sorted, uint32_t* num_visible) {
+    if (!r) return fail(WS_ERR_INVALID, "ws_renderer_download_frame: null renderer");
+    ws_frame_stats st;
+    int rc = ws_renderer_frame_stats(r, &st);
+    if (rc) return rc;
+    if (num_visible) *num_visible = st.num_visible;
+    const uint32_t v = st.num_visible;
+    if ((splats || keys || src_index || sorted) && capacity < v)
+        return fail(WS_ERR_INVALID, "ws_renderer_download_frame: capacity smaller than the visible count");
+    if (src_index && !r->capture)
+        return fail(WS_ERR_STATE, "ws_renderer_download_frame: src_index needs ws_renderer_enable_capture before prepare");
+    if (v == 0) return WS_OK;
+    if (splats) WS_HIP(hipMemcpy(splats, r->splats, (size_t)v * 20, hipMemcpyDeviceToHost));
+    if (src_index) WS_HIP(hipMemcpy(src_index, r->src_index, (size_t)v * 4, hipMemcpyDeviceToHost));
+    if (sorted) WS_HIP(hipMemcpy(sorted, r->sorted_idx, (size_t)v * 4, hipMemcpyDeviceToHost));
+    if (keys) {
+        // the sort permutes the keys in place; un-permute them with the sorted indices so that the caller
+        // gets keys in STORE order (what preprocess wrote)
+        std::vector<uint32_t> ks(v), idx(v);
+        uint32_t* sorted_keys = (r->sorted_idx == r->vals_a) ? r->keys_a : r->keys_b;
+        WS_HIP(hipMemcpy(ks.data(), sorted_keys, (size_t)v * 4, hipMemcpyDeviceToHost));
+        WS_HIP(hipMemcpy(idx.data(), r->sorted_idx, (size_t)v * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < v; ++i)
+            if (idx[i] < v) keys[idx[i]] = ks[i];
+    }
+    return WS_OK;
+}
+
+// ---- GPURSSorter ---------------------------------------------------------------------------------------
+int ws_sorter_create(ws_context* ctx, uint32_t max_n, ws_sorter** out) {
+    if (!ctx || !out) return fail(WS_ERR_INVALID, "ws_sorter_create: null argument");
+    *out = nullptr;
+    if (max_n == 0 || max_n >= (1u << 30)) return fail(WS_ERR_INVALID, "ws_sorter_create: max_n out of range");
+    ws_sorter* s = new (std::nothrow) ws_sorter();
+    if (!s) return fail(WS_ERR_OOM, "ws_sorter_create: host allocation failed");
+    s->ctx = ctx;
+    int rc = alloc_sort_scratch(s->sc, max_n, true, nullptr);
+    if (rc == WS_OK) rc = dmalloc(&s->sc.tickets, 8);
+    if (rc == WS_OK) {
+        s->error = s->sc.tickets + 4;
+        s->sc.error = s->error;
+        hipError_t e = hipMemset(s->sc.tickets, 0, 8 * sizeof(uint32_t));
+        if (e != hipSuccess) rc = hip_fail(e, "ws_sorter_create: memset");
+    }
+    if (rc != WS_OK) {
+        ws_sorter_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return WS_OK;
+}
+
+void ws_sorter_destroy(ws_sorter* s) {
+    if (!s) return;
+    (void)hipDeviceSynchronize();
+    dfree(s->sc.tickets);
+    free_sort_scratch(s->sc, true);
+    delete s;
+}
+
+int ws_sorter_sort(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, const uint32_t* d_count, uint32_t n,
+                   void* stream_v) {
+    if (!s || !d_keys || !d_payload) return fail(WS_ERR_INVALID, "ws_sorter_sort: null argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    uint32_t *ok = nullptr, *ov = nullptr;
+    int rc = launch_sort_pairs(s->sc, d_keys, d_payload, d_count, n, 0, 32, false, s->ctx->sort_algo, stream, &ok, &ov);
+    if (rc) return rc;
+    if (ok != d_keys) return fail(WS_ERR_STATE, "ws_sorter_sort: internal ping-pong parity error");
+    return WS_OK;
+}
+
+int ws_sort_selftest(ws_context* ctx, int* passed) {
+    if (!ctx || !passed) return fail(WS_ERR_INVALID, "ws_sort_selftest: null argument");
+    *passed = 0;
+    const uint32_t n = 8192;  // gpu_rs.rs:297
+    std::vector<float> scrambled(n), expect(n);
+    std::vector<uint32_t> payload(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        scrambled[i] = (float)(n - 1 - i);
+        expect[i] = (float)i;
+        payload[i] = i;
+    }
+    ws_sorter* s = nullptr;
+    int rc = ws_sorter_create(ctx, n, &s);
+    if (rc) return rc;
+    uint32_t *dk = nullptr, *dv = nullptr;
+    rc = dmalloc(&dk, n);
+    if (rc == WS_OK) rc = dmalloc(&dv, n);
+    if (rc == WS_OK) {
+        hipError_t e = hipMemcpy(dk, scrambled.data(), n * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dv, payload.data(), n * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = hip_fail(e, "ws_sort_selftest: upload");
+    }
+    if (rc == WS_OK) rc = ws_sorter_sort(s, dk, dv, nullptr, n, nullptr);
+    std::vector<float> got(n);
+    if (rc == WS_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(got.data(), dk, n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "ws_sort_selftest: download");
+    }
+    if (rc == WS_OK) *passed = std::memcmp(got.data(), expect.data(), n * 4) == 0 ? 1 : 0;
+    dfree(dk);
+    dfree(dv);
+    ws_sorter_destroy(s);
+    return rc;
+}
+
+}  // extern "C"

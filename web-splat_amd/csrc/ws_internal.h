@@ -1,0 +1,171 @@
+// ws_internal.h -- shared internal declarations of libwebsplat_hip (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "websplat.h"
+
+namespace ws {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define WS_HIP(expr)                                          \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return ::ws::hip_fail(_e, #expr); \
+    } while (0)
+
+// ---- geometry of the rasteriser ----------------------------------------------------------------
+constexpr int TILE = 16;                     // 16x16-pixel tiles (north star)
+constexpr float CUTOFF = 2.3539888583335364f; // gaussian.wgsl:2  sqrt(ln 255)
+constexpr float CUT_A = 2.0f * CUTOFF;       // gaussian.wgsl:61 discard if a > 2*CUTOFF
+constexpr float T_MIN = 1.0f / 16384.0f;     // front-to-back early-out (6.1e-5; DESIGN.md section Blend)
+
+// ---- device-side frame counters (one 64-B record per renderer, zeroed each frame) ---------------
+struct FrameCounters {
+    uint32_t num_visible;    // V  (reference: SortInfos.keys_size, preprocess.wgsl:262)
+    uint32_t k1_ticket;      // dynamic block id dispenser of the preprocess kernel
+    uint32_t num_entries;    // D  (clamped to capacity)
+    uint32_t overflow;       // D exceeded capacity
+    uint32_t sort_ticket[8]; // per-pass dynamic tile id dispensers of the radix sort
+    uint32_t _pad[4];
+};
+static_assert(sizeof(FrameCounters) == 64, "FrameCounters layout");
+
+// ---- kernel parameter blocks (passed by value; the analogue of the reference's uniform buffers) ---
+struct K1Params {
+    ws_camera_uniform cam;   // renderer.rs:290-306
+    ws_settings_uniform rs;  // renderer.rs:602-618
+    ws_gaussian_quantization quant; // compressed only (pointcloud.rs:389-396)
+    uint32_t num_points;
+    uint32_t sh_deg_layout;  // compressed: number of coefficients per packed SH record, (sh_deg+1)^2
+    uint32_t tiles_x, tiles_y;
+};
+
+// uncompressed point cloud in HBM: eight planes of 16-B chunks, plane p of Gaussian i at
+// planes + (p*N + i)*16.  plane 0 = {x,y,z, opacity f16 | pad}; plane 1 = {cov f16 x6, pad 4 B};
+// planes 2..7 = the 96-B SH record ([[f16;3];16]) in 16-B pieces.
+constexpr int PC_PLANES = 8;
+
+// ---- sort ---------------------------------------------------------------------------------------
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_KPT = 16;                          // keys per thread
+constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;    // 4096 keys per work tile
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+
+struct SortScratch {
+    uint32_t* keys_alt = nullptr;     // ping-pong partner of the caller's key buffer   [cap]
+    uint32_t* vals_alt = nullptr;     // ping-pong partner of the caller's value buffer [cap]
+    uint32_t* hist = nullptr;         // [4][256] digit histograms
+    uint32_t* status = nullptr;       // [4][tiles][256] decoupled look-back words
+    uint32_t* tickets = nullptr;      // [4] (may alias FrameCounters::sort_ticket)
+    uint32_t* tile_sums = nullptr;    // [tiles][256] reduce-then-scan path (WS_SORT_ALGO=0)
+    uint32_t* error = nullptr;        // device word OR-ed with 4 if a look-back spin ever times out
+    uint32_t cap = 0;
+    uint32_t tiles = 0;
+};
+
+size_t sort_status_words(uint32_t cap);
+
+// Launch an ascending stable LSD radix sort of (key, value) pairs on `stream`.
+//   d_count == nullptr -> sort n pairs; else the count is read on the device (clamped to n).
+//   begin_bit/end_bit: key bits that participate (multiples of 8).
+//   implicit_iota: values of the first pass are the element positions (vals in is not read).
+// The result lands in (keys, vals) if the pass count is even, else in (scratch.keys_alt, vals_alt);
+// *out_keys / *out_vals receive the final pointers.
+int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
+                      int begin_bit, int end_bit, bool implicit_iota, int algo, hipStream_t stream,
+                      uint32_t** out_keys, uint32_t** out_vals);
+
+// ---- preprocess ---------------------------------------------------------------------------------
+struct K1Buffers {
+    const uint4* planes;         // uncompressed: PC_PLANES planes
+    const uint8_t* gaussians_c;  // compressed: 24-B records
+    const uint8_t* sh_bytes;     // compressed: packed int8 SH
+    const uint8_t* covars;       // compressed: 12-B covariance codebook
+    uint8_t* splats;             // [N] x 20 B  (pointcloud.rs:352-358 Splat)
+    uint32_t* keys;              // [N] depth keys
+    uint2* rects;                // [N] tile rect (x0 | y0<<16, x1 | y1<<16), inclusive; x0 > x1 = empty
+    uint32_t* src_index;         // [N] or nullptr (capture mode)
+    uint32_t* block_status;      // [blocks] look-back words, zeroed per frame
+    FrameCounters* counters;
+};
+int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, hipStream_t stream);
+uint32_t preprocess_blocks(uint32_t n);
+
+// ---- binning + blend ----------------------------------------------------------------------------
+struct BinBuffers {
+    const uint32_t* sorted_idx;  // [V] store indices in draw order (far -> near)
+    const uint2* rects;          // [N] by store index
+    uint32_t* counts;            // [N] tiles touched per sorted position, then exclusive offsets
+    uint32_t* block_sums;        // scan scratch
+    uint32_t* entry_keys;        // [cap] tile ids
+    uint32_t* entry_vals;        // [cap] store indices
+    uint32_t entry_cap;
+    uint2* tile_ranges;          // [tiles] (begin, end) into the sorted entry list
+    FrameCounters* counters;
+    uint32_t max_points;         // N (upper bound of V)
+    uint32_t tiles_x, tiles_y;
+};
+int launch_bin_count_scan(const BinBuffers& b, hipStream_t stream);
+int launch_bin_emit(const BinBuffers& b, hipStream_t stream);
+int launch_tile_ranges(const uint32_t* sorted_keys, const BinBuffers& b, hipStream_t stream);
+
+struct BlendParams {
+    const uint8_t* splats;      // [V] x 20 B
+    const uint32_t* entry_vals; // sorted by tile, far -> near inside a tile
+    const uint2* tile_ranges;
+    uint32_t width, height, tiles_x, tiles_y;
+    float background[4];
+    void* out;
+    size_t pitch;
+    int format;
+};
+int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
+
+// ---- host math (host_camera.cpp) ----------------------------------------------------------------
+void build_camera_uniform(const ws_camera& cam, const uint32_t viewport[2], ws_camera_uniform* out);
+
+// ---- half helpers usable on both sides ------------------------------------------------------------
+uint16_t host_f32_to_f16(float f);
+float host_f16_to_f32(uint16_t h);
+
+}  // namespace ws
+
+// opaque handle definitions -------------------------------------------------------------------------
+struct ws_context {
+    int device = 0;
+    hipDeviceProp_t props;
+    int sort_algo = 1;    // 1 = one-sweep (decoupled look-back), 0 = reduce-then-scan
+    int blend_variant = 0;
+};
+
+struct ws_pointcloud {
+    ws_context* ctx = nullptr;
+    uint32_t num_points = 0;
+    uint32_t sh_deg = 0;
+    bool compressed = false;
+    ws_aabb bbox{};
+    float center[3] = {0, 0, 0};
+    bool has_up = false;
+    float up[3] = {0, 0, 0};
+    bool has_mip = false, mip = false;
+    bool has_kernel_size = false;
+    float kernel_size = 0.f;
+    bool has_background = false;
+    float background[3] = {0, 0, 0};
+    ws_gaussian_quantization quant{};
+    // device memory
+    uint4* planes = nullptr;         // uncompressed
+    uint8_t* gaussians_c = nullptr;  // compressed
+    uint8_t* sh_bytes = nullptr;
+    uint8_t* covars = nullptr;
+    size_t device_bytes = 0;
+};

@@ -1,0 +1,8 @@
+"""websplat -- Python binding of libwebsplat_hip.so, the MI355X drop-in for web-splat's render path.
+
+Importing this package loads the HIP library; there is no CPU fallback (ImportError if it is not built).
+"""
+from ._lib import (LIB_PATH, WebSplatError, lib, check, ws_gaussian_quantization, ws_quantization)  # noqa: F401
+from .api import (Aabb, Context, GaussianRenderer, GenericGaussianPointCloud, GPURSSorter, PerspectiveCamera,  # noqa: F401
+                  PointCloud, SplattingArgs, pointcloud_stats, FORMATS)
+from . import synth  # noqa: F401

@@ -1,0 +1,451 @@
+"""Python mirror of the reference's render-path API on top of the C ABI.
+
+Names follow the reference so that tests read like web-splat code:
+  WGPUContext         (src/lib.rs:57-125)        -> Context
+  PerspectiveCamera   (src/camera.rs:6-35)       -> PerspectiveCamera
+  Aabb                (src/pointcloud.rs:398-470)-> Aabb
+  SplattingArgs       (src/renderer.rs:585-599)  -> SplattingArgs
+  PointCloud          (src/pointcloud.rs:72-222) -> PointCloud
+  GaussianRenderer    (src/renderer.rs:17-283)   -> GaussianRenderer
+  GPURSSorter         (src/gpu_rs.rs:63-885)     -> GPURSSorter
+No compute happens here; every method is one call into libwebsplat_hip.so.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import lib, check
+
+FORMATS = {
+    "rgba8unorm": (L.WS_FORMAT_RGBA8_UNORM, np.uint8, 4),
+    "rgba16float": (L.WS_FORMAT_RGBA16_FLOAT, np.float16, 8),
+    "rgba32float": (L.WS_FORMAT_RGBA32_FLOAT, np.float32, 16),
+}
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+@dataclass
+class Aabb:
+    min: Sequence[float]
+    max: Sequence[float]
+
+    def to_c(self):
+        a = L.ws_aabb()
+        a.min[:] = [float(x) for x in self.min]
+        a.max[:] = [float(x) for x in self.max]
+        return a
+
+    @staticmethod
+    def from_c(a):
+        return Aabb(list(a.min), list(a.max))
+
+    def radius(self):
+        a = self.to_c()
+        return lib.ws_aabb_radius(C.byref(a))
+
+    def center(self):
+        return [lo + (hi - lo) / 2.0 for lo, hi in zip(self.min, self.max)]
+
+
+@dataclass
+class PerspectiveCamera:
+    position: Sequence[float] = (0.0, 0.0, -1.0)
+    rotation: Sequence[float] = (1.0, 0.0, 0.0, 0.0)  # quaternion (s, x, y, z)
+    fovx: float = float(np.deg2rad(45.0))
+    fovy: float = float(np.deg2rad(45.0))
+    znear: float = 0.1
+    zfar: float = 100.0
+    fov2view_ratio: float = 1.0
+
+    def to_c(self):
+        c = L.ws_camera()
+        c.position[:] = [float(x) for x in self.position]
+        c.rotation[:] = [float(x) for x in self.rotation]
+        c.fovx, c.fovy, c.znear, c.zfar = self.fovx, self.fovy, self.znear, self.zfar
+        c.fov2view_ratio = self.fov2view_ratio
+        return c
+
+    @staticmethod
+    def from_c(c):
+        return PerspectiveCamera(list(c.position), list(c.rotation), c.fovx, c.fovy, c.znear, c.zfar,
+                                 c.fov2view_ratio)
+
+    def fit_near_far(self, aabb: Aabb):
+        c = self.to_c()
+        a = aabb.to_c()
+        check(lib.ws_camera_fit_near_far(C.byref(c), C.byref(a)))
+        self.znear, self.zfar = c.znear, c.zfar
+        return self
+
+    @staticmethod
+    def from_scene_camera(position, rotation_rows, fx, fy, width, height):
+        """scene.rs:85-108 `impl Into<PerspectiveCamera> for SceneCamera`."""
+        out = L.ws_camera()
+        pos = _f3(position)
+        rot = (C.c_float * 9)(*[float(x) for row in rotation_rows for x in row])
+        check(lib.ws_camera_from_scene(pos, rot, float(fx), float(fy), int(width), int(height), C.byref(out)))
+        return PerspectiveCamera.from_c(out)
+
+    def uniform(self, viewport):
+        u = L.ws_camera_uniform()
+        c = self.to_c()
+        vp = (C.c_uint32 * 2)(int(viewport[0]), int(viewport[1]))
+        check(lib.ws_build_camera_uniform(C.byref(c), vp, C.byref(u)))
+        return u
+
+
+@dataclass
+class SplattingArgs:
+    camera: PerspectiveCamera
+    viewport: Sequence[int]
+    gaussian_scaling: float = 1.0
+    max_sh_deg: int = 3
+    mip_splatting: Optional[bool] = None
+    kernel_size: Optional[float] = None
+    clipping_box: Optional[Aabb] = None
+    walltime: float = 100.0  # seconds; offline callers pass Duration::from_secs(100)
+    scene_center: Optional[Sequence[float]] = None
+    scene_extend: Optional[float] = None
+    background_color: Sequence[float] = (0.0, 0.0, 0.0, 0.0)
+
+    def to_c(self):
+        a = L.ws_splatting_args()
+        a.camera = self.camera.to_c()
+        a.viewport[:] = [int(self.viewport[0]), int(self.viewport[1])]
+        a.gaussian_scaling = float(self.gaussian_scaling)
+        a.max_sh_deg = int(self.max_sh_deg)
+        a.has_mip_splatting = int(self.mip_splatting is not None)
+        a.mip_splatting = int(bool(self.mip_splatting))
+        a.has_kernel_size = int(self.kernel_size is not None)
+        a.kernel_size = float(self.kernel_size or 0.0)
+        a.has_clipping_box = int(self.clipping_box is not None)
+        if self.clipping_box is not None:
+            a.clipping_box = self.clipping_box.to_c()
+        a.walltime_secs = float(self.walltime)
+        a.has_scene_center = int(self.scene_center is not None)
+        if self.scene_center is not None:
+            a.scene_center[:] = [float(x) for x in self.scene_center]
+        a.has_scene_extend = int(self.scene_extend is not None)
+        a.scene_extend = float(self.scene_extend or 0.0)
+        a.background_color[:] = [float(x) for x in self.background_color]
+        return a
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        check(lib.ws_context_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            lib.ws_context_destroy(self.handle)
+            self.handle = None
+
+    def sync(self, stream=None):
+        check(lib.ws_sync(self.handle, C.c_void_p(stream or 0)))
+
+    def device_info(self):
+        name = C.create_string_buffer(128)
+        cus = C.c_uint32()
+        mem = C.c_uint64()
+        check(lib.ws_device_info(self.handle, name, 128, C.byref(cus), C.byref(mem)))
+        return {"arch": name.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}
+
+    # plain device buffers -------------------------------------------------------------------
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        check(lib.ws_device_malloc(self.handle, int(nbytes), C.byref(p)))
+        return p.value
+
+    def free(self, ptr: int):
+        check(lib.ws_device_free(self.handle, C.c_void_p(ptr)))
+
+    def upload(self, ptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        check(lib.ws_memcpy_h2d(self.handle, C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes, None))
+
+    def download(self, ptr: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        check(lib.ws_memcpy_d2h(self.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, None))
+        return out
+
+    def sort_selftest(self) -> bool:
+        ok = C.c_int(0)
+        check(lib.ws_sort_selftest(self.handle, C.byref(ok)))
+        return bool(ok.value)
+
+
+@dataclass
+class GenericGaussianPointCloud:
+    """io/mod.rs:27-43: what a loader produces (host byte blobs + metadata)."""
+    gaussians: np.ndarray  # uint8, N x 28 (or N x 24 compressed)
+    sh_coefs: np.ndarray   # uint8, N x 96 (or packed int8)
+    sh_deg: int
+    num_points: int
+    aabb: Aabb
+    center: Sequence[float]
+    compressed: bool = False
+    covars: Optional[np.ndarray] = None          # uint8, M x 12
+    quantization: Optional[L.ws_gaussian_quantization] = None
+    up: Optional[Sequence[float]] = None
+    kernel_size: Optional[float] = None
+    mip_splatting: Optional[bool] = None
+    background_color: Optional[Sequence[float]] = None
+
+    @staticmethod
+    def from_ply_rows(rows: np.ndarray, sh_deg: int, **meta):
+        """io/ply.rs:50-100 + io/mod.rs:63-105 through the library's host-side loader code."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        n = rows.shape[0]
+        g = np.empty((n, 28), dtype=np.uint8)
+        s = np.empty((n, 96), dtype=np.uint8)
+        check(lib.ws_ply_rows_convert(rows.ctypes.data_as(C.c_void_p), n, int(sh_deg),
+                                      g.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p)))
+        aabb, center, up = pointcloud_stats(g, 28, Aabb([0, 0, 0], [0, 0, 0]))
+        return GenericGaussianPointCloud(g, s, sh_deg, n, aabb, center, up=up, **meta)
+
+
+def pointcloud_stats(gaussians: np.ndarray, stride: int, start: Aabb):
+    start_c = start.to_c()
+    bbox = L.ws_aabb()
+    center = (C.c_float * 3)()
+    has_up = C.c_int32()
+    up = (C.c_float * 3)()
+    n = gaussians.shape[0]
+    check(lib.ws_pointcloud_stats(gaussians.ctypes.data_as(C.c_void_p), n, stride, C.byref(start_c), C.byref(bbox),
+                                  center, C.byref(has_up), up))
+    return Aabb.from_c(bbox), list(center), (list(up) if has_up.value else None)
+
+
+class PointCloud:
+    """pointcloud.rs:99-222 PointCloud::new(device, GenericGaussianPointCloud)."""
+
+    def __init__(self, ctx: Context, pc: GenericGaussianPointCloud = None, _handle=None):
+        self.ctx = ctx
+        if _handle is not None:
+            self.handle = _handle
+            return
+        d = L.ws_pointcloud_desc()
+        g = np.ascontiguousarray(pc.gaussians)
+        s = np.ascontiguousarray(pc.sh_coefs)
+        d.num_points = pc.num_points
+        d.sh_deg = pc.sh_deg
+        d.compressed = int(pc.compressed)
+        d.gaussians = g.ctypes.data
+        d.gaussians_bytes = g.nbytes
+        d.sh_coefs = s.ctypes.data
+        d.sh_coefs_bytes = s.nbytes
+        keep = [g, s]
+        if pc.compressed:
+            cv = np.ascontiguousarray(pc.covars)
+            keep.append(cv)
+            d.covars = cv.ctypes.data
+            d.covars_bytes = cv.nbytes
+            d.quantization = C.pointer(pc.quantization)
+        d.bbox = pc.aabb.to_c()
+        d.center[:] = [float(x) for x in pc.center]
+        d.has_up = int(pc.up is not None)
+        if pc.up is not None:
+            d.up[:] = [float(x) for x in pc.up]
+        d.has_mip_splatting = int(pc.mip_splatting is not None)
+        d.mip_splatting = int(bool(pc.mip_splatting))
+        d.has_kernel_size = int(pc.kernel_size is not None)
+        d.kernel_size = float(pc.kernel_size or 0.0)
+        d.has_background_color = int(pc.background_color is not None)
+        if pc.background_color is not None:
+            d.background_color[:] = [float(x) for x in pc.background_color]
+        h = C.c_void_p()
+        check(lib.ws_pointcloud_create(ctx.handle, C.byref(d), C.byref(h)))
+        self.handle = h
+
+    @staticmethod
+    def load_ply(ctx: Context, path: str):
+        h = C.c_void_p()
+        check(lib.ws_pointcloud_load_ply(ctx.handle, path.encode(), C.byref(h)))
+        return PointCloud(ctx, _handle=h)
+
+    def close(self):
+        if self.handle:
+            lib.ws_pointcloud_destroy(self.handle)
+            self.handle = None
+
+    def num_points(self):
+        return lib.ws_pointcloud_num_points(self.handle)
+
+    def sh_deg(self):
+        return lib.ws_pointcloud_sh_deg(self.handle)
+
+    def compressed(self):
+        return bool(lib.ws_pointcloud_compressed(self.handle))
+
+    def bbox(self) -> Aabb:
+        a = L.ws_aabb()
+        check(lib.ws_pointcloud_bbox(self.handle, C.byref(a)))
+        return Aabb.from_c(a)
+
+    def center(self):
+        c = (C.c_float * 3)()
+        check(lib.ws_pointcloud_center(self.handle, c))
+        return list(c)
+
+    def up(self):
+        c = (C.c_float * 3)()
+        return list(c) if lib.ws_pointcloud_up(self.handle, c) else None
+
+    def mip_splatting(self):
+        v = C.c_int32()
+        return bool(v.value) if lib.ws_pointcloud_mip_splatting(self.handle, C.byref(v)) else None
+
+    def dilation_kernel_size(self):
+        v = C.c_float()
+        return v.value if lib.ws_pointcloud_kernel_size(self.handle, C.byref(v)) else None
+
+    def background_color(self):
+        c = (C.c_float * 3)()
+        return list(c) if lib.ws_pointcloud_background_color(self.handle, c) else None
+
+    def settings_uniform(self, args: SplattingArgs):
+        u = L.ws_settings_uniform()
+        a = args.to_c()
+        check(lib.ws_build_settings_uniform(C.byref(a), self.handle, C.byref(u)))
+        return u
+
+
+class GaussianRenderer:
+    """renderer.rs:33-283.  `prepare` + `render` enqueue on a HIP stream; nothing syncs except the
+    read-back helpers (num_visible_points, frame_stats, stage_times, download_*)."""
+
+    def __init__(self, ctx: Context, color_format: str = "rgba32float", sh_deg: int = 3, compressed: bool = False):
+        self.ctx = ctx
+        self.color_format_name = color_format
+        fmt, self.np_dtype, self.texel_bytes = FORMATS[color_format]
+        h = C.c_void_p()
+        check(lib.ws_renderer_create(ctx.handle, fmt, int(sh_deg), int(compressed), C.byref(h)))
+        self.handle = h
+        self._own_target = None
+        self._own_target_shape = None
+
+    def close(self):
+        if self._own_target:
+            self.ctx.free(self._own_target)
+            self._own_target = None
+        if self.handle:
+            lib.ws_renderer_destroy(self.handle)
+            self.handle = None
+
+    def color_format(self):
+        return self.color_format_name
+
+    def enable_timers(self, on=True):
+        check(lib.ws_renderer_enable_timers(self.handle, int(on)))
+
+    def enable_capture(self, on=True):
+        check(lib.ws_renderer_enable_capture(self.handle, int(on)))
+
+    def set_tile_entry_capacity(self, entries: int):
+        check(lib.ws_renderer_set_tile_entry_capacity(self.handle, int(entries)))
+
+    def prepare(self, pc: PointCloud, args: SplattingArgs, stream=None):
+        a = args.to_c()
+        check(lib.ws_renderer_prepare(self.handle, pc.handle, C.byref(a), C.c_void_p(stream or 0)))
+        self._viewport = (int(args.viewport[0]), int(args.viewport[1]))
+
+    def render(self, pc: PointCloud, target_ptr: int = None, pitch: int = None, background=(0.0, 0.0, 0.0, 0.0),
+               stream=None):
+        w, h = self._viewport
+        if target_ptr is None:
+            if self._own_target_shape != (w, h):
+                if self._own_target:
+                    self.ctx.free(self._own_target)
+                self._own_target = self.ctx.malloc(w * h * self.texel_bytes)
+                self._own_target_shape = (w, h)
+            target_ptr = self._own_target
+        if pitch is None:
+            pitch = w * self.texel_bytes
+        bg = (C.c_float * 4)(*[float(x) for x in background])
+        check(lib.ws_renderer_render(self.handle, pc.handle, bg, C.c_void_p(target_ptr), pitch, C.c_void_p(stream or 0)))
+        return target_ptr
+
+    def download_target(self) -> np.ndarray:
+        """download_texture (bin/render.rs:187-246) for the renderer-owned target: H x W x 4."""
+        w, h = self._own_target_shape
+        self.ctx.sync()
+        return self.ctx.download(self._own_target, (h, w, 4), self.np_dtype)
+
+    def num_visible_points(self) -> int:
+        v = C.c_uint32()
+        check(lib.ws_renderer_num_visible(self.handle, C.byref(v)))
+        return v.value
+
+    def frame_stats(self):
+        s = L.ws_frame_stats()
+        check(lib.ws_renderer_frame_stats(self.handle, C.byref(s)))
+        return {"num_visible": s.num_visible, "num_tile_entries": s.num_tile_entries,
+                "tile_entries_capacity": s.tile_entries_capacity, "overflow": s.overflow}
+
+    def stage_times(self):
+        s = L.ws_stage_times()
+        check(lib.ws_renderer_stage_times(self.handle, C.byref(s)))
+        return {"preprocess": s.preprocess_ms, "sorting": s.sorting_ms, "binning": s.binning_ms,
+                "rasterization": s.rasterization_ms}
+
+    def download_frame(self, with_src_index=False):
+        v = self.num_visible_points()
+        splats = np.empty((v, 20), dtype=np.uint8)
+        keys = np.empty(v, dtype=np.uint32)
+        sorted_idx = np.empty(v, dtype=np.uint32)
+        src = np.empty(v, dtype=np.uint32) if with_src_index else None
+        nv = C.c_uint32()
+        check(lib.ws_renderer_download_frame(
+            self.handle, v, splats.ctypes.data_as(C.c_void_p), keys.ctypes.data_as(C.c_void_p),
+            src.ctypes.data_as(C.c_void_p) if src is not None else None, sorted_idx.ctypes.data_as(C.c_void_p),
+            C.byref(nv)))
+        return {"num_visible": nv.value, "splats": splats, "keys": keys, "sorted": sorted_idx, "src_index": src}
+
+
+class GPURSSorter:
+    """gpu_rs.rs: GPURSSorter::new + create_sort_stuff(max_n); sort() = record_sort / record_sort_indirect."""
+
+    def __init__(self, ctx: Context, max_n: int):
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(lib.ws_sorter_create(ctx.handle, int(max_n), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib.ws_sorter_destroy(self.handle)
+            self.handle = None
+
+    def sort(self, d_keys: int, d_payload: int, n: int, d_count: int = None, stream=None):
+        check(lib.ws_sorter_sort(self.handle, C.c_void_p(d_keys), C.c_void_p(d_payload),
+                                 C.c_void_p(d_count) if d_count else None, int(n), C.c_void_p(stream or 0)))
+
+    def sort_host(self, keys: np.ndarray, payload: np.ndarray, count: int = None):
+        """Convenience for tests: upload, sort, download. `count` exercises the device-side count path."""
+        n = keys.shape[0]
+        dk = self.ctx.malloc(max(n, 1) * 4)
+        dv = self.ctx.malloc(max(n, 1) * 4)
+        dc = None
+        try:
+            self.ctx.upload(dk, keys.astype(np.uint32))
+            self.ctx.upload(dv, payload.astype(np.uint32))
+            if count is not None:
+                dc = self.ctx.malloc(4)
+                self.ctx.upload(dc, np.array([count], dtype=np.uint32))
+            self.sort(dk, dv, n, dc)
+            self.ctx.sync()
+            return self.ctx.download(dk, (n,), np.uint32), self.ctx.download(dv, (n,), np.uint32)
+        finally:
+            self.ctx.free(dk)
+            self.ctx.free(dv)
+            if dc:
+                self.ctx.free(dc)
