@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the render hot path (prepare + render) on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame = one pass of the hot path (K1 preprocess -> depth radix sort -> tile binning ->
+tile blend) over one camera view of the synthetic scene, inputs resident in HBM, output left in HBM.
+Procedure = the reference's bin/measure.rs:98-153: frames are enqueued back-to-back on one stream with a
+single sync at the end (throughput, not latency).  The scene is replicated on every GPU and views are
+sharded view i -> rank i mod N (no data-path collective; "scaling": "weak": every rank renders K frames).
+
+Workloads (BASELINE.json configs):
+  c2  (default) bonsai-like synthetic, 1.2 M Gaussians, 1200x799 -- configs[1]; the real bonsai .ply is not
+                on disk and cannot be downloaded, so the seeded stand-in of SURVEY 8(d) is used
+  hd1m          the north-star headline: same distribution, 1 M Gaussians, 1920x1080
+  c3            5 M Gaussians, 1920x1080 (sort stress)
+  c1            10 k Gaussians, 800x600
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "web-splat_amd"), os.path.join(ROOT, "tests"), ROOT]
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def build_workload(ws, name, n_views):
+    from websplat import synth
+    if name == "c2":
+        rows, (w, h), f = synth.scene_c2(n=1_200_000, seed=1), (1200, 799), 1200.0
+        cams = synth.orbit_cameras(n_views, w, h, f, f)
+    elif name == "hd1m":
+        rows, (w, h), f = synth.scene_c2(n=1_000_000, seed=1), (1920, 1080), 1920.0
+        cams = synth.orbit_cameras(n_views, w, h, f, f)
+    elif name == "c3":
+        rows, (w, h) = synth.scene_c3(n=5_000_000, seed=2), (1920, 1080)
+        cams = [synth.camera_c3(w, h)] * n_views
+    elif name == "c1":
+        rows, (w, h) = synth.scene_c1(n=10_000, seed=0), (800, 600)
+        cams = [synth.camera_c1(w, h)] * n_views
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    gpc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
+    args = []
+    for cj in cams:
+        cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, cj.width, cj.height)
+        cam.fit_near_far(gpc.aabb)
+        args.append(ws.SplattingArgs(camera=cam, viewport=(w, h), max_sh_deg=3))
+    return gpc, args, (w, h)
+
+
+def cpu_baseline(gpc, arg, viewport, budget_s=20.0):
+    """The oracle (CPU restatement of the reference path) timed on this host's cores: a bounded sample of
+    whole frames of the same workload.  Reported, never used by the product path."""
+    import oracle_lib as oracle
+    cam = oracle.make_camera(arg.camera.position, arg.camera.rotation, arg.camera.fovx, arg.camera.fovy,
+                             arg.camera.znear, arg.camera.zfar, arg.camera.fov2view_ratio)
+    w, h = viewport
+    cu = oracle.camera_uniform(cam, w, h)
+    rs = oracle.settings_uniform(oracle.make_aabb(gpc.aabb.min, gpc.aabb.max), gpc.center)
+    oracle.render_frame(gpc.gaussians, gpc.sh_coefs, cu, rs, w, h)  # warm-up (page-in, thread pool)
+    t0 = time.perf_counter()
+    frames = 0
+    while True:
+        oracle.render_frame(gpc.gaussians, gpc.sh_coefs, cu, rs, w, h)
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or frames >= 10:
+            break
+    return {"value": frames / dt, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"{frames} whole frames (view 0) of the same workload, 1 warm-up, OpenMP over "
+                      f"{oracle.num_threads()} threads, oracle built -O2 -ffp-contract=off"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--views", type=int, default=64)
+    ap.add_argument("--format", default="rgba32float")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    torch.cuda.set_device(local_rank)
+
+    import websplat as ws  # raises if the HIP library is not built: there is no fallback
+    ctx = ws.Context(local_rank)
+    gpc, views, viewport = build_workload(ws, a.workload, a.views)
+    pc = ws.PointCloud(ctx, gpc)
+    r = ws.GaussianRenderer(ctx, a.format, 3, False)
+    w, h = viewport
+    target = torch.empty((h, w, 4), dtype={"rgba32float": torch.float32, "rgba16float": torch.float16,
+                                           "rgba8unorm": torch.uint8}[a.format], device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    my_views = [views[i] for i in range(len(views)) if i % world == rank] or views[:1]
+
+    def frame(i):
+        v = my_views[i % len(my_views)]
+        r.prepare(pc, v, stream=stream)
+        r.render(pc, target_ptr=target.data_ptr(), stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        frame(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        frame(a.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # RCCL: the only collective, off the data path
+        elapsed = float(t.item())
+
+    # ---- per-stage kernel time (HIP events on the launch stream) for the roofline block, rank 0 only ----
+    out = None
+    if rank == 0:
+        r.enable_timers(True)
+        acc = {"preprocess": 0.0, "sorting": 0.0, "binning": 0.0, "rasterization": 0.0}
+        stat_acc = {"num_visible": 0, "num_tile_entries": 0}
+        reps = min(len(my_views), 16)
+        for i in range(reps):
+            frame(i)
+            st = r.stage_times()
+            fs = r.frame_stats()
+            for k in acc:
+                acc[k] += st[k] / reps
+            for k in stat_acc:
+                stat_acc[k] += fs[k] / reps
+        overflow = r.frame_stats()["overflow"]
+        n = gpc.num_points
+        V, D = stat_acc["num_visible"], stat_acc["num_tile_entries"]
+        # algorithmic bytes per launch (DESIGN.md "Roofline accounting")
+        bytes_k1 = n * 124 + V * 28
+        bytes_sort = 68 * V
+        bytes_blend = D * 24 + w * h * 16
+        stages = {
+            "preprocess": {"ms": acc["preprocess"], "alg_bytes": bytes_k1},
+            "sorting": {"ms": acc["sorting"], "alg_bytes": bytes_sort},
+            "binning": {"ms": acc["binning"], "alg_bytes": V * 20 + D * 8 + 2 * (4 * D + 2 * 16 * D)},
+            "rasterization": {"ms": acc["rasterization"], "alg_bytes": bytes_blend},
+        }
+        for s in stages.values():
+            s["GBps"] = (s["alg_bytes"] / (s["ms"] * 1e-3) / 1e9) if s["ms"] > 0 else 0.0
+            s["frac_hbm_peak"] = s["GBps"] / HBM_PEAK_GBS
+        dominant = max(stages, key=lambda k: stages[k]["ms"])
+        # K1 ("preprocess") is a single kernel launch, so its event time IS the kernel's duration; it is the
+        # HBM-streaming kernel the metric names ("achieved HBM GB/s for the sort and projection passes")
+        k1 = stages["preprocess"]
+        roofline = {"kernel": "k_preprocess<false>", "bound": "hbm", "achieved": k1["GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": k1["frac_hbm_peak"], "traffic": None,
+                    "alg_bytes_per_launch": bytes_k1, "avg_launch_ms": k1["ms"],
+                    "dominant_stage_by_time": dominant}
+        fps = world * a.steps / elapsed
+        out = {
+            "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {n} Gaussians (sh_deg 3), {w}x{h}, {a.format} target, "
+                                   f"{len(views)} orbit views sharded view i -> rank i mod N",
+                       "gaussians": n, "width": w, "height": h, "views": len(views),
+                       "avg_visible": V, "avg_tile_entries": D, "overflow": overflow},
+            "roofline": roofline,
+            "stages": stages,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(gpc, views[0], viewport)
+        elif world == 1:
+            out["cpu_baseline"] = None
+    barrier()
+    r.close()
+    pc.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

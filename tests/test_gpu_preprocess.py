@@ -1,0 +1,179 @@
+"""GPU parity of K1 / K1c (preprocess.wgsl:163-280, preprocess_compressed.wgsl:206-332) against the oracle,
+called through the C ABI (ws_renderer_prepare + ws_renderer_download_frame).
+
+Tolerance: the visible set and the store order are equal; each of the ten f16 fields of a Splat
+is within 1 f16 ulp of the oracle's (the kernel is built with -ffp-contract=off, so in practice almost every
+field is bit-identical; the test reports and bounds the fraction that is not); depth keys differ by at most
+2 ulp of the f32 they encode."""
+import numpy as np
+import pytest
+
+import scenes
+from websplat import synth
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["v1x", "v1y", "v2x", "v2y", "cx", "cy", "r", "g", "b", "a"]
+
+
+def _prepare(ws, ctx, scene, compressed=False, pc=None, sh_deg=None):
+    own = pc is None
+    if own:
+        pc = ws.PointCloud(ctx, scene.gpc)
+    r = ws.GaussianRenderer(ctx, "rgba32float", scene.sh_deg if sh_deg is None else sh_deg, compressed)
+    r.enable_capture(True)
+    r.prepare(pc, scene.args)
+    frame = r.download_frame(with_src_index=True)
+    stats = r.frame_stats()
+    r.close()
+    return pc, frame, stats
+
+
+def _compare(frame, o_splats, o_keys, o_src, key_ulp=2, max_inexact_frac=0.02):
+    assert frame["num_visible"] == len(o_keys), "visible count differs from the oracle"
+    assert np.array_equal(frame["src_index"], o_src), "visible set / ordered compaction differs"
+    g = frame["splats"].view(np.uint16).reshape(-1, 10)
+    o = o_splats.view(np.uint16).reshape(-1, 10)
+    nan_o = (o & 0x7FFF) > 0x7C00
+    nan_g = (g & 0x7FFF) > 0x7C00
+    assert np.array_equal(nan_o, nan_g), "NaN pattern differs"
+    d = scenes.half_ulp_diff(g, o)
+    d[nan_o] = 0
+    worst = d.max(axis=0)
+    assert d.max() <= 1, f"f16 field off by more than 1 ulp: {dict(zip(FIELDS, worst))}"
+    inexact = float((d > 0).mean())
+    assert inexact <= max_inexact_frac, f"{inexact:.4%} of the halves are not bit-identical"
+    kd = np.abs(frame["keys"].astype(np.int64) - o_keys.astype(np.int64))
+    assert kd.max() <= key_ulp, f"depth keys differ by {kd.max()}"
+    return inexact
+
+
+def test_k1_c1_default(ws, ctx, oracle):
+    sc = scenes.c1(ws, oracle)
+    pc, frame, stats = _prepare(ws, ctx, sc)
+    try:
+        o_splats, o_keys, o_src = sc.oracle_k1(pc)
+        assert 0 < len(o_keys) <= 10_000
+        _compare(frame, o_splats, o_keys, o_src)
+        assert stats["overflow"] == 0
+    finally:
+        pc.close()
+
+
+@pytest.mark.parametrize("sh_deg", [0, 1, 2, 3])
+def test_k1_sh_degrees(ws, ctx, oracle, sh_deg):
+    """render_settings.max_sh_deg selects the degree at run time (preprocess.wgsl:124-154)."""
+    sc = scenes.c1(ws, oracle, n=6000, viewport=(640, 480), seed=20 + sh_deg, max_sh_deg=sh_deg)
+    pc, frame, _ = _prepare(ws, ctx, sc)
+    try:
+        _compare(frame, *sc.oracle_k1(pc))
+    finally:
+        pc.close()
+
+
+@pytest.mark.parametrize("case", ["mip_on", "mip_from_pc", "kernel_0p1", "scaling_0p5", "fade_in", "clip_box",
+                                  "walltime_zero", "scene_extend"])
+def test_k1_render_settings(ws, ctx, oracle, case):
+    """SplattingArgs -> SplattingArgsUniform defaults (renderer.rs:620-651) and their effect in K1."""
+    kw, meta = {}, {}
+    if case == "mip_on":
+        kw = dict(mip_splatting=True)
+    elif case == "mip_from_pc":
+        meta = dict(mip_splatting=True, kernel_size=0.1)
+    elif case == "kernel_0p1":
+        kw = dict(kernel_size=0.1)
+    elif case == "scaling_0p5":
+        kw = dict(gaussian_scaling=0.5)
+    elif case == "fade_in":
+        kw = dict(walltime=1.7)  # mid fade: smoothstep in (0,1) for part of the cloud (preprocess.wgsl:196-203)
+    elif case == "walltime_zero":
+        kw = dict(walltime=0.0)  # scale_mod = 0: covariance collapses to the dilation kernel
+    elif case == "clip_box":
+        kw = dict(clipping_box=ws.Aabb([-0.5, -0.25, -1.0], [0.75, 0.5, 0.1]))
+    elif case == "scene_extend":
+        kw = dict(scene_extend=10.0, walltime=3.0)
+    sc = scenes.c1(ws, oracle, n=8000, viewport=(640, 480), seed=31, pc_meta=meta, **kw)
+    pc, frame, _ = _prepare(ws, ctx, sc)
+    try:
+        o = sc.oracle_k1(pc)
+        if case == "clip_box":
+            assert 0 < len(o[1]) < 4000
+        _compare(frame, *o)
+    finally:
+        pc.close()
+
+
+def test_k1_culling_views(ws, ctx, oracle):
+    """Cameras inside / beside the cloud: frustum cull (z<=0, z>=1, 1.2 w bounds), splats behind the camera."""
+    rows = synth.scene_c2(n=60_000, seed=4)
+    for cam_index, pos in enumerate([[0.0, 0.0, 0.0], [0.3, -0.2, -1.0], [5.0, -1.0, 0.0]]):
+        cj = synth.look_at_camera(cam_index, pos, [0.2, 0.1, 0.5] if cam_index < 2 else [0, 0, 0], 400, 300, 350.0, 350.0)
+        sc = scenes.Scene(ws, oracle, rows, 3, cj, (400, 300))
+        pc, frame, _ = _prepare(ws, ctx, sc)
+        try:
+            o = sc.oracle_k1(pc)
+            assert 0 < len(o[1]) < 60_000
+            _compare(frame, *o)
+        finally:
+            pc.close()
+
+
+def test_k1_full_size_c2(ws, ctx, oracle):
+    """C2 (1.2 M bonsai-like, 1200x799): full per-splat parity at BASELINE size (oracle K1 takes ~1 s)."""
+    sc = scenes.c2(ws, oracle)
+    pc, frame, stats = _prepare(ws, ctx, sc)
+    try:
+        o = sc.oracle_k1(pc)
+        assert len(o[1]) > 200_000
+        _compare(frame, *o)
+        # draw order: keys non-decreasing along `sorted`, ties in store order, permutation of 0..V-1
+        k = frame["keys"][frame["sorted"]]
+        assert np.all(k[1:] >= k[:-1])
+        ties = k[1:] == k[:-1]
+        assert np.all(frame["sorted"][1:][ties] > frame["sorted"][:-1][ties])
+        assert np.array_equal(np.sort(frame["sorted"]), np.arange(len(k), dtype=np.uint32))
+        assert stats["overflow"] == 0 and stats["num_tile_entries"] > 0
+    finally:
+        pc.close()
+
+
+# ---- K1c ---------------------------------------------------------------------------------------------
+def _compressed_pc(ws, oracle, blobs):
+    q = ws.ws_gaussian_quantization()
+    for name in ("color_dc", "color_rest", "opacity", "scaling_factor"):
+        zp, s = blobs["quant"][name]
+        getattr(q, name).zero_point = int(zp)
+        getattr(q, name).scale = float(s)
+    g = blobs["gaussians"]
+    aabb, center, up = ws.pointcloud_stats(g, 24, ws.Aabb([-1, -1, -1], [1, 1, 1]))  # Aabb::unit(), io/mod.rs:119
+    return ws.GenericGaussianPointCloud(g, blobs["sh"], blobs["sh_deg"], blobs["num_points"], aabb, center,
+                                        compressed=True, covars=blobs["covars"], quantization=q, up=up)
+
+
+@pytest.mark.parametrize("sh_deg,max_deg", [(3, 3), (3, 1), (2, 2), (1, 1), (0, 0)])
+def test_k1c_vs_oracle(ws, ctx, oracle, sh_deg, max_deg):
+    """int8 de-quantisation (incl. -128 -> -127 of unpack4x8snorm), codebook gathers, SH records that are not
+    4-byte aligned (record length 3*(deg+1)^2 is odd for every degree), 24-bit depth key, '<'/'>' culling."""
+    blobs = synth.compressed_blobs(n=50_000, n_geometry=1024, n_sh=777, seed=40 + sh_deg, sh_deg=sh_deg)
+    blobs["sh"][:64] = 0x80  # int8 -128 in the first records
+    gpc = _compressed_pc(ws, oracle, blobs)
+    pc = ws.PointCloud(ctx, gpc)
+    try:
+        cj = synth.look_at_camera(0, [0.0, 0.0, -3.0], [0, 0, 0], 800, 600, 800.0, 800.0)
+        cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, 800, 600)
+        cam.fit_near_far(gpc.aabb)
+        args = ws.SplattingArgs(camera=cam, viewport=(800, 600), max_sh_deg=max_deg)
+        r = ws.GaussianRenderer(ctx, "rgba32float", sh_deg, True)
+        r.enable_capture(True)
+        r.prepare(pc, args)
+        frame = r.download_frame(with_src_index=True)
+        r.close()
+        cu = oracle.copy_struct(oracle.CameraUniform, cam.uniform((800, 600)))
+        rs = oracle.copy_struct(oracle.SettingsUniform, pc.settings_uniform(args))
+        oq = oracle.make_quantization(blobs["quant"])
+        o = oracle.preprocess_compressed(blobs["gaussians"], blobs["sh"], blobs["covars"], oq, sh_deg, cu, rs)
+        assert len(o[1]) > 10_000
+        # exp() of the scaling factor comes from different libm's: allow a little more inexactness
+        _compare(frame, *o, key_ulp=1, max_inexact_frac=0.10)
+    finally:
+        pc.close()

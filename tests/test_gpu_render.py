@@ -1,0 +1,247 @@
+"""GPU parity of the whole render path (prepare + render through the C ABI) against the oracle image
+(K1 -> stable depth sort -> gaussian.wgsl quad rasterisation + PREMULTIPLIED_ALPHA_BLENDING).
+
+Stated tolerance (SURVEY 8c / BASELINE north star "within a stated float tolerance"):
+  premultiplied RGBA, f32 target:  max-abs <= 2e-3, mean-abs <= 1e-4  vs the oracle's f32-target image.
+Sources of the gap: front-to-back vs back-to-front summation order, the T < 2^-14 early-out, device exp."""
+import numpy as np
+import pytest
+
+import scenes
+from websplat import synth
+
+pytestmark = pytest.mark.gpu
+
+MAX_ABS = 2e-3
+MEAN_ABS = 1e-4
+
+
+def _render(ws, ctx, scene, fmt="rgba32float", background=(0, 0, 0, 0), pc=None, sh_deg=None):
+    own = pc is None
+    if own:
+        pc = ws.PointCloud(ctx, scene.gpc)
+    r = ws.GaussianRenderer(ctx, fmt, scene.sh_deg if sh_deg is None else sh_deg, False)
+    try:
+        r.prepare(pc, scene.args)
+        r.render(pc, background=background)
+        img = r.download_target()
+        stats = r.frame_stats()
+    finally:
+        r.close()
+    return pc, img, stats
+
+
+def _assert_close(img, ref, max_abs=MAX_ABS, mean_abs=MEAN_ABS):
+    d = np.abs(img.astype(np.float64) - ref.astype(np.float64))
+    assert np.isfinite(img).all()
+    assert d.max() <= max_abs, f"max-abs {d.max():.3e} at {np.unravel_index(d.argmax(), d.shape)}"
+    assert d.mean() <= mean_abs, f"mean-abs {d.mean():.3e}"
+    return d.max(), d.mean()
+
+
+def test_image_c1(ws, ctx, oracle):
+    """BASELINE config 1: 10 k Gaussians, 800x600, single view."""
+    sc = scenes.c1(ws, oracle)
+    pc, img, stats = _render(ws, ctx, sc)
+    try:
+        ref, _ = sc.oracle_image(pc)
+        assert ref[..., 3].max() > 0.9 and (ref[..., 3] > 0).mean() > 0.2  # the scene actually covers the image
+        _assert_close(img, ref)
+        assert stats["overflow"] == 0
+    finally:
+        pc.close()
+
+
+@pytest.mark.parametrize("viewport", [(801, 599), (16, 16), (17, 33), (250, 7)])
+def test_image_odd_viewports(ws, ctx, oracle, viewport):
+    """Viewports that are not multiples of the 16-px tile, down to a single tile."""
+    sc = scenes.c1(ws, oracle, n=3000, viewport=viewport, seed=9)
+    pc, img, _ = _render(ws, ctx, sc)
+    try:
+        ref, _ = sc.oracle_image(pc)
+        assert img.shape == (viewport[1], viewport[0], 4)
+        _assert_close(img, ref)
+    finally:
+        pc.close()
+
+
+def test_image_background_and_formats(ws, ctx, oracle):
+    """Clear colour (bin/render.rs:113-116 uses TRANSPARENT, the viewer a user colour) and the three target
+    formats the reference's front-ends use.  f16 / unorm8 targets are rounded once at the end here, whereas
+    the reference's ROPs round after every blend: compare against the f32 oracle with the format's own
+    quantisation step as tolerance."""
+    sc = scenes.c1(ws, oracle, n=5000, viewport=(320, 240), seed=12)
+    bg = (0.1, 0.3, 0.5, 1.0)
+    pc, img32, _ = _render(ws, ctx, sc, background=bg)
+    try:
+        ref, _ = sc.oracle_image(pc, background=bg)
+        _assert_close(img32, ref)
+        assert np.allclose(img32[0, 0], bg, atol=1e-6) or ref[0, 0, 3] != 1.0
+        _, img16, _ = _render(ws, ctx, sc, fmt="rgba16float", background=bg, pc=pc)
+        assert img16.dtype == np.float16
+        assert np.abs(img16.astype(np.float32) - ref).max() <= MAX_ABS + 2e-3  # f16 ulp at ~2.0 is 2e-3
+        _, img8, _ = _render(ws, ctx, sc, fmt="rgba8unorm", background=bg, pc=pc)
+        assert img8.dtype == np.uint8
+        want8 = np.clip(ref, 0, 1) * 255.0
+        assert np.abs(img8.astype(np.float32) - want8).max() <= 0.5 + 255 * MAX_ABS + 1e-3
+    finally:
+        pc.close()
+
+
+def test_single_splat_analytic(ws, ctx, oracle):
+    """gaussian.wgsl:59-67 on one isotropic Gaussian straight ahead: alpha(x) = min(0.99, a * exp(-r^2/2s^2))
+    inside a <= 2*CUTOFF, exactly 0 outside."""
+    row = np.zeros((1, 62), dtype=np.float32)
+    row[0, 0:3] = [0.0, 0.0, 0.0]
+    row[0, 6:9] = [1.0, 0.5, -0.5]
+    row[0, 54] = 2.0                      # opacity logit
+    row[0, 55:58] = np.log(0.05)          # isotropic scale
+    row[0, 58:62] = [1, 0, 0, 0]
+    cj = synth.look_at_camera(0, [0.0, 0.0, -2.0], [0, 0, 0], 128, 128, 256.0, 256.0)
+    sc = scenes.Scene(ws, oracle, row, 3, cj, (128, 128))
+    pc, img, stats = _render(ws, ctx, sc)
+    try:
+        assert stats["num_visible"] == 1
+        ref, (splats, _, _, _) = sc.oracle_image(pc)
+        _assert_close(img, ref, max_abs=5e-6, mean_abs=1e-6)
+        h = splats.view(np.uint16).reshape(10)
+        f = [oracle.f16_to_f32(int(x)) for x in h]
+        # axes in px (|v| = sqrt(2 lambda)), centre px; kept region a = |M^-1 d|^2 <= 2*CUTOFF
+        M = np.array([[f[0] * 128, f[2] * 128], [-f[1] * 128, -f[3] * 128]])
+        c = np.array([(f[4] * 0.5 + 0.5) * 128, (0.5 - f[5] * 0.5) * 128])
+        ys, xs = np.mgrid[0:128, 0:128]
+        d = np.stack([xs + 0.5 - c[0], ys + 0.5 - c[1]], -1)
+        p = d @ np.linalg.inv(M).T
+        a = (p ** 2).sum(-1)
+        want = np.where(a <= 2 * 2.3539888583335364, np.minimum(0.99, np.exp(-a) * f[9]), 0.0)
+        assert np.abs(img[..., 3] - want).max() < 1e-5
+        assert (img[..., 3] == 0).sum() == (want == 0).sum()
+        lam = 0.5 * (M[0, 0] ** 2 + M[1, 0] ** 2)  # eigenvalue of the screen covariance
+        sigma_px = 0.05 * 256.0 / 2.0              # sigma * f / z
+        assert np.isclose(lam, sigma_px ** 2 + 0.3, rtol=2e-3)  # + dilation kernel (preprocess.wgsl:238-240)
+    finally:
+        pc.close()
+
+
+def test_two_splats_depth_order(ws, ctx, oracle):
+    """Blend order follows depth, not storage order (renderer.rs:65 + key order preprocess.wgsl:273)."""
+    def rows(order):
+        r = np.zeros((2, 62), dtype=np.float32)
+        near = dict(z=-0.5, col=[3.0, -3.0, -3.0])
+        far = dict(z=0.5, col=[-3.0, -3.0, 3.0])
+        for i, s in enumerate(order):
+            g = near if s == "near" else far
+            r[i, 0:3] = [0.0, 0.0, g["z"]]
+            r[i, 6:9] = g["col"]
+            r[i, 54] = 8.0
+            r[i, 55:58] = np.log(0.2)
+            r[i, 58:62] = [1, 0, 0, 0]
+        return r
+    cj = synth.look_at_camera(0, [0.0, 0.0, -3.0], [0, 0, 0], 96, 96, 120.0, 120.0)
+    imgs = []
+    for order in (("near", "far"), ("far", "near")):
+        sc = scenes.Scene(ws, oracle, rows(order), 3, cj, (96, 96))
+        pc, img, _ = _render(ws, ctx, sc)
+        ref, _ = sc.oracle_image(pc)
+        _assert_close(img, ref, max_abs=1e-5, mean_abs=1e-6)
+        imgs.append(img)
+        pc.close()
+    assert np.array_equal(imgs[0], imgs[1])
+    centre = imgs[0][48, 48]
+    assert centre[0] > 0.9 and centre[2] < 0.02  # the near (red) splat dominates
+
+
+def test_determinism_and_reuse(ws, ctx, oracle):
+    """Same view twice, and after rendering another view in between: identical bytes (ordered compaction +
+    stable sorts make the frame a pure function of scene and camera)."""
+    rows = synth.scene_c2(n=80_000, seed=6)
+    cams = synth.orbit_cameras(4, 480, 320, 420.0, 420.0)
+    sc0 = scenes.Scene(ws, oracle, rows, 3, cams[0], (480, 320))
+    sc1 = scenes.Scene(ws, oracle, rows, 3, cams[1], (480, 320))
+    pc = ws.PointCloud(ctx, sc0.gpc)
+    r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    r2 = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    try:
+        out = []
+        for sc in (sc0, sc1, sc0):
+            r.prepare(pc, sc.args)
+            r.render(pc)
+            out.append(r.download_target().copy())
+        assert np.array_equal(out[0], out[2])
+        assert not np.array_equal(out[0], out[1])
+        r2.prepare(pc, sc0.args)  # a second renderer on the same point cloud: private scratch
+        r2.render(pc)
+        assert np.array_equal(r2.download_target(), out[0])
+        ref, _ = sc0.oracle_image(pc)
+        _assert_close(out[0], ref)
+    finally:
+        r.close()
+        r2.close()
+        pc.close()
+
+
+def test_image_c2_subsample(ws, ctx, oracle):
+    """Bonsai-like scene with deep overdraw (300 k Gaussians at 1200x799): early-out and ordering under load."""
+    sc = scenes.c2(ws, oracle, n=300_000)
+    pc, img, stats = _render(ws, ctx, sc)
+    try:
+        ref, _ = sc.oracle_image(pc)
+        mx, mean = _assert_close(img, ref)
+        assert stats["overflow"] == 0
+        assert stats["num_tile_entries"] > stats["num_visible"]
+    finally:
+        pc.close()
+
+
+def test_errors_and_capacity(ws, ctx, oracle):
+    sc = scenes.c1(ws, oracle, n=4000, viewport=(320, 240), seed=2)
+    pc = ws.PointCloud(ctx, sc.gpc)
+    r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    try:
+        with pytest.raises(ws.WebSplatError) as e:  # render before prepare (the reference unwrap()s here)
+            r._viewport = (320, 240)
+            r.render(pc)
+        assert e.value.code == -5
+        r.set_tile_entry_capacity(1000)  # far too small: entries are dropped, flagged, nothing crashes
+        r.prepare(pc, sc.args)
+        r.render(pc)
+        st = r.frame_stats()
+        assert st["overflow"] & 1 and st["num_tile_entries"] == 1000
+        r.set_tile_entry_capacity(0)
+        r.prepare(pc, sc.args)
+        r.render(pc)
+        assert r.frame_stats()["overflow"] == 0
+        with pytest.raises(ws.WebSplatError):
+            ws.GaussianRenderer(ctx, "rgba32float", 4, False)  # sh_deg > 3
+        bad = ws.SplattingArgs(camera=sc.args.camera, viewport=(0, 10))
+        with pytest.raises(ws.WebSplatError):
+            r.prepare(pc, bad)
+    finally:
+        r.close()
+        pc.close()
+
+
+def test_ply_file_roundtrip(ws, ctx, oracle, tmp_path):
+    """io/ply.rs through the library's own loader: header comments, little and big endian bodies."""
+    rows = synth.scene_c1(n=2000, seed=8)
+    for big in (False, True):
+        p = tmp_path / f"scene_{int(big)}.ply"
+        synth.write_ply(str(p), rows, 3, comments=["mip=true", "kernel_size=0.25", "background_color=0.1,0.2,0.3"],
+                        big_endian=big)
+        pc = ws.PointCloud.load_ply(ctx, str(p))
+        try:
+            assert pc.num_points() == 2000 and pc.sh_deg() == 3 and not pc.compressed()
+            assert pc.mip_splatting() is True
+            assert np.isclose(pc.dilation_kernel_size(), 0.25)
+            assert np.allclose(pc.background_color(), [0.1, 0.2, 0.3])
+            g, _ = oracle.ply_rows_convert(rows, 3)
+            bbox, center, _ = oracle.pointcloud_stats(g, 28, oracle.make_aabb([0, 0, 0], [0, 0, 0]))
+            assert np.allclose(pc.bbox().min, list(bbox.min)) and np.allclose(pc.bbox().max, list(bbox.max))
+            assert np.allclose(pc.center(), center)
+            sc = scenes.c1(ws, oracle, n=2000, viewport=(200, 150), seed=8,
+                           pc_meta=dict(mip_splatting=True, kernel_size=0.25))
+            _, img, _ = _render(ws, ctx, sc, pc=pc)
+            ref, _ = sc.oracle_image(pc)
+            _assert_close(img, ref)
+        finally:
+            pc.close()

@@ -1,0 +1,105 @@
+"""GPU parity of the radix sort against the contract of GPURSSorter (gpu_rs.rs:865-884): ascending,
+stable, (u32, u32) pairs, count optionally read from device memory.  Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[1, 0], ids=["onesweep", "reduce_scan"])
+def sort_ctx(ws, request):
+    old = os.environ.get("WS_SORT_ALGO")
+    os.environ["WS_SORT_ALGO"] = str(request.param)
+    c = ws.Context(0)
+    if old is None:
+        del os.environ["WS_SORT_ALGO"]
+    else:
+        os.environ["WS_SORT_ALGO"] = old
+    yield c
+    c.close()
+
+
+def test_sort_known_answer(sort_ctx):
+    """The reference's own start-up self test: 8192 reversed f32 keys (gpu_rs.rs:295-331)."""
+    assert sort_ctx.sort_selftest()
+
+
+def _check(ws, ctx, oracle, keys, count=None):
+    n = len(keys)
+    sorter = ws.GPURSSorter(ctx, max(n, 1))
+    try:
+        k, p = sorter.sort_host(keys, np.arange(n, dtype=np.uint32), count=count)
+    finally:
+        sorter.close()
+    m = n if count is None else min(count, n)
+    ok, op = oracle.sort_pairs(keys[:m], np.arange(m, dtype=np.uint32))
+    assert np.array_equal(k[:m], ok), "keys differ from the stable reference sort"
+    assert np.array_equal(p[:m], op), "payload differs (stability or permutation broken)"
+    if m < n:  # elements past the device-side count are never touched
+        assert np.array_equal(k[m:], keys[m:])
+        assert np.array_equal(p[m:], np.arange(m, n, dtype=np.uint32))
+
+
+SIZES = [1, 2, 63, 64, 65, 255, 256, 3840, 4095, 4096, 4097, 8192, 12289, 100_000, 1_000_003]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_sort_random_u32(ws, sort_ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    _check(ws, sort_ctx, oracle, rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32))
+
+
+@pytest.mark.parametrize("kind", ["all_equal", "two_values", "few_distinct", "sorted", "reversed", "all_ones",
+                                  "depth_like", "low_byte_only", "high_byte_only"])
+def test_sort_distributions(ws, sort_ctx, oracle, kind):
+    n = 200_003
+    rng = np.random.default_rng(7)
+    if kind == "all_equal":
+        keys = np.full(n, 0x3F800000, dtype=np.uint32)
+    elif kind == "two_values":
+        keys = rng.integers(0, 2, size=n).astype(np.uint32) * 0x01000000
+    elif kind == "few_distinct":
+        keys = rng.integers(0, 17, size=n).astype(np.uint32) * 0x00010203
+    elif kind == "sorted":
+        keys = np.sort(rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32))
+    elif kind == "reversed":
+        keys = np.sort(rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32))[::-1].copy()
+    elif kind == "all_ones":
+        keys = np.full(n, 0xFFFFFFFF, dtype=np.uint32)  # same bit pattern as the padding keys
+    elif kind == "depth_like":
+        keys = (rng.uniform(0.0, 37.5, size=n).astype(np.float32)).view(np.uint32)  # bits of zfar - z
+    elif kind == "low_byte_only":
+        keys = rng.integers(0, 256, size=n).astype(np.uint32)
+    else:
+        keys = rng.integers(0, 256, size=n).astype(np.uint32) << 24
+    _check(ws, sort_ctx, oracle, keys)
+
+
+@pytest.mark.parametrize("n,count", [(10_000, 0), (10_000, 1), (10_000, 4096), (10_000, 4097), (10_000, 9_999),
+                                     (10_000, 10_000), (10_000, 50_000)])
+def test_sort_device_side_count(ws, sort_ctx, oracle, n, count):
+    """record_sort_indirect: the number of keys lives in device memory (gpu_rs.rs:875-884)."""
+    rng = np.random.default_rng(count)
+    _check(ws, sort_ctx, oracle, rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32), count=count)
+
+
+def test_sort_large_sortedness(ws, sort_ctx):
+    """Full-size property check (C3: 5 M keys): sortedness, permutation, stability -- no oracle involved."""
+    n = 5_000_000
+    rng = np.random.default_rng(99)
+    keys = rng.uniform(0.0, 20.0, size=n).astype(np.float32).view(np.uint32)
+    keys[::7] = keys[0]  # plenty of duplicates to exercise stability
+    sorter = ws.GPURSSorter(sort_ctx, n)
+    try:
+        k, p = sorter.sort_host(keys, np.arange(n, dtype=np.uint32))
+    finally:
+        sorter.close()
+    assert np.all(k[1:] >= k[:-1])
+    assert np.array_equal(keys[p], k)
+    seen = np.zeros(n, dtype=bool)
+    seen[p] = True
+    assert seen.all()
+    ties = k[1:] == k[:-1]
+    assert np.all(p[1:][ties] > p[:-1][ties])

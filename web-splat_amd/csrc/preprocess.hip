@@ -8,7 +8,7 @@
 //     instruction of a wave is one fully coalesced 1-KiB read, and a culled Gaussian costs 16 B
 //     instead of 124 B: SH / covariance planes are only touched by lanes that survive the cull.
 //   * Compaction is ORDERED (store order == Gaussian index order) through a ticketed, wave-parallel
-//     decoupled look-back over 256-Gaussian blocks: one 32-bit {flag,count} word per block, no fence
+//     decoupled look-back over 1024-Gaussian blocks: one 32-bit {flag,count} word per block, no fence
 //     needed because the word is its own payload.  The reference's atomicAdd(keys_size) order is
 //     nondeterministic (preprocess.wgsl:262); ordered compaction makes equal-depth ties, and hence the
 //     image, reproducible across runs and ranks.
@@ -27,6 +27,7 @@ namespace ws {
 namespace {
 
 constexpr int K1_THREADS = 256;
+constexpr int K1_ITEMS = 4;  // Gaussians per thread
 constexpr uint32_t LB_FLAG_AGG = 1u << 30;   // block aggregate available
 constexpr uint32_t LB_FLAG_INCL = 2u << 30;  // inclusive prefix available
 constexpr uint32_t LB_VALUE_MASK = (1u << 30) - 1u;
@@ -293,10 +294,153 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
     }
 }
 
+// Per-Gaussian front end: load position (+ the few words needed later), clip, project, frustum-cull.
+struct Front {
+    float xyz[3];
+    uint32_t w3;            // uncompressed: opacity f16 | pad ; compressed: opacity i8 | scale i8 | pad
+    uint32_t geometry_idx;  // compressed only
+    uint32_t sh_idx;        // compressed only
+};
+
+template <bool COMPRESSED>
+__device__ __forceinline__ void k1_load_front(const K1Buffers& b, uint32_t idx, Front* f) {
+    if (!COMPRESSED) {
+        const uint4 c0 = b.planes[idx];
+        f->xyz[0] = __uint_as_float(c0.x);
+        f->xyz[1] = __uint_as_float(c0.y);
+        f->xyz[2] = __uint_as_float(c0.z);
+        f->w3 = c0.w;
+        f->geometry_idx = f->sh_idx = 0u;
+    } else {
+        // GaussianCompressed, 24 B (pointcloud.rs:14-22): three 8-B loads per lane
+        const uint2* g = reinterpret_cast<const uint2*>(b.gaussians_c + (size_t)idx * 24);
+        const uint2 a = g[0], bb = g[1], cc = g[2];
+        f->xyz[0] = __uint_as_float(a.x);
+        f->xyz[1] = __uint_as_float(a.y);
+        f->xyz[2] = __uint_as_float(bb.x);
+        f->w3 = bb.y;
+        f->geometry_idx = cc.x;
+        f->sh_idx = cc.y;
+    }
+}
+
+// view / projection of one position; returns "survives clip box and frustum"
+template <bool COMPRESSED>
+__device__ __forceinline__ bool k1_project(const K1Params& p, const float xyz[3], float camspace[4], float pos2d[4]) {
+    // world-space clip box (preprocess.wgsl:177-179)
+    if (xyz[0] < p.rs.clip_min[0] || xyz[1] < p.rs.clip_min[1] || xyz[2] < p.rs.clip_min[2] ||
+        xyz[0] > p.rs.clip_max[0] || xyz[1] > p.rs.clip_max[1] || xyz[2] > p.rs.clip_max[2])
+        return false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float s = VM(0, r) * xyz[0];
+        s += VM(1, r) * xyz[1];
+        s += VM(2, r) * xyz[2];
+        s += VM(3, r) * 1.0f;
+        camspace[r] = s;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float s = PM(0, r) * camspace[0];
+        s += PM(1, r) * camspace[1];
+        s += PM(2, r) * camspace[2];
+        s += PM(3, r) * camspace[3];
+        pos2d[r] = s;
+    }
+    const float bounds = 1.2f * pos2d[3];
+    const float z = pos2d[2] / pos2d[3];
+    bool culled;
+    if (!COMPRESSED)  // preprocess.wgsl:190-192
+        culled = z <= 0.0f || z >= 1.0f || pos2d[0] < -bounds || pos2d[0] > bounds || pos2d[1] < -bounds ||
+                 pos2d[1] > bounds;
+    else  // preprocess_compressed.wgsl:231
+        culled = z < 0.0f || z > 1.0f || pos2d[0] < -bounds || pos2d[0] > bounds || pos2d[1] < -bounds ||
+                 pos2d[1] > bounds;
+    return !culled;
+}
+
+// Back end for one survivor: fetch covariance + SH, run the maths, produce the Splat / key / rect.
+template <bool COMPRESSED>
+__device__ __forceinline__ void k1_back(const K1Params& p, const K1Buffers& b, uint32_t idx, const Front& f,
+                                        SplatOut* so) {
+    float camspace[4], pos2d[4];
+    (void)k1_project<COMPRESSED>(p, f.xyz, camspace, pos2d);  // same instruction sequence as the front end
+    const uint32_t n = p.num_points;
+    float cov6[6];
+    float opacity;
+    Sh16 sh;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sh.c[c][0] = sh.c[c][1] = sh.c[c][2] = 0.0f;
+    if (!COMPRESSED) {
+        opacity = h2f(f.w3);
+        const uint4 c1 = b.planes[(size_t)1 * n + idx];
+        cov6[0] = h2f(c1.x);
+        cov6[1] = h2f(c1.x >> 16);
+        cov6[2] = h2f(c1.y);
+        cov6[3] = h2f(c1.y >> 16);
+        cov6[4] = h2f(c1.z);
+        cov6[5] = h2f(c1.z >> 16);
+        // SH planes 2..7: 48 halves, element e = 3*coef + channel.  Only the planes the active degree
+        // needs are fetched: deg0 -> 1 plane, deg1 -> 2, deg2 -> 4, deg3 -> 6.
+        const uint32_t deg = p.rs.max_sh_deg;
+        const int nplanes = deg == 0u ? 1 : (deg == 1u ? 2 : (deg == 2u ? 4 : 6));
+        uint32_t hw[24];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (q < nplanes) v = b.planes[(size_t)(2 + q) * n + idx];
+            hw[q * 4 + 0] = v.x;
+            hw[q * 4 + 1] = v.y;
+            hw[q * 4 + 2] = v.z;
+            hw[q * 4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 48; ++e) sh.c[e / 3][e % 3] = h2f(hw[e / 2] >> ((e & 1) * 16));
+    } else {
+        // preprocess_compressed.wgsl:236-242
+        const int op_i8 = (int)(signed char)(f.w3 & 0xFFu);
+        const int sc_i8 = (int)(signed char)((f.w3 >> 8) & 0xFFu);
+        opacity = ((float)op_i8 - (float)p.quant.opacity.zero_point) * p.quant.opacity.scale;
+        const float scaling_factor =
+            expf(((float)sc_i8 - (float)p.quant.scaling_factor.zero_point) * p.quant.scaling_factor.scale);
+        const float s2 = scaling_factor * scaling_factor;
+        const uint32_t* cv = reinterpret_cast<const uint32_t*>(b.covars + (size_t)f.geometry_idx * 12);
+        const uint32_t c0 = cv[0], c1 = cv[1], c2 = cv[2];
+        cov6[0] = h2f(c0) * s2;
+        cov6[1] = h2f(c0 >> 16) * s2;
+        cov6[2] = h2f(c1) * s2;
+        cov6[3] = h2f(c1 >> 16) * s2;
+        cov6[4] = h2f(c2) * s2;
+        cov6[5] = h2f(c2 >> 16) * s2;
+        // int8 SH record: 3*ncoef bytes, packed back to back, NOT 4-aligned
+        // (preprocess_compressed.wgsl:147-171).  unpack4x8snorm(x)*127 maps -128 to -127.
+        const uint32_t ncoef = p.sh_deg_layout;
+        uint32_t use = (p.rs.max_sh_deg + 1u) * (p.rs.max_sh_deg + 1u);
+        if (use > ncoef) use = ncoef;
+        const signed char* rec = reinterpret_cast<const signed char*>(b.sh_bytes) + (size_t)3 * ((size_t)f.sh_idx * ncoef);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if ((uint32_t)c < use) {
+                const float zp = (float)(c == 0 ? p.quant.color_dc.zero_point : p.quant.color_rest.zero_point);
+                const float sc = (c == 0 ? p.quant.color_dc.scale : p.quant.color_rest.scale);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float raw = fmaxf((float)rec[c * 3 + j] / 127.0f, -1.0f) * 127.0f;
+                    sh.c[c][j] = (raw - zp) * sc;
+                }
+            }
+        }
+    }
+    k1_math<COMPRESSED>(p, f.xyz, camspace, pos2d, opacity, cov6, sh, so);
+}
+
+// One workgroup = one ticket = K1_ITEMS x 256 consecutive Gaussians (1024): a single device-wide atomic per
+// 1024 Gaussians keeps the ticket dispenser (~11 ns per returning atomic on one address) far below the
+// kernel's HBM time.  Store order inside the block is (item, thread) = Gaussian index order.
 template <bool COMPRESSED>
 __global__ __launch_bounds__(K1_THREADS) void k_preprocess(const K1Params p, const K1Buffers b) {
     __shared__ uint32_t s_bid;
-    __shared__ uint32_t s_wave_cnt[K1_THREADS / 64];
+    __shared__ uint32_t s_cnt[K1_ITEMS][K1_THREADS / 64];
     __shared__ uint32_t s_base;
 
     const int tid = threadIdx.x;
@@ -306,152 +450,55 @@ __global__ __launch_bounds__(K1_THREADS) void k_preprocess(const K1Params p, con
     __syncthreads();
     const uint32_t bid = s_bid;
     const uint32_t n = p.num_points;
-    const uint32_t idx = bid * K1_THREADS + tid;
+    const uint32_t block_base = bid * (K1_THREADS * K1_ITEMS);
 
-    float xyz[3] = {0.f, 0.f, 0.f}, camspace[4] = {0.f, 0.f, 1.f, 1.f}, pos2d[4] = {0.f, 0.f, 0.f, 1.f};
-    uint32_t w3 = 0;  // uncompressed: opacity f16 in the low half; compressed: opacity/scale int8
-    uint32_t geometry_idx = 0, sh_idx = 0;
-    bool vis = false;
-    if (idx < n) {
-        if (!COMPRESSED) {
-            const uint4 c0 = b.planes[idx];
-            xyz[0] = __uint_as_float(c0.x);
-            xyz[1] = __uint_as_float(c0.y);
-            xyz[2] = __uint_as_float(c0.z);
-            w3 = c0.w;
-        } else {
-            // GaussianCompressed, 24 B (pointcloud.rs:14-22): three 8-B loads per lane
-            const uint2* g = reinterpret_cast<const uint2*>(b.gaussians_c + (size_t)idx * 24);
-            const uint2 a = g[0], bb = g[1], cc = g[2];
-            xyz[0] = __uint_as_float(a.x);
-            xyz[1] = __uint_as_float(a.y);
-            xyz[2] = __uint_as_float(bb.x);
-            w3 = bb.y;
-            geometry_idx = cc.x;
-            sh_idx = cc.y;
-        }
-        // world-space clip box (preprocess.wgsl:177-179)
-        bool keep = !(xyz[0] < p.rs.clip_min[0] || xyz[1] < p.rs.clip_min[1] || xyz[2] < p.rs.clip_min[2] ||
-                      xyz[0] > p.rs.clip_max[0] || xyz[1] > p.rs.clip_max[1] || xyz[2] > p.rs.clip_max[2]);
-        if (keep) {
+    // ---- front end for all items: issue every position load first, then cull ---------------------------
+    Front fr[K1_ITEMS];
+    bool vis[K1_ITEMS];
+    uint32_t lane_rank[K1_ITEMS];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s = VM(0, r) * xyz[0];
-                s += VM(1, r) * xyz[1];
-                s += VM(2, r) * xyz[2];
-                s += VM(3, r) * 1.0f;
-                camspace[r] = s;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s = PM(0, r) * camspace[0];
-                s += PM(1, r) * camspace[1];
-                s += PM(2, r) * camspace[2];
-                s += PM(3, r) * camspace[3];
-                pos2d[r] = s;
-            }
-            const float bounds = 1.2f * pos2d[3];
-            const float z = pos2d[2] / pos2d[3];
-            bool culled;
-            if (!COMPRESSED)  // preprocess.wgsl:190-192
-                culled = z <= 0.0f || z >= 1.0f || pos2d[0] < -bounds || pos2d[0] > bounds || pos2d[1] < -bounds ||
-                         pos2d[1] > bounds;
-            else  // preprocess_compressed.wgsl:231
-                culled = z < 0.0f || z > 1.0f || pos2d[0] < -bounds || pos2d[0] > bounds || pos2d[1] < -bounds ||
-                         pos2d[1] > bounds;
-            vis = !culled;
-        }
+    for (int it = 0; it < K1_ITEMS; ++it) {
+        const uint32_t idx = block_base + it * K1_THREADS + tid;
+        fr[it].xyz[0] = fr[it].xyz[1] = fr[it].xyz[2] = 0.0f;
+        fr[it].w3 = fr[it].geometry_idx = fr[it].sh_idx = 0u;
+        if (idx < n) k1_load_front<COMPRESSED>(b, idx, &fr[it]);
     }
-
-    // ---- ordered compaction, part 1: block aggregate, published as early as possible -------------
-    const unsigned long long vmask = __ballot(vis);
-    const uint32_t lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vmask, 0u));
-    if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(vmask);
-    __syncthreads();
-    uint32_t wave_off = 0, block_cnt = 0;
 #pragma unroll
-    for (int w = 0; w < K1_THREADS / 64; ++w) {
-        const uint32_t c = s_wave_cnt[w];
-        if (w < wave) wave_off += c;
-        block_cnt += c;
+    for (int it = 0; it < K1_ITEMS; ++it) {
+        const uint32_t idx = block_base + it * K1_THREADS + tid;
+        float camspace[4], pos2d[4];
+        vis[it] = (idx < n) && k1_project<COMPRESSED>(p, fr[it].xyz, camspace, pos2d);
+        const unsigned long long vmask = __ballot(vis[it]);
+        lane_rank[it] = __builtin_amdgcn_mbcnt_hi((uint32_t)(vmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vmask, 0u));
+        if (lane == 0) s_cnt[it][wave] = (uint32_t)__popcll(vmask);
+    }
+    __syncthreads();
+
+    // ---- ordered compaction, part 1: block aggregate, published before the heavy part -------------------
+    uint32_t off[K1_ITEMS];
+    uint32_t block_cnt = 0;
+#pragma unroll
+    for (int it = 0; it < K1_ITEMS; ++it) {
+#pragma unroll
+        for (int w = 0; w < K1_THREADS / 64; ++w) {
+            const uint32_t c = s_cnt[it][w];
+            if (w == wave) off[it] = block_cnt;
+            block_cnt += c;
+        }
     }
     if (tid == 0) st_agent(b.block_status + bid, (bid == 0 ? LB_FLAG_INCL : LB_FLAG_AGG) | block_cnt);
 
-    // ---- heavy part, only for survivors -----------------------------------------------------------
-    SplatOut so;
-    so.w[0] = so.w[1] = so.w[2] = so.w[3] = so.w[4] = 0u;
-    so.key = 0u;
-    so.rect = make_uint2(1u, 0u);
-    if (vis) {
-        float cov6[6];
-        float opacity;
-        Sh16 sh;
+    // ---- back end, only for survivors --------------------------------------------------------------------
+    SplatOut so[K1_ITEMS];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) sh.c[c][0] = sh.c[c][1] = sh.c[c][2] = 0.0f;
-        if (!COMPRESSED) {
-            opacity = h2f(w3);
-            const uint4 c1 = b.planes[(size_t)1 * n + idx];
-            cov6[0] = h2f(c1.x);
-            cov6[1] = h2f(c1.x >> 16);
-            cov6[2] = h2f(c1.y);
-            cov6[3] = h2f(c1.y >> 16);
-            cov6[4] = h2f(c1.z);
-            cov6[5] = h2f(c1.z >> 16);
-            // SH planes 2..7: 48 halves, element e = 3*coef + channel.  Only the planes the active
-            // degree needs are fetched: deg0 -> 1 plane, deg1 -> 2, deg2 -> 4, deg3 -> 6.
-            const uint32_t deg = p.rs.max_sh_deg;
-            const int nplanes = deg == 0u ? 1 : (deg == 1u ? 2 : (deg == 2u ? 4 : 6));
-            uint32_t hw[24];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (q < nplanes) v = b.planes[(size_t)(2 + q) * n + idx];
-                hw[q * 4 + 0] = v.x;
-                hw[q * 4 + 1] = v.y;
-                hw[q * 4 + 2] = v.z;
-                hw[q * 4 + 3] = v.w;
-            }
-#pragma unroll
-            for (int e = 0; e < 48; ++e) sh.c[e / 3][e % 3] = h2f(hw[e / 2] >> ((e & 1) * 16));
-        } else {
-            // preprocess_compressed.wgsl:236-242
-            const int op_i8 = (int)(signed char)(w3 & 0xFFu);
-            const int sc_i8 = (int)(signed char)((w3 >> 8) & 0xFFu);
-            opacity = ((float)op_i8 - (float)p.quant.opacity.zero_point) * p.quant.opacity.scale;
-            const float scaling_factor =
-                expf(((float)sc_i8 - (float)p.quant.scaling_factor.zero_point) * p.quant.scaling_factor.scale);
-            const float s2 = scaling_factor * scaling_factor;
-            const uint32_t* cv = reinterpret_cast<const uint32_t*>(b.covars + (size_t)geometry_idx * 12);
-            const uint32_t c0 = cv[0], c1 = cv[1], c2 = cv[2];
-            cov6[0] = h2f(c0) * s2;
-            cov6[1] = h2f(c0 >> 16) * s2;
-            cov6[2] = h2f(c1) * s2;
-            cov6[3] = h2f(c1 >> 16) * s2;
-            cov6[4] = h2f(c2) * s2;
-            cov6[5] = h2f(c2 >> 16) * s2;
-            // int8 SH record: 3*(deg_layout+1)^2 bytes, packed back to back, NOT 4-aligned
-            // (preprocess_compressed.wgsl:147-171).  unpack4x8snorm(x)*127 maps -128 to -127.
-            const uint32_t ncoef = p.sh_deg_layout;
-            uint32_t use = (p.rs.max_sh_deg + 1u) * (p.rs.max_sh_deg + 1u);
-            if (use > ncoef) use = ncoef;
-            const signed char* rec = reinterpret_cast<const signed char*>(b.sh_bytes) + (size_t)3 * ((size_t)sh_idx * ncoef);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                if ((uint32_t)c < use) {
-                    const float zp = (float)(c == 0 ? p.quant.color_dc.zero_point : p.quant.color_rest.zero_point);
-                    const float sc = (c == 0 ? p.quant.color_dc.scale : p.quant.color_rest.scale);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const float raw = fmaxf((float)rec[c * 3 + j] / 127.0f, -1.0f) * 127.0f;
-                        sh.c[c][j] = (raw - zp) * sc;
-                    }
-                }
-            }
-        }
-        k1_math<COMPRESSED>(p, xyz, camspace, pos2d, opacity, cov6, sh, &so);
+    for (int it = 0; it < K1_ITEMS; ++it) {
+        so[it].w[0] = so[it].w[1] = so[it].w[2] = so[it].w[3] = so[it].w[4] = 0u;
+        so[it].key = 0u;
+        so[it].rect = make_uint2(1u, 0u);
+        if (vis[it]) k1_back<COMPRESSED>(p, b, block_base + it * K1_THREADS + tid, fr[it], &so[it]);
     }
 
-    // ---- ordered compaction, part 2: look-back (wave 0) and scatter --------------------------------
+    // ---- ordered compaction, part 2: look-back (wave 0) and scatter ----------------------------------------
     if (wave == 0) {
         const uint32_t excl = lookback_exclusive(b.block_status, bid, lane, &b.counters->overflow);
         if (lane == 0) {
@@ -461,23 +508,27 @@ __global__ __launch_bounds__(K1_THREADS) void k_preprocess(const K1Params p, con
         }
     }
     __syncthreads();
-    if (vis) {
-        const uint32_t slot = s_base + wave_off + lane_rank;
-        uint32_t* sp = reinterpret_cast<uint32_t*>(b.splats + (size_t)slot * 20);
-        sp[0] = so.w[0];
-        sp[1] = so.w[1];
-        sp[2] = so.w[2];
-        sp[3] = so.w[3];
-        sp[4] = so.w[4];
-        b.keys[slot] = so.key;
-        b.rects[slot] = so.rect;
-        if (b.src_index) b.src_index[slot] = idx;
+    const uint32_t base = s_base;
+#pragma unroll
+    for (int it = 0; it < K1_ITEMS; ++it) {
+        if (vis[it]) {
+            const uint32_t slot = base + off[it] + lane_rank[it];
+            uint32_t* sp = reinterpret_cast<uint32_t*>(b.splats + (size_t)slot * 20);
+            sp[0] = so[it].w[0];
+            sp[1] = so[it].w[1];
+            sp[2] = so[it].w[2];
+            sp[3] = so[it].w[3];
+            sp[4] = so[it].w[4];
+            b.keys[slot] = so[it].key;
+            b.rects[slot] = so[it].rect;
+            if (b.src_index) b.src_index[slot] = block_base + it * K1_THREADS + tid;
+        }
     }
 }
 
 }  // namespace
 
-uint32_t preprocess_blocks(uint32_t n) { return (n + K1_THREADS - 1) / K1_THREADS; }
+uint32_t preprocess_blocks(uint32_t n) { return (n + K1_THREADS * K1_ITEMS - 1) / (K1_THREADS * K1_ITEMS); }
 
 int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, hipStream_t stream) {
     const uint32_t blocks = preprocess_blocks(p.num_points);

@@ -158,13 +158,16 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
+    const uint32_t count = device_count(d_count, n);
+    // The grid is sized for the host-side bound n; only ceil(count / TILE) workgroups have work.  The surplus
+    // ones leave BEFORE touching the ticket, so exactly the needed number of tickets 0..ntiles-1 is drawn and
+    // the dispenser (one returning atomic per tile on a single address) is not loaded by idle workgroups.
+    if ((uint64_t)blockIdx.x * SORT_TILE >= count) return;  // block-uniform
     if (LOOKBACK) {
         if (tid == 0) s_tile = atomicAdd(ticket, 1u);
         __syncthreads();
     }
     const uint32_t t = LOOKBACK ? s_tile : blockIdx.x;
-    const uint32_t count = device_count(d_count, n);
-    if ((uint64_t)t * SORT_TILE >= count) return;  // block-uniform
     const uint32_t tile_base = t * SORT_TILE;
     const uint32_t valid = (count - tile_base) < (uint32_t)SORT_TILE ? (count - tile_base) : (uint32_t)SORT_TILE;
 
