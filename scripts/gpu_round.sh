@@ -25,7 +25,7 @@ if [[ $WHAT == *bench* ]]; then
 fi
 if [[ $WHAT == *prof* ]]; then
   rm -rf $OUT/prof_$WORKLOAD
-  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$WORKLOAD -o prof -- python bench.py --steps 50 --warmup 5 --workload $WORKLOAD --no-cpu-baseline > $OUT/prof_$WORKLOAD.log 2>&1; echo "prof exit=$?" >> $OUT/summary.txt
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$WORKLOAD -o prof -- python bench.py --steps 50 --warmup 5 --workload $WORKLOAD --no-cpu-baseline > $OUT/prof_$WORKLOAD.log 2>&1; echo "prof exit=$?" >> $OUT/summary.txt
   find $OUT/prof_$WORKLOAD -name "*kernel_stats*" | head -3 >> $OUT/summary.txt
   # keep the traces small: drop the per-dispatch trace, keep the stats
   find $OUT/prof_$WORKLOAD -name "*kernel_trace*" -size +20M -delete

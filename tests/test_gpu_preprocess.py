@@ -29,7 +29,20 @@ def _prepare(ws, ctx, scene, compressed=False, pc=None, sh_deg=None):
     return pc, frame, stats
 
 
-def _compare(frame, o_splats, o_keys, o_src, key_ulp=2, max_inexact_frac=0.02):
+def _axes_cov(h, viewport):
+    """Screen covariance Sigma = (v1 v1^T + v2 v2^T) / 2 in px^2 from the f16 axes of a Splat."""
+    f = h[:, :4].view(np.float16).astype(np.float64)
+    w, hh = viewport
+    v1 = np.stack([f[:, 0] * w, f[:, 1] * hh], -1)
+    v2 = np.stack([f[:, 2] * w, f[:, 3] * hh], -1)
+    return 0.5 * (v1[:, :, None] * v1[:, None, :] + v2[:, :, None] * v2[:, None, :])
+
+
+def _compare(frame, o_splats, o_keys, o_src, key_ulp=2, max_inexact_frac=0.02, axes_by_cov=None):
+    """axes_by_cov = viewport: compare the four axis halves through the covariance they encode instead of
+    per field.  The eigenvector direction normalize((off, lambda1 - d1)) is ill-conditioned for nearly
+    isotropic splats, so a 1-ulp difference in an upstream libm call (K1c's exp) legitimately moves the axes
+    by many f16 ulps while the Gaussian they describe is unchanged."""
     assert frame["num_visible"] == len(o_keys), "visible count differs from the oracle"
     assert np.array_equal(frame["src_index"], o_src), "visible set / ordered compaction differs"
     g = frame["splats"].view(np.uint16).reshape(-1, 10)
@@ -39,6 +52,13 @@ def _compare(frame, o_splats, o_keys, o_src, key_ulp=2, max_inexact_frac=0.02):
     assert np.array_equal(nan_o, nan_g), "NaN pattern differs"
     d = scenes.half_ulp_diff(g, o)
     d[nan_o] = 0
+    if axes_by_cov is not None:
+        ok = ~nan_o[:, :4].any(axis=1)
+        cg, co = _axes_cov(g[ok], axes_by_cov), _axes_cov(o[ok], axes_by_cov)
+        scale = np.abs(co).max(axis=(1, 2))
+        rel = np.abs(cg - co).max(axis=(1, 2)) / np.maximum(scale, 1e-12)
+        assert rel.max() <= 2.0 ** -8, f"screen covariance differs by {rel.max():.3e} (relative)"
+        d[:, :4] = 0
     worst = d.max(axis=0)
     assert d.max() <= 1, f"f16 field off by more than 1 ulp: {dict(zip(FIELDS, worst))}"
     inexact = float((d > 0).mean())
@@ -150,12 +170,17 @@ def _compressed_pc(ws, oracle, blobs):
                                         compressed=True, covars=blobs["covars"], quantization=q, up=up)
 
 
-@pytest.mark.parametrize("sh_deg,max_deg", [(3, 3), (3, 1), (2, 2), (1, 1), (0, 0)])
-def test_k1c_vs_oracle(ws, ctx, oracle, sh_deg, max_deg):
+@pytest.mark.parametrize("sh_deg,max_deg,exact_exp", [(3, 3, False), (3, 3, True), (3, 1, False), (2, 2, False),
+                                                       (1, 1, True), (0, 0, False)])
+def test_k1c_vs_oracle(ws, ctx, oracle, sh_deg, max_deg, exact_exp):
     """int8 de-quantisation (incl. -128 -> -127 of unpack4x8snorm), codebook gathers, SH records that are not
     4-byte aligned (record length 3*(deg+1)^2 is odd for every degree), 24-bit depth key, '<'/'>' culling."""
     blobs = synth.compressed_blobs(n=50_000, n_geometry=1024, n_sh=777, seed=40 + sh_deg, sh_deg=sh_deg)
     blobs["sh"][:64] = 0x80  # int8 -128 in the first records
+    if exact_exp:
+        # scaling_factor = exp(0) = 1 on both sides: removes the only libm call, everything must then agree
+        # to the f16 ulp, field by field
+        blobs["quant"]["scaling_factor"] = (0, 0.0)
     gpc = _compressed_pc(ws, oracle, blobs)
     pc = ws.PointCloud(ctx, gpc)
     try:
@@ -173,7 +198,9 @@ def test_k1c_vs_oracle(ws, ctx, oracle, sh_deg, max_deg):
         oq = oracle.make_quantization(blobs["quant"])
         o = oracle.preprocess_compressed(blobs["gaussians"], blobs["sh"], blobs["covars"], oq, sh_deg, cu, rs)
         assert len(o[1]) > 10_000
-        # exp() of the scaling factor comes from different libm's: allow a little more inexactness
-        _compare(frame, *o, key_ulp=1, max_inexact_frac=0.10)
+        if exact_exp:
+            _compare(frame, *o, key_ulp=1)
+        else:  # exp() comes from different libm's (glibc vs ocml): axes compared through their covariance
+            _compare(frame, *o, key_ulp=1, max_inexact_frac=0.10, axes_by_cov=(800, 600))
     finally:
         pc.close()

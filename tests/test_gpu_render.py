@@ -91,13 +91,15 @@ def test_image_background_and_formats(ws, ctx, oracle):
 def test_single_splat_analytic(ws, ctx, oracle):
     """gaussian.wgsl:59-67 on one isotropic Gaussian straight ahead: alpha(x) = min(0.99, a * exp(-r^2/2s^2))
     inside a <= 2*CUTOFF, exactly 0 outside."""
+    # The Gaussian sits away from the origin: the PLY bbox starts at the origin (Aabb::zeroed, io/mod.rs:74), so
+    # the bbox radius (= scene_extend) is > 0 and the fade-in term (preprocess.wgsl:196-203) is 1 at walltime 100.
     row = np.zeros((1, 62), dtype=np.float32)
-    row[0, 0:3] = [0.0, 0.0, 0.0]
+    row[0, 0:3] = [0.5, 0.0, 0.0]
     row[0, 6:9] = [1.0, 0.5, -0.5]
     row[0, 54] = 2.0                      # opacity logit
     row[0, 55:58] = np.log(0.05)          # isotropic scale
     row[0, 58:62] = [1, 0, 0, 0]
-    cj = synth.look_at_camera(0, [0.0, 0.0, -2.0], [0, 0, 0], 128, 128, 256.0, 256.0)
+    cj = synth.look_at_camera(0, [0.5, 0.0, -2.0], [0.5, 0, 0], 128, 128, 256.0, 256.0)
     sc = scenes.Scene(ws, oracle, row, 3, cj, (128, 128))
     pc, img, stats = _render(ws, ctx, sc)
     try:
@@ -126,7 +128,13 @@ def test_single_splat_analytic(ws, ctx, oracle):
 def test_two_splats_depth_order(ws, ctx, oracle):
     """Blend order follows depth, not storage order (renderer.rs:65 + key order preprocess.wgsl:273)."""
     def rows(order):
-        r = np.zeros((2, 62), dtype=np.float32)
+        # two invisible (opacity ~ 0) Gaussians at z = +-2 stretch the bbox so that fit_near_far does not put
+        # the near plane exactly on the near splat (z <= 0 is culled, preprocess.wgsl:190)
+        r = np.zeros((4, 62), dtype=np.float32)
+        r[2, 0:3], r[3, 0:3] = [0.0, 0.0, -2.0], [0.0, 0.0, 2.0]
+        r[2:, 54] = -30.0
+        r[2:, 55:58] = np.log(0.01)
+        r[2:, 58] = 1.0
         near = dict(z=-0.5, col=[3.0, -3.0, -3.0])
         far = dict(z=0.5, col=[-3.0, -3.0, 3.0])
         for i, s in enumerate(order):
@@ -137,7 +145,7 @@ def test_two_splats_depth_order(ws, ctx, oracle):
             r[i, 55:58] = np.log(0.2)
             r[i, 58:62] = [1, 0, 0, 0]
         return r
-    cj = synth.look_at_camera(0, [0.0, 0.0, -3.0], [0, 0, 0], 96, 96, 120.0, 120.0)
+    cj = synth.look_at_camera(0, [0.0, 0.0, -4.0], [0, 0, 0], 96, 96, 160.0, 160.0)
     imgs = []
     for order in (("near", "far"), ("far", "near")):
         sc = scenes.Scene(ws, oracle, rows(order), 3, cj, (96, 96))

@@ -20,6 +20,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include "lookback.h"
 #include "ws_internal.h"
 
 namespace ws {
@@ -28,54 +29,9 @@ namespace {
 
 constexpr int K1_THREADS = 256;
 constexpr int K1_ITEMS = 4;  // Gaussians per thread
-constexpr uint32_t LB_FLAG_AGG = 1u << 30;   // block aggregate available
-constexpr uint32_t LB_FLAG_INCL = 2u << 30;  // inclusive prefix available
-constexpr uint32_t LB_VALUE_MASK = (1u << 30) - 1u;
-constexpr uint32_t LB_SPIN_LIMIT = 1u << 24;
 
 __device__ __forceinline__ float h2f(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)(h & 0xFFFFu))); }
 __device__ __forceinline__ uint32_t f2h(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
-
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// Exclusive prefix of the per-block visible counts, for block `bid`, computed by ONE wave.
-// Lane l inspects predecessor bid-1-l; the window slides back by 64 until an inclusive prefix is met.
-__device__ uint32_t lookback_exclusive(const uint32_t* status, uint32_t bid, int lane, uint32_t* error_word) {
-    uint32_t sum = 0;
-    int64_t base = (int64_t)bid - 1;
-    uint32_t spins = 0;
-    while (true) {
-        const int64_t i = base - lane;
-        uint32_t w = LB_FLAG_INCL;  // virtual predecessor of block 0: inclusive prefix 0
-        if (i >= 0) w = ld_agent(status + i);
-        // all lanes up to the first INCL lane must be published
-        const unsigned long long incl = __ballot((w >> 30) == 2u);
-        const int first = incl ? (__ffsll((long long)incl) - 1) : 64;
-        const unsigned long long pending = __ballot((w >> 30) == 0u && lane <= first);
-        if (pending) {
-            if (++spins > LB_SPIN_LIMIT) {
-                if (lane == 0) atomicOr(error_word, 2u);
-                return sum;
-            }
-            __builtin_amdgcn_s_sleep(2);
-            continue;
-        }
-        sum += wave_sum(lane <= first ? (w & LB_VALUE_MASK) : 0u);
-        if (incl) return sum;
-        base -= 64;
-    }
-}
 
 // SH basis constants: preprocess.wgsl:4-23
 __device__ constexpr float SH_C0 = 0.28209479177387814f;
@@ -486,7 +442,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_preprocess(const K1Params p, con
             block_cnt += c;
         }
     }
-    if (tid == 0) st_agent(b.block_status + bid, (bid == 0 ? LB_FLAG_INCL : LB_FLAG_AGG) | block_cnt);
+    if (tid == 0) lb::st(b.block_status + bid, lb::pack(p.epoch, bid == 0 ? lb::FLAG_INCL : lb::FLAG_AGG, block_cnt));
 
     // ---- back end, only for survivors --------------------------------------------------------------------
     SplatOut so[K1_ITEMS];
@@ -500,10 +456,10 @@ __global__ __launch_bounds__(K1_THREADS) void k_preprocess(const K1Params p, con
 
     // ---- ordered compaction, part 2: look-back (wave 0) and scatter ----------------------------------------
     if (wave == 0) {
-        const uint32_t excl = lookback_exclusive(b.block_status, bid, lane, &b.counters->overflow);
+        const uint32_t excl = lb::wave_lookback(b.block_status, bid, p.epoch, lane, &b.counters->overflow, 2u);
         if (lane == 0) {
             s_base = excl;
-            if (bid != 0) st_agent(b.block_status + bid, LB_FLAG_INCL | (excl + block_cnt));
+            if (bid != 0) lb::st(b.block_status + bid, lb::pack(p.epoch, lb::FLAG_INCL, excl + block_cnt));
             if (bid == gridDim.x - 1) b.counters->num_visible = excl + block_cnt;
         }
     }

@@ -8,15 +8,17 @@
 // stable counting sort on the tile id of depth-ordered (tile, splat) entries) and one workgroup composites the
 // list front-to-back out of LDS, keeping colour and transmittance in registers and writing each pixel once.
 //
-//   k_bin_count   : per depth-sorted splat: gather its tile rectangle, count tiles, per-block sums
-//   k_bin_scan    : exclusive scan of the block sums (single block), total D -> FrameCounters
-//   k_bin_emit    : per block: scan its counts, emit (tile id, splat) entries, load-balanced through LDS
+//   k_bin_prefix  : per depth-sorted splat: gather its tile rectangle, count tiles, exclusive prefix over the
+//                   draw order in ONE pass (ticketed wave-parallel decoupled look-back), total D
+//   k_bin_emit    : entry-parallel: every workgroup produces exactly EMIT_TILE (tile id, splat) entries, whatever
+//                   the footprint of the splats they come from (LDS binary search over the splat offsets)
 //   (radix sort of the entries by tile id: sort.hip, 2 passes, stable -> depth order kept inside a tile)
 //   k_tile_ranges : [begin,end) of every tile in the sorted entry list
 //   k_blend       : 16x16 pixels per workgroup, splats staged through LDS 256 at a time, early-out on T
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include "lookback.h"
 #include "ws_internal.h"
 
 namespace ws {
@@ -33,18 +35,6 @@ __device__ __forceinline__ uint32_t rect_count(uint2 r) {
     const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu, y1 = r.y >> 16;
     if (x0 > x1 || y0 > y1) return 0u;
     return (x1 - x0 + 1u) * (y1 - y0 + 1u);
-}
-
-__device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v, uint32_t* s_tmp) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
-    __syncthreads();
-    uint32_t t = 0;
-#pragma unroll
-    for (int w = 0; w < BIN_THREADS / 64; ++w) t += s_tmp[w];
-    __syncthreads();
-    return t;
 }
 
 __device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t* s_tmp, uint32_t* total) {
@@ -69,118 +59,125 @@ __device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t
     return wave_off + incl - v;
 }
 
-// ---- k_bin_count: gather rects in draw order, write them contiguously, per-block tile totals ------------
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ sorted_idx,
-                                                          const uint2* __restrict__ rects,
-                                                          uint2* __restrict__ rects_sorted,
-                                                          uint32_t* __restrict__ block_sums,
-                                                          const FrameCounters* __restrict__ counters) {
+// ---- k_bin_prefix ------------------------------------------------------------------------------------
+// Draw position i (far -> near) -> rects_sorted[i], offsets[i] = sum of tiles touched by positions < i.
+// Also records, for every multiple m*EMIT_TILE of the entry index, the draw position whose entry range
+// contains it (emit_start[m]): the emit kernel then needs no global search to find where its slice starts.
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __restrict__ sorted_idx,
+                                                           const uint2* __restrict__ rects,
+                                                           uint2* __restrict__ rects_sorted,
+                                                           uint32_t* __restrict__ offsets,
+                                                           uint32_t* __restrict__ emit_start,
+                                                           uint64_t* __restrict__ status,
+                                                           FrameCounters* __restrict__ counters, uint32_t entry_cap,
+                                                           uint32_t epoch) {
     __shared__ uint32_t s_tmp[BIN_THREADS / 64];
+    __shared__ uint32_t s_bid;
+    __shared__ uint32_t s_base;
     const uint32_t v = counters->num_visible;
-    const uint32_t base = blockIdx.x * BIN_ITEMS;
-    uint32_t sum = 0;
-    if (base < v) {
-#pragma unroll
-        for (int k = 0; k < BIN_IPT; ++k) {
-            const uint32_t i = base + k * BIN_THREADS + threadIdx.x;  // coalesced
-            if (i < v) {
-                const uint2 r = rects[sorted_idx[i]];
-                rects_sorted[i] = r;
-                sum += rect_count(r);
-            }
-        }
-    }
-    const uint32_t tot = block_reduce_sum(sum, s_tmp);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
+    if ((uint64_t)blockIdx.x * BIN_ITEMS >= v) return;  // surplus workgroups leave before drawing a ticket
+    const int tid = threadIdx.x;
+    if (tid == 0) s_bid = atomicAdd(&counters->bin_ticket, 1u);
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const uint32_t nblocks = (v + BIN_ITEMS - 1) / BIN_ITEMS;
+    const uint32_t base = bid * BIN_ITEMS;
 
-// ---- k_bin_scan: exclusive scan of block sums (one block), D -> counters -------------------------------
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__ block_sums, uint32_t nblocks,
-                                                         FrameCounters* __restrict__ counters, uint32_t entry_cap) {
-    __shared__ uint32_t s_tmp[BIN_THREADS / 64];
-    uint32_t running = 0;  // block-uniform
-    for (uint32_t b0 = 0; b0 < nblocks; b0 += BIN_THREADS) {
-        const uint32_t b = b0 + threadIdx.x;
-        const uint32_t c = b < nblocks ? block_sums[b] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan256(c, s_tmp, &tot);
-        if (b < nblocks) block_sums[b] = running + ex;
-        running += tot;
-        // NOTE: 32-bit totals; D above 2^32 is out of scope (capacity is a u32)
-    }
-    if (threadIdx.x == 0) {
-        if (running > entry_cap) {
-            counters->overflow |= 1u;
-            running = entry_cap;
-        }
-        counters->num_entries = running;
-    }
-}
-
-// ---- k_bin_emit: (tile id, splat) entries in draw order ---------------------------------------------
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __restrict__ sorted_idx,
-                                                         const uint2* __restrict__ rects_sorted,
-                                                         const uint32_t* __restrict__ block_offsets,
-                                                         uint32_t* __restrict__ entry_keys,
-                                                         uint32_t* __restrict__ entry_vals, uint32_t entry_cap,
-                                                         const FrameCounters* __restrict__ counters,
-                                                         uint32_t tiles_x) {
-    __shared__ uint32_t s_off[BIN_ITEMS + 1];
-    __shared__ uint2 s_rect[BIN_ITEMS];
-    __shared__ uint32_t s_idx[BIN_ITEMS];
-    __shared__ uint32_t s_tmp[BIN_THREADS / 64];
-
-    const uint32_t v = counters->num_visible;
-    const uint32_t base = blockIdx.x * BIN_ITEMS;
-    if (base >= v) return;
-    const uint32_t out_base = block_offsets[blockIdx.x];
-
-    // blocked arrangement: thread t owns items [t*IPT, t*IPT + IPT)
+    // blocked arrangement: thread t owns draw positions base + t*IPT .. + IPT-1
+    uint2 r[BIN_IPT];
     uint32_t cnt[BIN_IPT];
     uint32_t tsum = 0;
 #pragma unroll
     for (int k = 0; k < BIN_IPT; ++k) {
-        const uint32_t li = threadIdx.x * BIN_IPT + k;
-        const uint32_t i = base + li;
-        uint2 r = make_uint2(1u, 0u);
-        uint32_t id = 0u;
-        if (i < v) {
-            r = rects_sorted[i];
-            id = sorted_idx[i];
-        }
-        s_rect[li] = r;
-        s_idx[li] = id;
-        cnt[k] = rect_count(r);
+        const uint32_t i = base + tid * BIN_IPT + k;
+        r[k] = make_uint2(1u, 0u);
+        if (i < v) r[k] = rects[sorted_idx[i]];
+        cnt[k] = rect_count(r[k]);
         tsum += cnt[k];
     }
     uint32_t block_total;
     uint32_t ex = block_exclusive_scan256(tsum, s_tmp, &block_total);
+    if (tid == 0) lb::st(status + bid, lb::pack(epoch, bid == 0 ? lb::FLAG_INCL : lb::FLAG_AGG, block_total));
+    if (tid < 64) {
+        const uint32_t excl = lb::wave_lookback(status, bid, epoch, tid, &counters->overflow, 4u);
+        if (tid == 0) {
+            s_base = excl;
+            const uint32_t incl = excl + block_total;  // saturates at 2^30-1 inside pack(); capacity is below that
+            if (bid != 0) lb::st(status + bid, lb::pack(epoch, lb::FLAG_INCL, incl));
+            if (bid == nblocks - 1) {
+                uint32_t d = incl;
+                if (d > entry_cap) {
+                    atomicOr(&counters->overflow, 1u);
+                    d = entry_cap;
+                }
+                counters->num_entries = d;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t off = s_base + ex;
 #pragma unroll
     for (int k = 0; k < BIN_IPT; ++k) {
-        s_off[threadIdx.x * BIN_IPT + k] = ex;
-        ex += cnt[k];
-    }
-    if (threadIdx.x == 0) s_off[BIN_ITEMS] = block_total;
-    __syncthreads();
-
-    // every thread produces entries e, e + 256, ...: find the owning item by binary search in LDS
-    for (uint32_t e = threadIdx.x; e < block_total; e += BIN_THREADS) {
-        uint32_t lo = 0, hi = BIN_ITEMS;  // largest item with s_off[item] <= e
-#pragma unroll
-        for (int step = 0; step < 11; ++step) {  // log2(2048)
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_off[mid] <= e) lo = mid; else hi = mid;
+        const uint32_t i = base + tid * BIN_IPT + k;
+        if (i < v) {
+            rects_sorted[i] = r[k];
+            offsets[i] = off;
+            if (cnt[k]) {
+                // multiples of EMIT_TILE inside [off, off + cnt)
+                const uint32_t m_first = (off + EMIT_TILE - 1) / EMIT_TILE;
+                const uint32_t last = off + cnt[k] - 1u;
+                for (uint32_t m = m_first; (uint64_t)m * EMIT_TILE <= last; ++m)
+                    if ((uint64_t)m * EMIT_TILE < entry_cap) emit_start[m] = i;
+            }
         }
-        const uint2 r = s_rect[lo];
+        off += cnt[k];
+    }
+}
+
+// ---- k_bin_emit: (tile id, splat) entries in draw order, EMIT_TILE entries per workgroup ---------------
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __restrict__ sorted_idx,
+                                                         const uint2* __restrict__ rects_sorted,
+                                                         const uint32_t* __restrict__ offsets,
+                                                         const uint32_t* __restrict__ emit_start,
+                                                         uint32_t* __restrict__ entry_keys,
+                                                         uint32_t* __restrict__ entry_vals,
+                                                         const FrameCounters* __restrict__ counters,
+                                                         uint32_t tiles_x) {
+    __shared__ uint32_t s_off[EMIT_TILE + 2];
+    const uint32_t d = counters->num_entries;
+    const uint32_t v = counters->num_visible;
+    const uint32_t e0 = blockIdx.x * EMIT_TILE;
+    if (e0 >= d) return;
+    const uint32_t e1 = (d - e0) < (uint32_t)EMIT_TILE ? d : e0 + EMIT_TILE;
+    // draw positions [s_lo, s_hi] own the entries [e0, e1)
+    const uint32_t s_lo = emit_start[blockIdx.x];
+    const uint32_t s_hi = (e1 < d) ? emit_start[blockIdx.x + 1] : (v - 1u);
+    // Positions that own entries of this slice number at most EMIT_TILE + 1, but visible splats with an EMPTY
+    // tile rectangle (centre inside the 1.2x cull bounds, footprint off screen) can sit in between in any
+    // number: normally the offsets fit the LDS window, otherwise the search runs on global memory (rare).
+    const uint32_t ns = s_hi - s_lo + 1u;
+    const bool in_lds = ns <= (uint32_t)EMIT_TILE + 2u;  // block-uniform
+    if (in_lds)
+        for (uint32_t k = threadIdx.x; k < ns; k += BIN_THREADS) s_off[k] = offsets[s_lo + k];
+    __syncthreads();
+    const uint32_t* goff = offsets + s_lo;
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += BIN_THREADS) {
+        // largest k in [0, ns) with off[k] <= e  (zero-footprint positions share their successor's offset and
+        // are skipped by taking the LAST such k)
+        uint32_t lo = 0, hi = ns;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint32_t ov = in_lds ? s_off[mid] : goff[mid];
+            if (ov <= e) lo = mid; else hi = mid;
+        }
+        const uint32_t pos = s_lo + lo;
+        const uint2 r = rects_sorted[pos];
         const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu;
         const uint32_t w = x1 - x0 + 1u;
-        const uint32_t k = e - s_off[lo];
+        const uint32_t k = e - (in_lds ? s_off[lo] : goff[lo]);
         const uint32_t ty = y0 + k / w, tx = x0 + k % w;
-        const uint64_t g = (uint64_t)out_base + e;
-        if (g < entry_cap) {
-            entry_keys[g] = ty * tiles_x + tx;
-            entry_vals[g] = s_idx[lo];
-        }
+        entry_keys[e] = ty * tiles_x + tx;
+        entry_vals[e] = sorted_idx[pos];
     }
 }
 
@@ -301,33 +298,28 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
 
 }  // namespace
 
-static uint32_t bin_blocks(uint32_t max_points) { return (max_points + BIN_ITEMS - 1) / BIN_ITEMS; }
+uint32_t bin_prefix_blocks(uint32_t max_points) { return (max_points + BIN_ITEMS - 1) / BIN_ITEMS; }
 
-// counts buffer doubles as the depth-ordered rect list (uint2 per sorted position): see ws_api.cpp
-int launch_bin_count_scan(const BinBuffers& b, hipStream_t stream) {
-    const uint32_t blocks = bin_blocks(b.max_points);
+int launch_bin_prefix(const BinBuffers& b, hipStream_t stream) {
+    const uint32_t blocks = bin_prefix_blocks(b.max_points);
     if (blocks == 0) return WS_OK;
-    hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx, b.rects,
-                       reinterpret_cast<uint2*>(b.counts), b.block_sums, b.counters);
-    WS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(BIN_THREADS), 0, stream, b.block_sums, blocks, b.counters, b.entry_cap);
+    hipLaunchKernelGGL(k_bin_prefix, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx, b.rects, b.rects_sorted,
+                       b.offsets, b.emit_start, b.block_status, b.counters, b.entry_cap, b.epoch);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }
 
 int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
-    const uint32_t blocks = bin_blocks(b.max_points);
+    const uint32_t blocks = (b.entry_cap + EMIT_TILE - 1) / EMIT_TILE;
     if (blocks == 0) return WS_OK;
-    hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx,
-                       reinterpret_cast<const uint2*>(b.counts), b.block_sums, b.entry_keys, b.entry_vals, b.entry_cap,
-                       b.counters, b.tiles_x);
+    hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx, b.rects_sorted, b.offsets,
+                       b.emit_start, b.entry_keys, b.entry_vals, b.counters, b.tiles_x);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }
 
 int launch_tile_ranges(const uint32_t* sorted_keys, const BinBuffers& b, hipStream_t stream) {
     const uint32_t ntiles = b.tiles_x * b.tiles_y;
-    WS_HIP(hipMemsetAsync(b.tile_ranges, 0, (size_t)ntiles * sizeof(uint2), stream));
     uint32_t blocks = (b.entry_cap + 256 * 8 - 1) / (256 * 8);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;

@@ -5,37 +5,35 @@
 //
 //   * one-sweep: one histogram pass over the keys for ALL digits, then one pass per digit that reads
 //     and writes every pair exactly once; the cross-tile prefix comes from a decoupled look-back over
-//     32-bit {flag,count} words (one per tile and digit) read/written with agent-scope atomics, so it
-//     is correct for any placement of tiles on the 8 XCDs (each XCD has its own L2).
+//     epoch-tagged 64-bit {epoch,flag,count} words (lookback.h), one per tile and digit, read and written
+//     with agent-scope atomics, so it is correct for any placement of tiles on the 8 XCDs.
+//   * the look-back is WINDOWED: thread d (digit d) fetches the words of 4 predecessor tiles per round
+//     trip.  With ~1000 co-resident tiles starting together a one-word-per-poll look-back needs ~sqrt(2k)
+//     dependent L2 round trips for tile k; the window divides that chain.
 //   * work tiles are handed out by an atomic ticket, so a tile only ever waits on tiles that have
-//     already started -- no dependence on dispatch order.
+//     already started -- no dependence on dispatch order.  Surplus workgroups (the grid is sized for the
+//     host-side bound) leave before touching the ticket.
 //   * ranking inside a wave uses wave64 ballots (8 per key) instead of the reference's O(subgroup)
 //     shared-memory match loop (radix_sort.wgsl:279-302), plus per-wave LDS digit counters.
 //   * keys and values are reordered through LDS so that global writes are contiguous per digit run.
 //   * tile = 256 threads x 16 keys = 4096 pairs (the reference uses 3840, gpu_rs.rs:14-21).
+//   * nothing is zeroed per pass: status words carry the epoch; histograms and tickets live in the
+//     caller's per-frame zero arena.
 //
 // A second, look-back-free path (per-tile histograms -> column scan -> scatter) is kept selectable
 // (algo 0) as an independent cross-check of the one-sweep path.
 #include <hip/hip_runtime.h>
 
+#include "lookback.h"
 #include "ws_internal.h"
 
 namespace ws {
 
 namespace {
 
-constexpr uint32_t FLAG_AGG = 1u << 30;
-constexpr uint32_t FLAG_INCL = 2u << 30;
-constexpr uint32_t VALUE_MASK = (1u << 30) - 1u;
-constexpr uint32_t SPIN_LIMIT = 1u << 24;
 constexpr int WAVES = SORT_THREADS / 64;
-
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+constexpr int HIST_COPIES = 8;  // replicated LDS bins: lanes l and l+8k share a copy -> <= 8-way conflicts
+constexpr int LB_WINDOW = 4;
 
 __device__ __forceinline__ uint32_t device_count(const uint32_t* d_count, uint32_t n) {
     if (!d_count) return n;
@@ -43,8 +41,8 @@ __device__ __forceinline__ uint32_t device_count(const uint32_t* d_count, uint32
     return c < n ? c : n;
 }
 
-// exclusive scan of one value per thread over a 256-thread block; `total` optional
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_tmp /*[WAVES]*/, uint32_t* total) {
+// exclusive scan of one value per thread over a 256-thread block
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_tmp /*[WAVES]*/) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = v;
 #pragma unroll
@@ -54,48 +52,51 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     }
     if (lane == 63) s_tmp[wave] = incl;
     __syncthreads();
-    uint32_t wave_off = 0, tot = 0;
+    uint32_t wave_off = 0;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        const uint32_t c = s_tmp[w];
-        if (w < wave) wave_off += c;
-        tot += c;
-    }
+    for (int w = 0; w < WAVES; ++w)
+        if (w < wave) wave_off += s_tmp[w];
     __syncthreads();  // s_tmp reusable
-    if (total) *total = tot;
     return wave_off + incl - v;
 }
 
 // ---- histogram of every participating digit in one read of the keys -----------------------------
+// LDS bins are replicated HIST_COPIES times (copy = lane & 7): depth keys and tile ids are strongly
+// clustered in their upper digits, and 64 lanes hammering one LDS word serialise.
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys,
                                                            const uint32_t* __restrict__ d_count, uint32_t n,
                                                            int begin_bit, int npass, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t sh[4 * RADIX];
-    for (int i = threadIdx.x; i < 4 * RADIX; i += SORT_THREADS) sh[i] = 0u;
+    __shared__ uint32_t sh[4 * RADIX * HIST_COPIES];
+    for (int i = threadIdx.x; i < npass * RADIX * HIST_COPIES; i += SORT_THREADS) sh[i] = 0u;
     __syncthreads();
     const uint32_t count = device_count(d_count, n);
     const uint32_t count4 = count >> 2;
+    const uint32_t copy = threadIdx.x & (HIST_COPIES - 1);
     const uint4* keys4 = reinterpret_cast<const uint4*>(keys);
     for (uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x; i < count4; i += gridDim.x * SORT_THREADS) {
         const uint4 k = keys4[i];
         for (int p = 0; p < npass; ++p) {
             const int sft = begin_bit + p * RADIX_BITS;
-            atomicAdd(&sh[p * RADIX + ((k.x >> sft) & (RADIX - 1))], 1u);
-            atomicAdd(&sh[p * RADIX + ((k.y >> sft) & (RADIX - 1))], 1u);
-            atomicAdd(&sh[p * RADIX + ((k.z >> sft) & (RADIX - 1))], 1u);
-            atomicAdd(&sh[p * RADIX + ((k.w >> sft) & (RADIX - 1))], 1u);
+            uint32_t* h = sh + p * RADIX * HIST_COPIES + copy;
+            atomicAdd(h + ((k.x >> sft) & (RADIX - 1)) * HIST_COPIES, 1u);
+            atomicAdd(h + ((k.y >> sft) & (RADIX - 1)) * HIST_COPIES, 1u);
+            atomicAdd(h + ((k.z >> sft) & (RADIX - 1)) * HIST_COPIES, 1u);
+            atomicAdd(h + ((k.w >> sft) & (RADIX - 1)) * HIST_COPIES, 1u);
         }
     }
     if (blockIdx.x == 0) {
         const uint32_t i = (count4 << 2) + threadIdx.x;
         if (i < count) {
             const uint32_t k = keys[i];
-            for (int p = 0; p < npass; ++p) atomicAdd(&sh[p * RADIX + ((k >> (begin_bit + p * RADIX_BITS)) & (RADIX - 1))], 1u);
+            for (int p = 0; p < npass; ++p)
+                atomicAdd(sh + p * RADIX * HIST_COPIES + ((k >> (begin_bit + p * RADIX_BITS)) & (RADIX - 1)) * HIST_COPIES + copy, 1u);
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < npass * RADIX; i += SORT_THREADS) {
-        const uint32_t c = sh[i];
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < HIST_COPIES; ++r) c += sh[i * HIST_COPIES + r];
         if (c) atomicAdd(&hist[i], c);
     }
 }
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_scan(const uint32_t*
     const uint32_t d = threadIdx.x;
     uint32_t total = 0;
     for (uint32_t t = 0; t < ntiles; ++t) total += tile_sums[(size_t)t * RADIX + d];
-    uint32_t running = block_exclusive_scan(total, s_tmp, nullptr);
+    uint32_t running = block_exclusive_scan(total, s_tmp);
     for (uint32_t t = 0; t < ntiles; ++t) {
         const uint32_t c = tile_sums[(size_t)t * RADIX + d];
         tile_sums[(size_t)t * RADIX + d] = running;
@@ -143,10 +144,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ d_count, uint32_t n, int shift, int iota,
     const uint32_t* __restrict__ hist,     // [256] global digit histogram of this pass      (LOOKBACK)
-    uint32_t* __restrict__ status,         // [tiles][256] look-back words, zeroed           (LOOKBACK)
-    uint32_t* __restrict__ ticket,         // tile dispenser, zeroed                         (LOOKBACK)
+    uint64_t* __restrict__ status,         // [tiles][256] epoch-tagged look-back words      (LOOKBACK)
+    uint32_t* __restrict__ ticket,         // tile dispenser, zero on entry                  (LOOKBACK)
     const uint32_t* __restrict__ tile_off, // [tiles][256] global exclusive offsets          (!LOOKBACK)
-    uint32_t* __restrict__ error_word) {
+    uint32_t epoch, uint32_t* __restrict__ error_word) {
     __shared__ uint32_t s_wave_hist[WAVES][RADIX];
     __shared__ uint32_t s_local_excl[RADIX];
     __shared__ uint32_t s_global_base[RADIX];
@@ -160,8 +161,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 
     const uint32_t count = device_count(d_count, n);
     // The grid is sized for the host-side bound n; only ceil(count / TILE) workgroups have work.  The surplus
-    // ones leave BEFORE touching the ticket, so exactly the needed number of tickets 0..ntiles-1 is drawn and
-    // the dispenser (one returning atomic per tile on a single address) is not loaded by idle workgroups.
+    // ones leave BEFORE touching the ticket, so exactly the needed number of tickets 0..ntiles-1 is drawn.
     if ((uint64_t)blockIdx.x * SORT_TILE >= count) return;  // block-uniform
     if (LOOKBACK) {
         if (tid == 0) s_tile = atomicAdd(ticket, 1u);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         const uint32_t cnt = (uint32_t)__popcll(m);
         const int leader = __ffsll((long long)m) - 1;
         uint32_t prev = 0u;
-        if (lane == leader) {
+        if (lane == leader) {  // one lane per distinct digit: plain read-modify-write, deterministic
             prev = s_wave_hist[wave][d];
             s_wave_hist[wave][d] = prev + cnt;
         }
@@ -217,50 +217,63 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 
     // ---- per digit (thread d = digit d): prefix over waves, tile count --------------------------------
     uint32_t tile_cnt = 0;
-    {
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const uint32_t c = s_wave_hist[w][tid];
-            s_wave_hist[w][tid] = tile_cnt;
-            tile_cnt += c;
-        }
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = s_wave_hist[w][tid];
+        s_wave_hist[w][tid] = tile_cnt;
+        tile_cnt += c;
     }
-    const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp, nullptr);
-    s_local_excl[tid] = local_excl;
-
     uint32_t global_base;  // global position of the first key of digit `tid` coming from this tile
     if (LOOKBACK) {
-        const uint32_t digit_base = block_exclusive_scan(hist[tid], s_tmp, nullptr);
+        // publish first, scan afterwards: successors can use the aggregate while this tile is still busy.
         // padding keys (0xFFFFFFFF, digit 255 in every pass) are ranked last and never published
         const uint32_t pub_cnt = tile_cnt - ((tid == RADIX - 1) ? ((uint32_t)SORT_TILE - valid) : 0u);
-        uint32_t* my_status = status + (size_t)t * RADIX + tid;
-        st_agent(my_status, (t == 0 ? FLAG_INCL : FLAG_AGG) | pub_cnt);
+        uint64_t* my_status = status + (size_t)t * RADIX + tid;
+        lb::st(my_status, lb::pack(epoch, t == 0 ? lb::FLAG_INCL : lb::FLAG_AGG, pub_cnt));
+        const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp);
+        s_local_excl[tid] = local_excl;
+        const uint32_t digit_base = block_exclusive_scan(hist[tid], s_tmp);
         uint32_t prev_sum = 0;
         if (t > 0) {
-            int64_t i = (int64_t)t - 1;
+            int64_t i = (int64_t)t - 1;  // next predecessor to consume
             uint32_t spins = 0;
-            while (true) {
-                const uint32_t w = ld_agent(status + (size_t)i * RADIX + tid);
-                const uint32_t flag = w >> 30;
-                if (flag == 0u) {
-                    if (++spins > SPIN_LIMIT) {
-                        if (error_word) atomicOr(error_word, 4u);
+            bool done = false;
+            while (!done) {
+                uint64_t w[LB_WINDOW];
+#pragma unroll
+                for (int j = 0; j < LB_WINDOW; ++j) {
+                    const int64_t idx = i - j;
+                    w[j] = idx >= 0 ? lb::ld(status + (size_t)idx * RADIX + tid) : lb::pack(epoch, lb::FLAG_INCL, 0u);
+                }
+                int consumed = 0;
+#pragma unroll
+                for (int j = 0; j < LB_WINDOW; ++j) {
+                    if (done || consumed < j) continue;  // stop at the first unpublished word
+                    const uint32_t flag = lb::flag_of(w[j], epoch);
+                    if (flag == 0u) continue;
+                    prev_sum += lb::value_of(w[j]);
+                    consumed = j + 1;
+                    if (flag == lb::FLAG_INCL) done = true;
+                }
+                i -= consumed;
+                if (!done && consumed < LB_WINDOW) {
+                    if (++spins > lb::SPIN_LIMIT) {
+                        if (error_word) atomicOr(error_word, 8u);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
-                    continue;
                 }
-                prev_sum += w & VALUE_MASK;
-                if (flag == 2u) break;
-                --i;
             }
-            st_agent(my_status, FLAG_INCL | (prev_sum + pub_cnt));
+            lb::st(my_status, lb::pack(epoch, lb::FLAG_INCL, prev_sum + pub_cnt));
         }
         global_base = digit_base + prev_sum;
+        s_global_base[tid] = global_base - local_excl;  // add the tile-local position to get the address
     } else {
+        const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp);
+        s_local_excl[tid] = local_excl;
         global_base = tile_off[(size_t)t * RADIX + tid];
+        s_global_base[tid] = global_base - local_excl;
     }
-    s_global_base[tid] = global_base - local_excl;  // add the tile-local position to get the address
     __syncthreads();
 
     // ---- reorder keys through LDS, write contiguous digit runs ----------------------------------------
@@ -294,14 +307,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 
 }  // namespace
 
-size_t sort_status_words(uint32_t cap) {
-    const size_t tiles = ((size_t)cap + SORT_TILE - 1) / SORT_TILE;
-    return 4 * (tiles ? tiles : 1) * RADIX;
-}
-
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
-                      int begin_bit, int end_bit, bool implicit_iota, int algo, hipStream_t stream,
-                      uint32_t** out_keys, uint32_t** out_vals) {
+                      int begin_bit, int end_bit, bool implicit_iota, bool hist_ready, int algo, uint32_t epoch,
+                      hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals) {
     if (out_keys) *out_keys = keys;
     if (out_vals) *out_vals = vals;
     if (n == 0) return WS_OK;
@@ -317,13 +325,10 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
     uint32_t* kout = sc.keys_alt;
     uint32_t* vout = sc.vals_alt;
 
-    if (algo == 1) {
-        WS_HIP(hipMemsetAsync(sc.hist, 0, 4 * RADIX * sizeof(uint32_t), stream));
-        WS_HIP(hipMemsetAsync(sc.status, 0, (size_t)npass * sc.tiles * RADIX * sizeof(uint32_t), stream));
-        WS_HIP(hipMemsetAsync(sc.tickets, 0, 4 * sizeof(uint32_t), stream));
+    if (algo == 1 && !hist_ready) {
         uint32_t hist_blocks = (n / 4 + SORT_THREADS * 8 - 1) / (SORT_THREADS * 8);
         if (hist_blocks < 1) hist_blocks = 1;
-        if (hist_blocks > 2048) hist_blocks = 2048;
+        if (hist_blocks > 1024) hist_blocks = 1024;
         hipLaunchKernelGGL(k_sort_hist, dim3(hist_blocks), dim3(SORT_THREADS), 0, stream, kin, d_count, n, begin_bit,
                            npass, sc.hist);
         WS_HIP(hipGetLastError());
@@ -334,14 +339,14 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
         if (algo == 1) {
             hipLaunchKernelGGL(k_sort_scatter<true>, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout,
                                d_count, n, shift, iota, sc.hist + p * RADIX, sc.status + (size_t)p * sc.tiles * RADIX,
-                               sc.tickets + p, (const uint32_t*)nullptr, sc.error);
+                               sc.tickets + p, (const uint32_t*)nullptr, epoch, sc.error);
         } else {
             hipLaunchKernelGGL(k_sort_tile_hist, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift,
                                sc.tile_sums);
             hipLaunchKernelGGL(k_sort_tile_scan, dim3(1), dim3(SORT_THREADS), 0, stream, d_count, n, sc.tile_sums);
             hipLaunchKernelGGL(k_sort_scatter<false>, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout,
-                               d_count, n, shift, iota, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                               (uint32_t*)nullptr, sc.tile_sums, (uint32_t*)nullptr);
+                               d_count, n, shift, iota, (const uint32_t*)nullptr, (uint64_t*)nullptr,
+                               (uint32_t*)nullptr, sc.tile_sums, epoch, (uint32_t*)nullptr);
         }
         WS_HIP(hipGetLastError());
         uint32_t* tk = kin;

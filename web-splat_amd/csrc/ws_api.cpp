@@ -48,10 +48,19 @@ static void dfree(T*& p) {
 
 using namespace ws;
 
+// small per-sort zero arena of a stand-alone sorter: tickets, error word, digit histograms
+struct SorterZero {
+    uint32_t tickets[4];
+    uint32_t error;
+    uint32_t _pad[3];
+    uint32_t hist[4 * RADIX];
+};
+
 struct ws_sorter {
     ws_context* ctx = nullptr;
     SortScratch sc;
-    uint32_t* error = nullptr;
+    SorterZero* zero = nullptr;
+    uint32_t epoch = 0;
 };
 
 struct ws_renderer {
@@ -71,12 +80,17 @@ struct ws_renderer {
     uint2* rects = nullptr;
     uint2* rects_sorted = nullptr;
     uint32_t* src_index = nullptr;
-    uint32_t* block_status = nullptr;
-    uint32_t* bin_block_sums = nullptr;
+    uint64_t* k1_status = nullptr;   // epoch-tagged look-back words (never re-zeroed)
+    uint64_t* bin_status = nullptr;
+    uint32_t* bin_offsets = nullptr;
+    uint32_t* emit_start = nullptr;
     uint32_t *ekeys_a = nullptr, *ekeys_b = nullptr, *evals_a = nullptr, *evals_b = nullptr;
-    uint2* tile_ranges = nullptr;
-    FrameCounters* counters = nullptr;
+    FrameZero* zero = nullptr;       // counters + histograms + tile ranges: ONE memset per frame
+    size_t zero_bytes = 0;
+    uint2* tile_ranges = nullptr;    // inside the zero arena
+    FrameCounters* counters = nullptr;  // = &zero->counters
     SortScratch sort_depth, sort_tiles;
+    uint32_t epoch = 0;
 
     // last prepared frame
     bool prepared = false;
@@ -96,13 +110,13 @@ static void free_sort_scratch(SortScratch& sc, bool own_alt) {
         dfree(sc.keys_alt);
         dfree(sc.vals_alt);
     }
-    dfree(sc.hist);
     dfree(sc.status);
     dfree(sc.tile_sums);
     sc = SortScratch();
 }
 
-static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, uint32_t* tickets) {
+// status words are zeroed ONCE here; afterwards the epoch tag makes stale words invisible (lookback.h)
+static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt) {
     sc.cap = cap;
     sc.tiles = (cap + SORT_TILE - 1) / SORT_TILE;
     if (sc.tiles == 0) sc.tiles = 1;
@@ -111,10 +125,10 @@ static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, uint3
         if ((rc = dmalloc(&sc.keys_alt, (size_t)cap + 4))) return rc;
         if ((rc = dmalloc(&sc.vals_alt, (size_t)cap + 4))) return rc;
     }
-    if ((rc = dmalloc(&sc.hist, 4 * RADIX))) return rc;
-    if ((rc = dmalloc(&sc.status, 4 * (size_t)sc.tiles * RADIX))) return rc;
+    const size_t status_words = 4 * (size_t)sc.tiles * RADIX;
+    if ((rc = dmalloc(&sc.status, status_words))) return rc;
+    WS_HIP(hipMemset(sc.status, 0, status_words * sizeof(uint64_t)));
     if ((rc = dmalloc(&sc.tile_sums, (size_t)sc.tiles * RADIX))) return rc;
-    sc.tickets = tickets;
     return WS_OK;
 }
 
@@ -127,14 +141,18 @@ static void renderer_free_scratch(ws_renderer* r) {
     dfree(r->rects);
     dfree(r->rects_sorted);
     dfree(r->src_index);
-    dfree(r->block_status);
-    dfree(r->bin_block_sums);
+    dfree(r->k1_status);
+    dfree(r->bin_status);
+    dfree(r->bin_offsets);
+    dfree(r->emit_start);
     dfree(r->ekeys_a);
     dfree(r->ekeys_b);
     dfree(r->evals_a);
     dfree(r->evals_b);
-    dfree(r->tile_ranges);
-    dfree(r->counters);
+    if (r->zero) (void)hipFree(r->zero);
+    r->zero = nullptr;
+    r->tile_ranges = nullptr;
+    r->counters = nullptr;
     free_sort_scratch(r->sort_depth, false);
     free_sort_scratch(r->sort_tiles, false);
     r->cap_points = 0;
@@ -149,12 +167,13 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
         // (16 B per entry: 1.2 M Gaussians -> 0.46 GB, 5 M -> 1.9 GB)
         want_cap = std::max<uint64_t>(8ull << 20, 24ull * n);
     }
-    want_cap = std::min<uint64_t>(want_cap, 0xFFFFF000ull);
-    if (r->cap_points == n && r->vw == vw && r->vh == vh && r->entry_cap == (uint32_t)want_cap && r->counters) return WS_OK;
+    // look-back words carry 30-bit counts (lookback.h): keep D below 2^30
+    want_cap = std::min<uint64_t>(want_cap, (1ull << 30) - 2 * EMIT_TILE);
+    if (r->cap_points == n && r->vw == vw && r->vh == vh && r->entry_cap == (uint32_t)want_cap && r->zero) return WS_OK;
     WS_HIP(hipDeviceSynchronize());
     renderer_free_scratch(r);
     int rc;
-    const size_t np = (size_t)n + 4;
+    const size_t np = (size_t)n + 8;
     if ((rc = dmalloc(&r->splats, np * 20))) return rc;
     if ((rc = dmalloc(&r->keys_a, np))) return rc;
     if ((rc = dmalloc(&r->keys_b, np))) return rc;
@@ -163,25 +182,35 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     if ((rc = dmalloc(&r->rects, np))) return rc;
     if ((rc = dmalloc(&r->rects_sorted, np))) return rc;
     if ((rc = dmalloc(&r->src_index, np))) return rc;
-    if ((rc = dmalloc(&r->block_status, (size_t)preprocess_blocks(n) + 1))) return rc;
-    if ((rc = dmalloc(&r->bin_block_sums, (size_t)n / 2048 + 2))) return rc;
+    if ((rc = dmalloc(&r->bin_offsets, np))) return rc;
+    const size_t k1_words = (size_t)preprocess_blocks(n) + 1, bin_words = (size_t)bin_prefix_blocks(n) + 1;
+    if ((rc = dmalloc(&r->k1_status, k1_words))) return rc;
+    if ((rc = dmalloc(&r->bin_status, bin_words))) return rc;
+    WS_HIP(hipMemset(r->k1_status, 0, k1_words * sizeof(uint64_t)));
+    WS_HIP(hipMemset(r->bin_status, 0, bin_words * sizeof(uint64_t)));
     r->entry_cap = (uint32_t)want_cap;
-    const size_t ne = (size_t)r->entry_cap + 4;
+    const size_t ne = (size_t)r->entry_cap + 8;
     if ((rc = dmalloc(&r->ekeys_a, ne))) return rc;
     if ((rc = dmalloc(&r->ekeys_b, ne))) return rc;
     if ((rc = dmalloc(&r->evals_a, ne))) return rc;
     if ((rc = dmalloc(&r->evals_b, ne))) return rc;
+    if ((rc = dmalloc(&r->emit_start, (size_t)r->entry_cap / EMIT_TILE + 4))) return rc;
     r->tiles_x = (vw + TILE - 1) / TILE;
     r->tiles_y = (vh + TILE - 1) / TILE;
-    if ((rc = dmalloc(&r->tile_ranges, (size_t)r->tiles_x * r->tiles_y))) return rc;
-    if ((rc = dmalloc(&r->counters, 1))) return rc;
-    WS_HIP(hipMemset(r->counters, 0, sizeof(FrameCounters)));
-    if ((rc = alloc_sort_scratch(r->sort_depth, n ? n : 1, false, nullptr))) return rc;
+    // the per-frame zero arena: counters | depth histograms | tile histograms | tile ranges
+    r->zero_bytes = sizeof(FrameZero) + (size_t)r->tiles_x * r->tiles_y * sizeof(uint2);
+    WS_HIP(hipMalloc(reinterpret_cast<void**>(&r->zero), r->zero_bytes));
+    WS_HIP(hipMemset(r->zero, 0, r->zero_bytes));
+    r->counters = &r->zero->counters;
+    r->tile_ranges = reinterpret_cast<uint2*>(reinterpret_cast<char*>(r->zero) + sizeof(FrameZero));
+    if ((rc = alloc_sort_scratch(r->sort_depth, n ? n : 1, false))) return rc;
     r->sort_depth.keys_alt = r->keys_b;
     r->sort_depth.vals_alt = r->vals_b;
-    if ((rc = alloc_sort_scratch(r->sort_tiles, r->entry_cap, false, nullptr))) return rc;
+    r->sort_depth.hist = r->zero->depth_hist;
+    if ((rc = alloc_sort_scratch(r->sort_tiles, r->entry_cap, false))) return rc;
     r->sort_tiles.keys_alt = r->ekeys_b;
     r->sort_tiles.vals_alt = r->evals_b;
+    r->sort_tiles.hist = r->zero->tile_hist;
     r->sort_depth.tickets = r->counters->sort_ticket;
     r->sort_tiles.tickets = r->counters->sort_ticket + 4;
     r->sort_depth.error = &r->counters->overflow;
@@ -189,6 +218,7 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     r->cap_points = n;
     r->vw = vw;
     r->vh = vh;
+    r->epoch = 0;  // fresh (zeroed) status arrays
     return WS_OK;
 }
 
@@ -491,12 +521,21 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     kb.keys = r->keys_a;
     kb.rects = r->rects;
     kb.src_index = r->capture ? r->src_index : nullptr;
-    kb.block_status = r->block_status;
+    kb.block_status = r->k1_status;
     kb.counters = r->counters;
 
-    // GPURSSorter::record_reset_indirect_buffer (gpu_rs.rs:720-727): keys_size = 0, dispatch = 0
-    WS_HIP(hipMemsetAsync(r->counters, 0, sizeof(FrameCounters), stream));
-    WS_HIP(hipMemsetAsync(r->block_status, 0, ((size_t)preprocess_blocks(pc->num_points) + 1) * sizeof(uint32_t), stream));
+    // look-back epoch of this frame (lookback.h); on wrap-around the status arrays are re-zeroed
+    if (++r->epoch == 0) {
+        WS_HIP(hipMemsetAsync(r->k1_status, 0, ((size_t)preprocess_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
+        WS_HIP(hipMemsetAsync(r->bin_status, 0, ((size_t)bin_prefix_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
+        WS_HIP(hipMemsetAsync(r->sort_depth.status, 0, 4 * (size_t)r->sort_depth.tiles * RADIX * sizeof(uint64_t), stream));
+        WS_HIP(hipMemsetAsync(r->sort_tiles.status, 0, 4 * (size_t)r->sort_tiles.tiles * RADIX * sizeof(uint64_t), stream));
+        r->epoch = 1;
+    }
+    kp.epoch = r->epoch;
+    // GPURSSorter::record_reset_indirect_buffer (gpu_rs.rs:720-727): keys_size = 0, dispatch = 0 -- here ONE
+    // memset clears the counters, every ticket, both sorts' digit histograms and the tile ranges
+    WS_HIP(hipMemsetAsync(r->zero, 0, r->zero_bytes, stream));
     if (r->timers) WS_HIP(hipEventRecord(r->ev[0], stream));
     if ((rc = launch_preprocess(kp, kb, pc->compressed, stream))) return rc;
     if (r->timers) WS_HIP(hipEventRecord(r->ev[1], stream));
@@ -504,7 +543,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     // depth sort: V (key, store index) pairs, 4 x 8 bit, values start as iota (preprocess.wgsl:274)
     uint32_t *sk = nullptr, *sv = nullptr;
     if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
-                                true, r->ctx->sort_algo, stream, &sk, &sv)))
+                                true, false, r->ctx->sort_algo, r->epoch, stream, &sk, &sv)))
         return rc;
     r->sorted_idx = sv;
     if (r->timers) WS_HIP(hipEventRecord(r->ev[2], stream));
@@ -513,8 +552,10 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     BinBuffers bb;
     bb.sorted_idx = r->sorted_idx;
     bb.rects = r->rects;
-    bb.counts = reinterpret_cast<uint32_t*>(r->rects_sorted);
-    bb.block_sums = r->bin_block_sums;
+    bb.rects_sorted = r->rects_sorted;
+    bb.offsets = r->bin_offsets;
+    bb.emit_start = r->emit_start;
+    bb.block_status = r->bin_status;
     bb.entry_keys = r->ekeys_a;
     bb.entry_vals = r->evals_a;
     bb.entry_cap = r->entry_cap;
@@ -523,14 +564,15 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     bb.max_points = pc->num_points;
     bb.tiles_x = r->tiles_x;
     bb.tiles_y = r->tiles_y;
-    if ((rc = launch_bin_count_scan(bb, stream))) return rc;
+    bb.epoch = r->epoch;
+    if ((rc = launch_bin_prefix(bb, stream))) return rc;
     if ((rc = launch_bin_emit(bb, stream))) return rc;
     const uint32_t ntiles = r->tiles_x * r->tiles_y;
     int tile_bits = 8;
     while ((1ull << tile_bits) < ntiles) tile_bits += 8;
     uint32_t *ek = nullptr, *evv = nullptr;
     if ((rc = launch_sort_pairs(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap, 0,
-                                tile_bits, false, r->ctx->sort_algo, stream, &ek, &evv)))
+                                tile_bits, false, false, r->ctx->sort_algo, r->epoch, stream, &ek, &evv)))
         return rc;
     r->entries_sorted = evv;
     if ((rc = launch_tile_ranges(ek, bb, stream))) return rc;
@@ -651,13 +693,12 @@ int ws_sorter_create(ws_context* ctx, uint32_t max_n, ws_sorter** out) {
     ws_sorter* s = new (std::nothrow) ws_sorter();
     if (!s) return fail(WS_ERR_OOM, "ws_sorter_create: host allocation failed");
     s->ctx = ctx;
-    int rc = alloc_sort_scratch(s->sc, max_n, true, nullptr);
-    if (rc == WS_OK) rc = dmalloc(&s->sc.tickets, 8);
+    int rc = alloc_sort_scratch(s->sc, max_n, true);
+    if (rc == WS_OK) rc = dmalloc(&s->zero, 1);
     if (rc == WS_OK) {
-        s->error = s->sc.tickets + 4;
-        s->sc.error = s->error;
-        hipError_t e = hipMemset(s->sc.tickets, 0, 8 * sizeof(uint32_t));
-        if (e != hipSuccess) rc = hip_fail(e, "ws_sorter_create: memset");
+        s->sc.tickets = s->zero->tickets;
+        s->sc.error = &s->zero->error;
+        s->sc.hist = s->zero->hist;
     }
     if (rc != WS_OK) {
         ws_sorter_destroy(s);
@@ -670,7 +711,7 @@ int ws_sorter_create(ws_context* ctx, uint32_t max_n, ws_sorter** out) {
 void ws_sorter_destroy(ws_sorter* s) {
     if (!s) return;
     (void)hipDeviceSynchronize();
-    dfree(s->sc.tickets);
+    dfree(s->zero);
     free_sort_scratch(s->sc, true);
     delete s;
 }
@@ -679,8 +720,14 @@ int ws_sorter_sort(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, const ui
                    void* stream_v) {
     if (!s || !d_keys || !d_payload) return fail(WS_ERR_INVALID, "ws_sorter_sort: null argument");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (++s->epoch == 0) {
+        WS_HIP(hipMemsetAsync(s->sc.status, 0, 4 * (size_t)s->sc.tiles * RADIX * sizeof(uint64_t), stream));
+        s->epoch = 1;
+    }
+    WS_HIP(hipMemsetAsync(s->zero, 0, sizeof(SorterZero), stream));
     uint32_t *ok = nullptr, *ov = nullptr;
-    int rc = launch_sort_pairs(s->sc, d_keys, d_payload, d_count, n, 0, 32, false, s->ctx->sort_algo, stream, &ok, &ov);
+    int rc = launch_sort_pairs(s->sc, d_keys, d_payload, d_count, n, 0, 32, false, false, s->ctx->sort_algo, s->epoch,
+                               stream, &ok, &ov);
     if (rc) return rc;
     if (ok != d_keys) return fail(WS_ERR_STATE, "ws_sorter_sort: internal ping-pong parity error");
     return WS_OK;

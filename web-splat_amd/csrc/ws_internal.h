@@ -22,21 +22,34 @@ int hip_fail(hipError_t e, const char* what);
     } while (0)
 
 // ---- geometry of the rasteriser ----------------------------------------------------------------
-constexpr int TILE = 16;                     // 16x16-pixel tiles (north star)
+constexpr int TILE = 16;                      // 16x16-pixel tiles (north star)
 constexpr float CUTOFF = 2.3539888583335364f; // gaussian.wgsl:2  sqrt(ln 255)
-constexpr float CUT_A = 2.0f * CUTOFF;       // gaussian.wgsl:61 discard if a > 2*CUTOFF
-constexpr float T_MIN = 1.0f / 16384.0f;     // front-to-back early-out (6.1e-5; DESIGN.md section Blend)
+constexpr float CUT_A = 2.0f * CUTOFF;        // gaussian.wgsl:61 discard if a > 2*CUTOFF
+constexpr float T_MIN = 1.0f / 16384.0f;      // front-to-back early-out (6.1e-5; DESIGN.md section Blend)
 
-// ---- device-side frame counters (one 64-B record per renderer, zeroed each frame) ---------------
+// ---- device-side frame state, zeroed by ONE memset at the start of every frame ------------------
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+
 struct FrameCounters {
     uint32_t num_visible;    // V  (reference: SortInfos.keys_size, preprocess.wgsl:262)
     uint32_t k1_ticket;      // dynamic block id dispenser of the preprocess kernel
     uint32_t num_entries;    // D  (clamped to capacity)
-    uint32_t overflow;       // D exceeded capacity
-    uint32_t sort_ticket[8]; // per-pass dynamic tile id dispensers of the radix sort
-    uint32_t _pad[4];
+    uint32_t overflow;       // bit 0: D exceeded capacity; bits 1..3: a look-back spin timed out (K1/bin/sort)
+    uint32_t sort_ticket[8]; // per-pass tile dispensers: [0..3] depth sort, [4..7] tile sort
+    uint32_t bin_ticket;     // block dispenser of the binning prefix kernel
+    uint32_t _pad[3];
 };
 static_assert(sizeof(FrameCounters) == 64, "FrameCounters layout");
+
+// Everything a frame needs zeroed lives in one contiguous arena: counters, the digit histograms of both
+// sorts, and the tile ranges (appended after this struct).
+struct FrameZero {
+    FrameCounters counters;
+    uint32_t depth_hist[4 * RADIX];
+    uint32_t tile_hist[4 * RADIX];
+    // uint2 tile_ranges[tiles] follows
+};
 
 // ---- kernel parameter blocks (passed by value; the analogue of the reference's uniform buffers) ---
 struct K1Params {
@@ -46,6 +59,7 @@ struct K1Params {
     uint32_t num_points;
     uint32_t sh_deg_layout;  // compressed: number of coefficients per packed SH record, (sh_deg+1)^2
     uint32_t tiles_x, tiles_y;
+    uint32_t epoch;          // look-back epoch of this frame (lookback.h)
 };
 
 // uncompressed point cloud in HBM: eight planes of 16-B chunks, plane p of Gaussian i at
@@ -57,32 +71,30 @@ constexpr int PC_PLANES = 8;
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_KPT = 16;                          // keys per thread
 constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;    // 4096 keys per work tile
-constexpr int RADIX_BITS = 8;
-constexpr int RADIX = 1 << RADIX_BITS;
 
 struct SortScratch {
     uint32_t* keys_alt = nullptr;     // ping-pong partner of the caller's key buffer   [cap]
     uint32_t* vals_alt = nullptr;     // ping-pong partner of the caller's value buffer [cap]
-    uint32_t* hist = nullptr;         // [4][256] digit histograms
-    uint32_t* status = nullptr;       // [4][tiles][256] decoupled look-back words
-    uint32_t* tickets = nullptr;      // [4] (may alias FrameCounters::sort_ticket)
+    uint32_t* hist = nullptr;         // [4][256] digit histograms, zero on entry
+    uint64_t* status = nullptr;       // [4][tiles][256] epoch-tagged look-back words (never re-zeroed)
+    uint32_t* tickets = nullptr;      // [4] tile dispensers, zero on entry
     uint32_t* tile_sums = nullptr;    // [tiles][256] reduce-then-scan path (WS_SORT_ALGO=0)
-    uint32_t* error = nullptr;        // device word OR-ed with 4 if a look-back spin ever times out
+    uint32_t* error = nullptr;        // device word OR-ed with 8 if a look-back spin ever times out
     uint32_t cap = 0;
     uint32_t tiles = 0;
 };
-
-size_t sort_status_words(uint32_t cap);
 
 // Launch an ascending stable LSD radix sort of (key, value) pairs on `stream`.
 //   d_count == nullptr -> sort n pairs; else the count is read on the device (clamped to n).
 //   begin_bit/end_bit: key bits that participate (multiples of 8).
 //   implicit_iota: values of the first pass are the element positions (vals in is not read).
+//   hist_ready: the digit histograms in sc.hist were already accumulated by the producer of the keys.
+//   sc.hist and sc.tickets must be zero on entry (the renderer zeroes them with the frame arena).
 // The result lands in (keys, vals) if the pass count is even, else in (scratch.keys_alt, vals_alt);
 // *out_keys / *out_vals receive the final pointers.
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
-                      int begin_bit, int end_bit, bool implicit_iota, int algo, hipStream_t stream,
-                      uint32_t** out_keys, uint32_t** out_vals);
+                      int begin_bit, int end_bit, bool implicit_iota, bool hist_ready, int algo, uint32_t epoch,
+                      hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals);
 
 // ---- preprocess ---------------------------------------------------------------------------------
 struct K1Buffers {
@@ -94,18 +106,22 @@ struct K1Buffers {
     uint32_t* keys;              // [N] depth keys
     uint2* rects;                // [N] tile rect (x0 | y0<<16, x1 | y1<<16), inclusive; x0 > x1 = empty
     uint32_t* src_index;         // [N] or nullptr (capture mode)
-    uint32_t* block_status;      // [blocks] look-back words, zeroed per frame
+    uint64_t* block_status;      // [blocks] epoch-tagged look-back words
     FrameCounters* counters;
 };
 int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, hipStream_t stream);
 uint32_t preprocess_blocks(uint32_t n);
 
 // ---- binning + blend ----------------------------------------------------------------------------
+constexpr int EMIT_TILE = 4096;  // tile entries produced per workgroup of the emit kernel
+
 struct BinBuffers {
     const uint32_t* sorted_idx;  // [V] store indices in draw order (far -> near)
     const uint2* rects;          // [N] by store index
-    uint32_t* counts;            // [N] tiles touched per sorted position, then exclusive offsets
-    uint32_t* block_sums;        // scan scratch
+    uint2* rects_sorted;         // [N] by draw position
+    uint32_t* offsets;           // [N] exclusive prefix of tiles touched, by draw position
+    uint32_t* emit_start;        // [cap / EMIT_TILE + 2] draw position owning entry m * EMIT_TILE
+    uint64_t* block_status;      // look-back words of the prefix kernel
     uint32_t* entry_keys;        // [cap] tile ids
     uint32_t* entry_vals;        // [cap] store indices
     uint32_t entry_cap;
@@ -113,10 +129,12 @@ struct BinBuffers {
     FrameCounters* counters;
     uint32_t max_points;         // N (upper bound of V)
     uint32_t tiles_x, tiles_y;
+    uint32_t epoch;
 };
-int launch_bin_count_scan(const BinBuffers& b, hipStream_t stream);
+int launch_bin_prefix(const BinBuffers& b, hipStream_t stream);
 int launch_bin_emit(const BinBuffers& b, hipStream_t stream);
 int launch_tile_ranges(const uint32_t* sorted_keys, const BinBuffers& b, hipStream_t stream);
+uint32_t bin_prefix_blocks(uint32_t max_points);
 
 struct BlendParams {
     const uint8_t* splats;      // [V] x 20 B
@@ -130,10 +148,10 @@ struct BlendParams {
 };
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
 
-// ---- host math (host_camera.cpp) ----------------------------------------------------------------
+// ---- host math (host_math.cpp) ------------------------------------------------------------------
 void build_camera_uniform(const ws_camera& cam, const uint32_t viewport[2], ws_camera_uniform* out);
 
-// ---- half helpers usable on both sides ------------------------------------------------------------
+// ---- half helpers ---------------------------------------------------------------------------------
 uint16_t host_f32_to_f16(float f);
 float host_f16_to_f32(uint16_t h);
 
