@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--views", type=int, default=64)
     ap.add_argument("--format", default="rgba32float")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("WS_BENCH_STREAMS", "1")),
+                    help="frames in flight per GPU: one renderer (private scratch) + one HIP stream each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -109,17 +111,23 @@ def main():
     ctx = ws.Context(local_rank)
     gpc, views, viewport = build_workload(ws, a.workload, a.views)
     pc = ws.PointCloud(ctx, gpc)
-    r = ws.GaussianRenderer(ctx, a.format, 3, False)
     w, h = viewport
-    target = torch.empty((h, w, 4), dtype={"rgba32float": torch.float32, "rgba16float": torch.float16,
-                                           "rgba8unorm": torch.uint8}[a.format], device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    my_views = [views[i] for i in range(len(views)) if i % world == rank] or views[:1]
+    tdtype = {"rgba32float": torch.float32, "rgba16float": torch.float16, "rgba8unorm": torch.uint8}[a.format]
+    # one renderer (private scratch), one output image and one HIP stream per frame in flight; the scene is shared
+    nstreams = max(1, a.streams)
+    renderers = [ws.GaussianRenderer(ctx, a.format, 3, False) for _ in range(nstreams)]
+    targets = [torch.empty((h, w, 4), dtype=tdtype, device="cuda") for _ in range(nstreams)]
+    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
+    streams = [s_.cuda_stream for s_ in tstreams]
+    r = renderers[0]
+    from websplat.shard import views_for_rank
+    my_views = [views[i] for i in views_for_rank(len(views), rank, world)] or views[:1]
 
     def frame(i):
         v = my_views[i % len(my_views)]
-        r.prepare(pc, v, stream=stream)
-        r.render(pc, target_ptr=target.data_ptr(), stream=stream)
+        k = i % nstreams
+        renderers[k].prepare(pc, v, stream=streams[k])
+        renderers[k].render(pc, target_ptr=targets[k].data_ptr(), stream=streams[k])
 
     def barrier():
         torch.cuda.synchronize()
@@ -143,6 +151,8 @@ def main():
     # ---- per-stage kernel time (HIP events on the launch stream) for the roofline block, rank 0 only ----
     out = None
     if rank == 0:
+        torch.cuda.synchronize()
+        nstreams = 1  # stage timing: one frame at a time on renderer 0
         r.enable_timers(True)
         acc = {"preprocess": 0.0, "sorting": 0.0, "binning": 0.0, "rasterization": 0.0}
         stat_acc = {"num_visible": 0, "num_tile_entries": 0}
@@ -185,8 +195,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {n} Gaussians (sh_deg 3), {w}x{h}, {a.format} target, "
-                                   f"{len(views)} orbit views sharded view i -> rank i mod N",
-                       "gaussians": n, "width": w, "height": h, "views": len(views),
+                                   f"{len(views)} orbit views sharded view i -> rank i mod N, {a.streams} frame(s) in flight per GPU",
+                       "gaussians": n, "width": w, "height": h, "views": len(views), "streams": a.streams,
                        "avg_visible": V, "avg_tile_entries": D, "overflow": overflow},
             "roofline": roofline,
             "stages": stages,
@@ -196,7 +206,8 @@ def main():
         elif world == 1:
             out["cpu_baseline"] = None
     barrier()
-    r.close()
+    for rr in renderers:
+        rr.close()
     pc.close()
     ctx.close()
     if dist is not None:
