@@ -164,3 +164,16 @@ def test_target_modes_order(oracle):
     # a unorm8 target saturates at 1 (SH colours are not clamped above), so compare where nothing saturated
     ok = (f32.max(axis=-1) < 0.95)
     assert np.abs(u8 - f32)[ok].max() < 6e-2
+
+
+def test_golden_sort_fixture(oracle):
+    """tests/golden/sort_known_answer.json restates the reference's own vector (gpu_rs.rs:295-331)."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sort_known_answer.json")))
+    n = g["n"]
+    keys_in = np.arange(n - 1, -1, -1, dtype=np.float32).view(np.uint32)
+    assert [int(x) for x in keys_in[:8]] == g["first8_in_bits"]
+    k, _ = oracle.sort_pairs(keys_in, np.arange(n, dtype=np.uint32))
+    assert [int(x) for x in k[:8]] == g["first8_out_bits"]
+    assert np.array_equal(k.view(np.float32), np.arange(n, dtype=np.float32))
