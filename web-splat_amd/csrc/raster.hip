@@ -142,8 +142,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
                                                          uint32_t* __restrict__ entry_keys,
                                                          uint32_t* __restrict__ entry_vals,
                                                          const FrameCounters* __restrict__ counters,
-                                                         uint32_t tiles_x) {
+                                                         uint32_t tiles_x, uint32_t* __restrict__ tile_hist,
+                                                         uint32_t tile_hist_pitch) {
+    constexpr int COPIES = 8;
     __shared__ uint32_t s_off[EMIT_TILE + 2];
+    __shared__ uint32_t s_hist[RADIX * COPIES];
     const uint32_t d = counters->num_entries;
     const uint32_t v = counters->num_visible;
     const uint32_t e0 = blockIdx.x * EMIT_TILE;
@@ -159,6 +162,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
     const bool in_lds = ns <= (uint32_t)EMIT_TILE + 2u;  // block-uniform
     if (in_lds)
         for (uint32_t k = threadIdx.x; k < ns; k += BIN_THREADS) s_off[k] = offsets[s_lo + k];
+    for (int k = threadIdx.x; k < RADIX * COPIES; k += BIN_THREADS) s_hist[k] = 0u;
+    const uint32_t copy = threadIdx.x & (COPIES - 1);
     __syncthreads();
     const uint32_t* goff = offsets + s_lo;
     for (uint32_t e = e0 + threadIdx.x; e < e1; e += BIN_THREADS) {
@@ -176,8 +181,17 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
         const uint32_t w = x1 - x0 + 1u;
         const uint32_t k = e - (in_lds ? s_off[lo] : goff[lo]);
         const uint32_t ty = y0 + k / w, tx = x0 + k % w;
-        entry_keys[e] = ty * tiles_x + tx;
+        const uint32_t key = ty * tiles_x + tx;
+        entry_keys[e] = key;
         entry_vals[e] = sorted_idx[pos];
+        atomicAdd(&s_hist[(key & (RADIX - 1)) * COPIES + copy], 1u);
+    }
+    if (tile_hist) {  // digit counts of sort tile blockIdx.x for the tile-id sort's first pass ([digit][tile])
+        __syncthreads();
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < COPIES; ++r) c += s_hist[threadIdx.x * COPIES + r];
+        tile_hist[(size_t)threadIdx.x * tile_hist_pitch + blockIdx.x] = c;
     }
 }
 
@@ -250,7 +264,9 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
             s_c[tid] = make_float4(h2f(w3), h2f(w3 >> 16), h2f(w4), 0.0f);
         }
         __syncthreads();
-        for (uint32_t k = 0; k < nb; ++k) {
+        // a wave whose 64 pixels are all saturated has nothing left to add: it only keeps staging
+        const uint32_t nk = (__ballot(!done) == 0ull) ? 0u : nb;
+        for (uint32_t k = 0; k < nk; ++k) {
             const float4 b4 = s_b[k];
             if (!(__float_as_uint(b4.w) & qbit)) continue;  // wave-uniform
             const float4 a4 = s_a[k];
@@ -313,7 +329,7 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     const uint32_t blocks = (b.entry_cap + EMIT_TILE - 1) / EMIT_TILE;
     if (blocks == 0) return WS_OK;
     hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx, b.rects_sorted, b.offsets,
-                       b.emit_start, b.entry_keys, b.entry_vals, b.counters, b.tiles_x);
+                       b.emit_start, b.entry_keys, b.entry_vals, b.counters, b.tiles_x, b.tile_hist, b.tile_hist_pitch);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }

@@ -1,27 +1,26 @@
 // sort.hip -- stable ascending LSD radix sort of (u32 key, u32 value) pairs for gfx950.
 //
 // Replaces GPURSSorter (src/gpu_rs.rs:63-885) and src/shaders/radix_sort.wgsl:48-512 of the reference:
-// same contract (ascending, stable, 8-bit digits, key count read from device memory), new design:
+// same contract (ascending, stable, 8-bit digits, key count read from device memory), new design.
 //
-//   * one-sweep: one histogram pass over the keys for ALL digits, then one pass per digit that reads
-//     and writes every pair exactly once; the cross-tile prefix comes from a decoupled look-back over
-//     epoch-tagged 64-bit {epoch,flag,count} words (lookback.h), one per tile and digit, read and written
-//     with agent-scope atomics, so it is correct for any placement of tiles on the 8 XCDs.
-//   * the look-back is WINDOWED: thread d (digit d) fetches the words of 4 predecessor tiles per round
-//     trip.  With ~1000 co-resident tiles starting together a one-word-per-poll look-back needs ~sqrt(2k)
-//     dependent L2 round trips for tile k; the window divides that chain.
-//   * work tiles are handed out by an atomic ticket, so a tile only ever waits on tiles that have
-//     already started -- no dependence on dispatch order.  Surplus workgroups (the grid is sized for the
-//     host-side bound) leave before touching the ticket.
-//   * ranking inside a wave uses wave64 ballots (8 per key) instead of the reference's O(subgroup)
-//     shared-memory match loop (radix_sort.wgsl:279-302), plus per-wave LDS digit counters.
-//   * keys and values are reordered through LDS so that global writes are contiguous per digit run.
-//   * tile = 256 threads x 16 keys = 4096 pairs (the reference uses 3840, gpu_rs.rs:14-21).
-//   * nothing is zeroed per pass: status words carry the epoch; histograms and tickets live in the
-//     caller's per-frame zero arena.
+// Common to both paths (k_sort_scatter): one workgroup = one tile of 256 x KPT pairs; ranking inside a
+// wave uses wave64 ballots (8 per key) instead of the reference's O(subgroup) shared-memory match loop
+// (radix_sort.wgsl:279-302), with per-wave LDS digit counters updated by one leader lane per digit
+// (deterministic, no LDS atomics); keys and values are reordered through LDS so that global writes are
+// contiguous per digit run; the first pass can synthesise the iota payload.
 //
-// A second, look-back-free path (per-tile histograms -> column scan -> scatter) is kept selectable
-// (algo 0) as an independent cross-check of the one-sweep path.
+// Cross-tile prefix, two selectable paths (measured on MI355X, profiles/):
+//   algo 0  "tile histograms -> column scan -> scatter": per pass a histogram kernel writes the digit counts of
+//           every tile (transposed, [digit][tile]), 256 workgroups scan one digit row each, the scatter kernel
+//           reads its offsets.  No spinning, nothing to order; costs one extra read of the keys per pass.
+//           When the producer of the keys already knows the per-tile digit counts of the first pass (the tile
+//           binning kernel does) that histogram kernel is skipped.
+//   algo 1  one-sweep: one histogram pass for all digits, then per pass a decoupled look-back over epoch-tagged
+//           64-bit {epoch,flag,count} words (lookback.h), windowed (4 predecessor tiles per round trip),
+//           tiles handed out by an atomic ticket.  Fewer launches, every pair read once per pass, but with
+//           ~1000 co-resident tiles starting together the look-back chain (~sqrt(2k) dependent L2 round trips
+//           for tile k, each ~1 us across 8 XCDs) costs more than re-reading the keys: ~2x slower per pass on
+//           6.6 M pairs.  Kept as a cross-check and for callers that prefer fewer launches.
 #include <hip/hip_runtime.h>
 
 #include "lookback.h"
@@ -42,7 +41,7 @@ __device__ __forceinline__ uint32_t device_count(const uint32_t* d_count, uint32
 }
 
 // exclusive scan of one value per thread over a 256-thread block
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_tmp /*[WAVES]*/) {
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_tmp /*[WAVES]*/, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = v;
 #pragma unroll
@@ -52,15 +51,19 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     }
     if (lane == 63) s_tmp[wave] = incl;
     __syncthreads();
-    uint32_t wave_off = 0;
+    uint32_t wave_off = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w)
-        if (w < wave) wave_off += s_tmp[w];
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = s_tmp[w];
+        if (w < wave) wave_off += c;
+        tot += c;
+    }
     __syncthreads();  // s_tmp reusable
+    if (total) *total = tot;
     return wave_off + incl - v;
 }
 
-// ---- histogram of every participating digit in one read of the keys -----------------------------
+// ---- algo 1: histogram of every participating digit in one read of the keys -------------------------
 // LDS bins are replicated HIST_COPIES times (copy = lane & 7): depth keys and tile ids are strongly
 // clustered in their upper digits, and 64 lanes hammering one LDS word serialise.
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys,
@@ -101,57 +104,68 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __re
     }
 }
 
-// ---- per-tile digit histogram (algo 0) ------------------------------------------------------------
+// ---- algo 0: digit counts of every tile, transposed: tile_sums[digit * tiles_cap + tile] ---------------
+template <int KPT>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ d_count, uint32_t n,
-                                                                int shift, uint32_t* __restrict__ tile_sums) {
-    __shared__ uint32_t sh[RADIX];
+                                                                int shift, uint32_t* __restrict__ tile_sums,
+                                                                uint32_t tiles_cap) {
+    constexpr int TILE_N = SORT_THREADS * KPT;
+    __shared__ uint32_t sh[RADIX * HIST_COPIES];
     const uint32_t count = device_count(d_count, n);
     const uint32_t t = blockIdx.x;
-    if ((uint64_t)t * SORT_TILE >= count) return;
-    sh[threadIdx.x] = 0u;
+    if ((uint64_t)t * TILE_N >= count) return;
+    for (int i = threadIdx.x; i < RADIX * HIST_COPIES; i += SORT_THREADS) sh[i] = 0u;
     __syncthreads();
-    const uint32_t base = t * SORT_TILE;
-#pragma unroll 4
-    for (int j = 0; j < SORT_KPT; ++j) {
+    const uint32_t base = t * TILE_N;
+    const uint32_t copy = threadIdx.x & (HIST_COPIES - 1);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
         const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
-        if (pos < count) atomicAdd(&sh[(keys[pos] >> shift) & (RADIX - 1)], 1u);
+        if (pos < count) atomicAdd(&sh[((keys[pos] >> shift) & (RADIX - 1)) * HIST_COPIES + copy], 1u);
     }
     __syncthreads();
-    tile_sums[(size_t)t * RADIX + threadIdx.x] = sh[threadIdx.x];
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < HIST_COPIES; ++r) c += sh[threadIdx.x * HIST_COPIES + r];
+    tile_sums[(size_t)threadIdx.x * tiles_cap + t] = c;
 }
 
-// column scan: tile_sums[t][d] -> global exclusive offset of (tile t, digit d)   (algo 0, one block)
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_scan(const uint32_t* __restrict__ d_count, uint32_t n,
-                                                                uint32_t* __restrict__ tile_sums) {
+// One workgroup per digit: exclusive scan of that digit's row over the tiles (in place), total -> hist[digit].
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* __restrict__ d_count, uint32_t n,
+                                                               uint32_t tile_n, uint32_t* __restrict__ tile_sums,
+                                                               uint32_t tiles_cap, uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_tmp[WAVES];
     const uint32_t count = device_count(d_count, n);
-    const uint32_t ntiles = (count + SORT_TILE - 1) / SORT_TILE;
-    const uint32_t d = threadIdx.x;
-    uint32_t total = 0;
-    for (uint32_t t = 0; t < ntiles; ++t) total += tile_sums[(size_t)t * RADIX + d];
-    uint32_t running = block_exclusive_scan(total, s_tmp);
-    for (uint32_t t = 0; t < ntiles; ++t) {
-        const uint32_t c = tile_sums[(size_t)t * RADIX + d];
-        tile_sums[(size_t)t * RADIX + d] = running;
-        running += c;
+    const uint32_t ntiles = (count + tile_n - 1) / tile_n;
+    uint32_t* row = tile_sums + (size_t)blockIdx.x * tiles_cap;
+    uint32_t running = 0;  // block-uniform
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += SORT_THREADS) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t c = t < ntiles ? row[t] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan(c, s_tmp, &tot);
+        if (t < ntiles) row[t] = running + ex;
+        running += tot;
     }
+    if (threadIdx.x == 0) hist[blockIdx.x] = running;
 }
 
-// ---- one digit pass: rank, look-back (or precomputed offsets), LDS reorder, scatter ----------------
-template <bool LOOKBACK>
+// ---- one digit pass: rank, cross-tile prefix (look-back or precomputed), LDS reorder, scatter ----------
+template <bool LOOKBACK, int KPT>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ d_count, uint32_t n, int shift, int iota,
-    const uint32_t* __restrict__ hist,     // [256] global digit histogram of this pass      (LOOKBACK)
+    const uint32_t* __restrict__ hist,     // [256] global digit histogram of this pass
     uint64_t* __restrict__ status,         // [tiles][256] epoch-tagged look-back words      (LOOKBACK)
     uint32_t* __restrict__ ticket,         // tile dispenser, zero on entry                  (LOOKBACK)
-    const uint32_t* __restrict__ tile_off, // [tiles][256] global exclusive offsets          (!LOOKBACK)
-    uint32_t epoch, uint32_t* __restrict__ error_word) {
+    const uint32_t* __restrict__ tile_off, // [256][tiles_cap] exclusive offsets per digit   (!LOOKBACK)
+    uint32_t tiles_cap, uint32_t epoch, uint32_t* __restrict__ error_word) {
+    constexpr int TILE_N = SORT_THREADS * KPT;
     __shared__ uint32_t s_wave_hist[WAVES][RADIX];
     __shared__ uint32_t s_local_excl[RADIX];
     __shared__ uint32_t s_global_base[RADIX];
-    __shared__ uint32_t s_data[SORT_TILE];
+    __shared__ uint32_t s_data[TILE_N];
     __shared__ uint32_t s_tmp[WAVES];
     __shared__ uint32_t s_tile;
 
@@ -162,26 +176,26 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t count = device_count(d_count, n);
     // The grid is sized for the host-side bound n; only ceil(count / TILE) workgroups have work.  The surplus
     // ones leave BEFORE touching the ticket, so exactly the needed number of tickets 0..ntiles-1 is drawn.
-    if ((uint64_t)blockIdx.x * SORT_TILE >= count) return;  // block-uniform
+    if ((uint64_t)blockIdx.x * TILE_N >= count) return;  // block-uniform
     if (LOOKBACK) {
         if (tid == 0) s_tile = atomicAdd(ticket, 1u);
         __syncthreads();
     }
     const uint32_t t = LOOKBACK ? s_tile : blockIdx.x;
-    const uint32_t tile_base = t * SORT_TILE;
-    const uint32_t valid = (count - tile_base) < (uint32_t)SORT_TILE ? (count - tile_base) : (uint32_t)SORT_TILE;
+    const uint32_t tile_base = t * TILE_N;
+    const uint32_t valid = (count - tile_base) < (uint32_t)TILE_N ? (count - tile_base) : (uint32_t)TILE_N;
 
     // ---- load (wave-striped: consecutive lanes read consecutive keys; order = (wave, j, lane)) ------
-    uint32_t key[SORT_KPT];
-    uint32_t val[SORT_KPT];
-    const uint32_t wave_base = tile_base + wave * (64 * SORT_KPT) + lane;
+    uint32_t key[KPT];
+    uint32_t val[KPT];
+    const uint32_t wave_base = tile_base + wave * (64 * KPT) + lane;
 #pragma unroll
-    for (int j = 0; j < SORT_KPT; ++j) {
+    for (int j = 0; j < KPT; ++j) {
         const uint32_t pos = wave_base + j * 64;
         key[j] = pos < count ? keys_in[pos] : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int j = 0; j < SORT_KPT; ++j) {
+    for (int j = 0; j < KPT; ++j) {
         const uint32_t pos = wave_base + j * 64;
         val[j] = iota ? pos : (pos < count ? vals_in[pos] : 0u);
     }
@@ -190,10 +204,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     __syncthreads();
 
     // ---- rank inside the wave with ballots; per-wave digit counters live in LDS ---------------------
-    uint32_t rank[SORT_KPT];
+    uint32_t rank[KPT];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int j = 0; j < SORT_KPT; ++j) {
+    for (int j = 0; j < KPT; ++j) {
         const uint32_t d = (key[j] >> shift) & (RADIX - 1);
         unsigned long long m = ~0ull;
 #pragma unroll
@@ -223,16 +237,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         s_wave_hist[w][tid] = tile_cnt;
         tile_cnt += c;
     }
-    uint32_t global_base;  // global position of the first key of digit `tid` coming from this tile
     if (LOOKBACK) {
         // publish first, scan afterwards: successors can use the aggregate while this tile is still busy.
         // padding keys (0xFFFFFFFF, digit 255 in every pass) are ranked last and never published
-        const uint32_t pub_cnt = tile_cnt - ((tid == RADIX - 1) ? ((uint32_t)SORT_TILE - valid) : 0u);
+        const uint32_t pub_cnt = tile_cnt - ((tid == RADIX - 1) ? ((uint32_t)TILE_N - valid) : 0u);
         uint64_t* my_status = status + (size_t)t * RADIX + tid;
         lb::st(my_status, lb::pack(epoch, t == 0 ? lb::FLAG_INCL : lb::FLAG_AGG, pub_cnt));
-        const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp);
+        const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp, nullptr);
         s_local_excl[tid] = local_excl;
-        const uint32_t digit_base = block_exclusive_scan(hist[tid], s_tmp);
+        const uint32_t digit_base = block_exclusive_scan(hist[tid], s_tmp, nullptr);
         uint32_t prev_sum = 0;
         if (t > 0) {
             int64_t i = (int64_t)t - 1;  // next predecessor to consume
@@ -266,28 +279,27 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             }
             lb::st(my_status, lb::pack(epoch, lb::FLAG_INCL, prev_sum + pub_cnt));
         }
-        global_base = digit_base + prev_sum;
-        s_global_base[tid] = global_base - local_excl;  // add the tile-local position to get the address
+        s_global_base[tid] = digit_base + prev_sum - local_excl;  // + tile-local position = global address
     } else {
-        const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp);
+        const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp, nullptr);
         s_local_excl[tid] = local_excl;
-        global_base = tile_off[(size_t)t * RADIX + tid];
-        s_global_base[tid] = global_base - local_excl;
+        const uint32_t digit_base = block_exclusive_scan(hist[tid], s_tmp, nullptr);
+        s_global_base[tid] = digit_base + tile_off[(size_t)tid * tiles_cap + t] - local_excl;
     }
     __syncthreads();
 
     // ---- reorder keys through LDS, write contiguous digit runs ----------------------------------------
-    uint32_t lpos[SORT_KPT];
+    uint32_t lpos[KPT];
 #pragma unroll
-    for (int j = 0; j < SORT_KPT; ++j) {
+    for (int j = 0; j < KPT; ++j) {
         const uint32_t d = (key[j] >> shift) & (RADIX - 1);
         lpos[j] = s_local_excl[d] + s_wave_hist[wave][d] + rank[j];
         s_data[lpos[j]] = key[j];
     }
     __syncthreads();
-    uint32_t gpos[SORT_KPT];
+    uint32_t gpos[KPT];
 #pragma unroll
-    for (int k = 0; k < SORT_KPT; ++k) {
+    for (int k = 0; k < KPT; ++k) {
         const uint32_t lp = k * SORT_THREADS + tid;
         const uint32_t kk = s_data[lp];
         const uint32_t d = (kk >> shift) & (RADIX - 1);
@@ -296,20 +308,52 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < SORT_KPT; ++j) s_data[lpos[j]] = val[j];
+    for (int j = 0; j < KPT; ++j) s_data[lpos[j]] = val[j];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < SORT_KPT; ++k) {
+    for (int k = 0; k < KPT; ++k) {
         const uint32_t lp = k * SORT_THREADS + tid;
         if (lp < valid) vals_out[gpos[k]] = s_data[lp];
     }
 }
 
+template <int KPT>
+int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout,
+                    const uint32_t* d_count, uint32_t n, int begin_bit, int npass, bool implicit_iota,
+                    bool first_tile_hist_ready, uint32_t epoch, hipStream_t stream, uint32_t** fk, uint32_t** fv) {
+    constexpr uint32_t TILE_N = SORT_THREADS * KPT;
+    const uint32_t tiles = (n + TILE_N - 1) / TILE_N;
+    for (int p = 0; p < npass; ++p) {
+        const int shift = begin_bit + p * RADIX_BITS;
+        const int iota = (implicit_iota && p == 0) ? 1 : 0;
+        if (!(p == 0 && first_tile_hist_ready))
+            hipLaunchKernelGGL(k_sort_tile_hist<KPT>, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift,
+                               sc.tile_sums, sc.tiles_cap);
+        hipLaunchKernelGGL(k_sort_col_scan, dim3(RADIX), dim3(SORT_THREADS), 0, stream, d_count, n, TILE_N, sc.tile_sums,
+                           sc.tiles_cap, sc.hist + p * RADIX);
+        hipLaunchKernelGGL((k_sort_scatter<false, KPT>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout,
+                           d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                           sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr);
+        WS_HIP(hipGetLastError());
+        uint32_t* tk = kin;
+        kin = kout;
+        kout = tk;
+        uint32_t* tv = vin;
+        vin = vout;
+        vout = tv;
+    }
+    *fk = kin;
+    *fv = vin;
+    return WS_OK;
+}
+
 }  // namespace
 
+uint32_t sort_tile_size(uint32_t n) { return n <= SORT_SMALL_MAX ? SORT_THREADS * SORT_KPT_SMALL : SORT_TILE; }
+
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
-                      int begin_bit, int end_bit, bool implicit_iota, bool hist_ready, int algo, uint32_t epoch,
-                      hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals) {
+                      int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
+                      uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals) {
     if (out_keys) *out_keys = keys;
     if (out_vals) *out_vals = vals;
     if (n == 0) return WS_OK;
@@ -318,43 +362,44 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
         return fail(WS_ERR_INVALID, "sort: bit range must be non-empty multiples of 8 within [0,32]");
     if ((reinterpret_cast<uintptr_t>(keys) & 15u) != 0) return fail(WS_ERR_INVALID, "sort: keys must be 16-byte aligned");
     const int npass = (end_bit - begin_bit) / RADIX_BITS;
-    const uint32_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
 
     uint32_t* kin = keys;
     uint32_t* vin = vals;
     uint32_t* kout = sc.keys_alt;
     uint32_t* vout = sc.vals_alt;
 
-    if (algo == 1 && !hist_ready) {
+    if (algo != 1) {
+        int rc;
+        if (sort_tile_size(n) == SORT_TILE)
+            rc = run_passes_scan<SORT_KPT>(sc, kin, vin, kout, vout, d_count, n, begin_bit, npass, implicit_iota,
+                                           first_tile_hist_ready, epoch, stream, &kin, &vin);
+        else
+            rc = run_passes_scan<SORT_KPT_SMALL>(sc, kin, vin, kout, vout, d_count, n, begin_bit, npass, implicit_iota,
+                                                 first_tile_hist_ready, epoch, stream, &kin, &vin);
+        if (rc) return rc;
+    } else {
+        const uint32_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
         uint32_t hist_blocks = (n / 4 + SORT_THREADS * 8 - 1) / (SORT_THREADS * 8);
         if (hist_blocks < 1) hist_blocks = 1;
         if (hist_blocks > 1024) hist_blocks = 1024;
         hipLaunchKernelGGL(k_sort_hist, dim3(hist_blocks), dim3(SORT_THREADS), 0, stream, kin, d_count, n, begin_bit,
                            npass, sc.hist);
         WS_HIP(hipGetLastError());
-    }
-    for (int p = 0; p < npass; ++p) {
-        const int shift = begin_bit + p * RADIX_BITS;
-        const int iota = (implicit_iota && p == 0) ? 1 : 0;
-        if (algo == 1) {
-            hipLaunchKernelGGL(k_sort_scatter<true>, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout,
-                               d_count, n, shift, iota, sc.hist + p * RADIX, sc.status + (size_t)p * sc.tiles * RADIX,
-                               sc.tickets + p, (const uint32_t*)nullptr, epoch, sc.error);
-        } else {
-            hipLaunchKernelGGL(k_sort_tile_hist, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift,
-                               sc.tile_sums);
-            hipLaunchKernelGGL(k_sort_tile_scan, dim3(1), dim3(SORT_THREADS), 0, stream, d_count, n, sc.tile_sums);
-            hipLaunchKernelGGL(k_sort_scatter<false>, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout,
-                               d_count, n, shift, iota, (const uint32_t*)nullptr, (uint64_t*)nullptr,
-                               (uint32_t*)nullptr, sc.tile_sums, epoch, (uint32_t*)nullptr);
+        for (int p = 0; p < npass; ++p) {
+            const int shift = begin_bit + p * RADIX_BITS;
+            const int iota = (implicit_iota && p == 0) ? 1 : 0;
+            hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
+                               kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX,
+                               sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr, 0u,
+                               epoch, sc.error);
+            WS_HIP(hipGetLastError());
+            uint32_t* tk = kin;
+            kin = kout;
+            kout = tk;
+            uint32_t* tv = vin;
+            vin = vout;
+            vout = tv;
         }
-        WS_HIP(hipGetLastError());
-        uint32_t* tk = kin;
-        kin = kout;
-        kout = tk;
-        uint32_t* tv = vin;
-        vin = vout;
-        vout = tv;
     }
     if (out_keys) *out_keys = kin;
     if (out_vals) *out_vals = vin;

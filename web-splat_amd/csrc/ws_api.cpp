@@ -128,7 +128,10 @@ static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt) {
     const size_t status_words = 4 * (size_t)sc.tiles * RADIX;
     if ((rc = dmalloc(&sc.status, status_words))) return rc;
     WS_HIP(hipMemset(sc.status, 0, status_words * sizeof(uint64_t)));
-    if ((rc = dmalloc(&sc.tile_sums, (size_t)sc.tiles * RADIX))) return rc;
+    const uint32_t small_n = std::min<uint32_t>(cap, SORT_SMALL_MAX);
+    const uint32_t small_tiles = (small_n + SORT_THREADS * SORT_KPT_SMALL - 1) / (SORT_THREADS * SORT_KPT_SMALL);
+    sc.tiles_cap = std::max<uint32_t>(std::max<uint32_t>(small_tiles, sc.tiles), 1u);
+    if ((rc = dmalloc(&sc.tile_sums, (size_t)sc.tiles_cap * RADIX))) return rc;
     return WS_OK;
 }
 
@@ -243,7 +246,7 @@ int ws_context_create(int hip_device, ws_context** out) {
     if (!ctx) return fail(WS_ERR_OOM, "ws_context_create: host allocation failed");
     ctx->device = hip_device;
     WS_HIP(hipGetDeviceProperties(&ctx->props, hip_device));
-    ctx->sort_algo = env_int("WS_SORT_ALGO", 1);
+    ctx->sort_algo = env_int("WS_SORT_ALGO", 0);
     ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
     *out = ctx;
     return WS_OK;
@@ -565,6 +568,11 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     bb.tiles_x = r->tiles_x;
     bb.tiles_y = r->tiles_y;
     bb.epoch = r->epoch;
+    // the emit kernel cuts the entry list into the same 4096-entry tiles the radix sort uses, so it can hand
+    // the sort the digit counts of its first pass for free
+    const bool fused_hist = r->ctx->sort_algo != 1 && sort_tile_size(r->entry_cap) == (uint32_t)EMIT_TILE;
+    bb.tile_hist = fused_hist ? r->sort_tiles.tile_sums : nullptr;
+    bb.tile_hist_pitch = r->sort_tiles.tiles_cap;
     if ((rc = launch_bin_prefix(bb, stream))) return rc;
     if ((rc = launch_bin_emit(bb, stream))) return rc;
     const uint32_t ntiles = r->tiles_x * r->tiles_y;
@@ -572,7 +580,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     while ((1ull << tile_bits) < ntiles) tile_bits += 8;
     uint32_t *ek = nullptr, *evv = nullptr;
     if ((rc = launch_sort_pairs(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap, 0,
-                                tile_bits, false, false, r->ctx->sort_algo, r->epoch, stream, &ek, &evv)))
+                                tile_bits, false, fused_hist, r->ctx->sort_algo, r->epoch, stream, &ek, &evv)))
         return rc;
     r->entries_sorted = evv;
     if ((rc = launch_tile_ranges(ek, bb, stream))) return rc;

@@ -71,6 +71,9 @@ constexpr int PC_PLANES = 8;
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_KPT = 16;                          // keys per thread
 constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;    // 4096 keys per work tile
+constexpr int SORT_KPT_SMALL = 4;                     // small inputs: 1024-key tiles -> 4x the workgroups
+constexpr uint32_t SORT_SMALL_MAX = 2u << 20;         // host-side bound n up to which the small tile is used
+uint32_t sort_tile_size(uint32_t n);                  // tile size the scan path (algo 0) uses for bound n
 
 struct SortScratch {
     uint32_t* keys_alt = nullptr;     // ping-pong partner of the caller's key buffer   [cap]
@@ -78,23 +81,25 @@ struct SortScratch {
     uint32_t* hist = nullptr;         // [4][256] digit histograms, zero on entry
     uint64_t* status = nullptr;       // [4][tiles][256] epoch-tagged look-back words (never re-zeroed)
     uint32_t* tickets = nullptr;      // [4] tile dispensers, zero on entry
-    uint32_t* tile_sums = nullptr;    // [tiles][256] reduce-then-scan path (WS_SORT_ALGO=0)
+    uint32_t* tile_sums = nullptr;    // [256][tiles_cap] per-tile digit counts / offsets of the scan path (algo 0)
     uint32_t* error = nullptr;        // device word OR-ed with 8 if a look-back spin ever times out
     uint32_t cap = 0;
-    uint32_t tiles = 0;
+    uint32_t tiles = 0;               // ceil(cap / SORT_TILE): one-sweep status rows per pass
+    uint32_t tiles_cap = 0;           // row pitch of tile_sums: the largest tile count any n <= cap can need
 };
 
 // Launch an ascending stable LSD radix sort of (key, value) pairs on `stream`.
 //   d_count == nullptr -> sort n pairs; else the count is read on the device (clamped to n).
 //   begin_bit/end_bit: key bits that participate (multiples of 8).
 //   implicit_iota: values of the first pass are the element positions (vals in is not read).
-//   hist_ready: the digit histograms in sc.hist were already accumulated by the producer of the keys.
-//   sc.hist and sc.tickets must be zero on entry (the renderer zeroes them with the frame arena).
+//   first_tile_hist_ready (algo 0): the producer of the keys already wrote the first pass's per-tile digit
+//     counts into sc.tile_sums (layout [digit][tiles_cap], tile = sort_tile_size(n) consecutive keys).
+//   algo 1 needs sc.hist and sc.tickets zero on entry (the renderer zeroes them with the frame arena).
 // The result lands in (keys, vals) if the pass count is even, else in (scratch.keys_alt, vals_alt);
 // *out_keys / *out_vals receive the final pointers.
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
-                      int begin_bit, int end_bit, bool implicit_iota, bool hist_ready, int algo, uint32_t epoch,
-                      hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals);
+                      int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
+                      uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals);
 
 // ---- preprocess ---------------------------------------------------------------------------------
 struct K1Buffers {
@@ -124,6 +129,8 @@ struct BinBuffers {
     uint64_t* block_status;      // look-back words of the prefix kernel
     uint32_t* entry_keys;        // [cap] tile ids
     uint32_t* entry_vals;        // [cap] store indices
+    uint32_t* tile_hist;         // nullptr, or the tile sort's tile_sums: emit workgroup m also writes the digit
+    uint32_t tile_hist_pitch;    //   counts (low 8 bits of the tile id) of sort tile m -> no histogram pass 0
     uint32_t entry_cap;
     uint2* tile_ranges;          // [tiles] (begin, end) into the sorted entry list
     FrameCounters* counters;
@@ -161,7 +168,7 @@ float host_f16_to_f32(uint16_t h);
 struct ws_context {
     int device = 0;
     hipDeviceProp_t props;
-    int sort_algo = 1;    // 1 = one-sweep (decoupled look-back), 0 = reduce-then-scan
+    int sort_algo = 0;    // 0 = tile histograms -> column scan -> scatter (default), 1 = one-sweep (look-back)
     int blend_variant = 0;
 };
 
