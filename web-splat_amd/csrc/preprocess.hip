@@ -33,6 +33,31 @@ constexpr int K1_ITEMS = 4;  // Gaussians per thread
 __device__ __forceinline__ float h2f(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)(h & 0xFFFFu))); }
 __device__ __forceinline__ uint32_t f2h(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
 
+// Arithmetic policy.  Default (WS_K1_STRICT=1): correctly rounded f32 division / sqrt and source-order
+// arithmetic everywhere, so that the visible set, the store order, the depth keys AND every f16 Splat field agree
+// with the CPU restatement of preprocess.wgsl at the 1-ulp level.  -DWS_K1_STRICT=0 switches the BACK end
+// (covariance, eigen-decomposition, SH -- everything that is rounded to f16 anyway) to the hardware's 1-ulp
+// rcp / sqrt / rsq plus FMA contraction: measured 54 -> 48 us on 1.2 M Gaussians (the kernel is VALU-issue
+// bound, profiles/r01), but the eigenvector of nearly isotropic splats is ill-conditioned and moves by many f16
+// ulps, and a few image pixels leave the 2e-3 tolerance -- not worth 6 us, so it is off by default.
+#ifndef WS_K1_STRICT
+#define WS_K1_STRICT 1
+#endif
+__device__ __forceinline__ float qdiv(float a, float b) {
+#if WS_K1_STRICT
+    return a / b;
+#else
+    return a * __builtin_amdgcn_rcpf(b);
+#endif
+}
+__device__ __forceinline__ float qsqrt(float a) {
+#if WS_K1_STRICT
+    return sqrtf(a);
+#else
+    return __builtin_amdgcn_sqrtf(a);
+#endif
+}
+
 // SH basis constants: preprocess.wgsl:4-23
 __device__ constexpr float SH_C0 = 0.28209479177387814f;
 __device__ constexpr float SH_C1 = 0.4886025119029199f;
@@ -81,20 +106,38 @@ struct SplatOut {
 #define VM(c, r) (p.cam.view[(c)*4 + (r)])
 #define PM(c, r) (p.cam.proj[(c)*4 + (r)])
 
+// depth key: preprocess.wgsl:270-273 / preprocess_compressed.wgsl:322-325.  Always strict; znear / zfar are
+// recovered from the projection matrix on the host with the same two f32 divisions the shader does.
+template <bool COMPRESSED>
+__device__ __forceinline__ uint32_t k1_depth_key(const K1Params& p, float clip_z) {
+    if (!COMPRESSED) return __float_as_uint(p.zfar - clip_z);
+    const float kf = 16777215.0f - (clip_z - p.znear) / (p.zfar - p.znear) * 16777215.0f;
+    uint32_t k = 0u;  // WGSL u32(f32) saturates
+    if (kf > 0.0f) k = (kf >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t)kf;
+    return k;
+}
+
 // From the frustum test onward: preprocess.wgsl:194-273 / preprocess_compressed.wgsl:234-325.
 template <bool COMPRESSED>
 __device__ void k1_math(const K1Params& p, const float xyz[3], const float camspace[4], const float pos2d[4],
                         float opacity, const float cov6[6], const Sh16& sh, SplatOut* out) {
-    // fade-in (preprocess.wgsl:196-203)
-    const float walltime = p.rs.walltime;
-    float scale_mod = 0.0f;
-    const float ddx = p.rs.scene_center[0] - xyz[0], ddy = p.rs.scene_center[1] - xyz[1],
-                ddz = p.rs.scene_center[2] - xyz[2];
-    const float dd = 5.0f * sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) / p.rs.scene_extend;
-    if (walltime > dd) {
-        float t = (walltime - dd - 0.0f) / (1.0f - 0.0f);
-        t = fminf(fmaxf(t, 0.0f), 1.0f);
-        scale_mod = t * t * (3.0f - 2.0f * t);
+#if !WS_K1_STRICT
+#pragma clang fp contract(fast)
+#endif
+    // fade-in (preprocess.wgsl:196-203).  p.fade_done (host, uniform): walltime is so far past the largest
+    // possible dd = 5 * |centre - xyz| / scene_extend that smoothstep() is exactly 1 for every Gaussian.
+    float scale_mod = 1.0f;
+    if (!p.fade_done) {
+        const float walltime = p.rs.walltime;
+        scale_mod = 0.0f;
+        const float ddx = p.rs.scene_center[0] - xyz[0], ddy = p.rs.scene_center[1] - xyz[1],
+                    ddz = p.rs.scene_center[2] - xyz[2];
+        const float dd = 5.0f * sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) / p.rs.scene_extend;
+        if (walltime > dd) {
+            float t = (walltime - dd - 0.0f) / (1.0f - 0.0f);
+            t = fminf(fmaxf(t, 0.0f), 1.0f);
+            scale_mod = t * t * (3.0f - 2.0f * t);
+        }
     }
     const float scaling = p.rs.gaussian_scaling * scale_mod;
 
@@ -106,10 +149,18 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
 
     const float fx = p.cam.focal[0], fy = p.cam.focal[1];
     const float cz = camspace[2];
+#if WS_K1_STRICT
     const float j00 = fx / cz;
     const float j02 = -(fx * camspace[0]) / (cz * cz);
     const float j11 = -fy / cz;
     const float j12 = (fy * camspace[1]) / (cz * cz);
+#else
+    const float rz = __builtin_amdgcn_rcpf(cz);
+    const float j00 = fx * rz;
+    const float j02 = -(fx * camspace[0]) * rz * rz;
+    const float j11 = -fy * rz;
+    const float j12 = (fy * camspace[1]) * rz * rz;
+#endif
     // W = transpose(mat3(view)) -> column k of W is row k of the view rotation;
     // T = W * J: T[0] = W[0]*j00 + W[1]*0 + W[2]*j02 ; T[1] = W[0]*0 + W[1]*j11 + W[2]*j12 ; T[2] = 0.
     float t0[3], t1[3];
@@ -158,7 +209,7 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
     if (p.rs.mip_splatting != 0u) {  // preprocess.wgsl:225-236
         const float det_0 = fmaxf(1e-6f, cov00 * cov11 - cov01 * cov01);
         const float det_1 = fmaxf(1e-6f, (cov00 + kernel_size) * (cov11 + kernel_size) - cov01 * cov01);
-        float coef = sqrtf(det_0 / (det_1 + 1e-6f) + 1e-6f);
+        float coef = qsqrt(qdiv(det_0, det_1 + 1e-6f) + 1e-6f);
         if (det_0 <= 1e-6f || det_1 <= 1e-6f) coef = 0.0f;
         opacity *= coef;
     }
@@ -167,7 +218,7 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
     const float diagonal2 = cov11 + kernel_size;
     const float mid = 0.5f * (diagonal1 + diagonal2);
     const float hx = (diagonal1 - diagonal2) / 2.0f;
-    const float radius = sqrtf(hx * hx + offDiagonal * offDiagonal);
+    const float radius = qsqrt(hx * hx + offDiagonal * offDiagonal);
     float lambda1, lambda2;
     if (!COMPRESSED) {
         lambda1 = mid + radius;
@@ -177,27 +228,41 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
         lambda2 = mid - fmaxf(radius, 0.1f);
     }
     const float dvx = offDiagonal, dvy = lambda1 - diagonal1;
-    const float dlen = sqrtf(dvx * dvx + dvy * dvy);
     float ex = 1.0f, ey = 0.0f;  // normalize((0,0)) is undefined in WGSL; defined as (1,0) here
+#if WS_K1_STRICT
+    const float dlen = sqrtf(dvx * dvx + dvy * dvy);
     if (dlen > 0.0f) {
         ex = dvx / dlen;
         ey = dvy / dlen;
     }
-    const float s1 = sqrtf(2.0f * lambda1), s2 = sqrtf(2.0f * lambda2);
+#else
+    const float dlen2 = dvx * dvx + dvy * dvy;
+    if (dlen2 > 0.0f) {
+        const float inv_len = __builtin_amdgcn_rsqf(dlen2);
+        ex = dvx * inv_len;
+        ey = dvy * inv_len;
+    }
+#endif
+    const float s1 = qsqrt(2.0f * lambda1), s2 = qsqrt(2.0f * lambda2);
     const float v1x = s1 * ex, v1y = s1 * ey;
     const float v2x = s2 * ey, v2y = s2 * (-ex);
-    const float vcx = pos2d[0] / pos2d[3], vcy = pos2d[1] / pos2d[3];
+    const float vcx = qdiv(pos2d[0], pos2d[3]), vcy = qdiv(pos2d[1], pos2d[3]);
 
     // colour: preprocess.wgsl:255-260
     const float dx = xyz[0] - p.cam.view_inv[12], dy = xyz[1] - p.cam.view_inv[13], dz = xyz[2] - p.cam.view_inv[14];
+#if WS_K1_STRICT
     const float dl = sqrtf(dx * dx + dy * dy + dz * dz);
     const float dirx = dx / dl, diry = dy / dl, dirz = dz / dl;
+#else
+    const float inv_dl = __builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz);
+    const float dirx = dx * inv_dl, diry = dy * inv_dl, dirz = dz * inv_dl;
+#endif
     const float cr = fmaxf(0.0f, eval_sh_channel(sh, 0, dirx, diry, dirz, p.rs.max_sh_deg));
     const float cg = fmaxf(0.0f, eval_sh_channel(sh, 1, dirx, diry, dirz, p.rs.max_sh_deg));
     const float cb = fmaxf(0.0f, eval_sh_channel(sh, 2, dirx, diry, dirz, p.rs.max_sh_deg));
 
     const float vw = p.cam.viewport[0], vh = p.cam.viewport[1];
-    const uint32_t h0 = f2h(v1x / vw), h1 = f2h(v1y / vh), h2 = f2h(v2x / vw), h3 = f2h(v2y / vh);
+    const uint32_t h0 = f2h(qdiv(v1x, vw)), h1 = f2h(qdiv(v1y, vh)), h2 = f2h(qdiv(v2x, vw)), h3 = f2h(qdiv(v2y, vh));
     const uint32_t h4 = f2h(vcx), h5 = f2h(vcy);
     out->w[0] = h0 | (h1 << 16);
     out->w[1] = h2 | (h3 << 16);
@@ -205,17 +270,7 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
     out->w[3] = f2h(cr) | (f2h(cg) << 16);
     out->w[4] = f2h(cb) | (f2h(opacity) << 16);
 
-    // depth key: preprocess.wgsl:270-273 / preprocess_compressed.wgsl:322-325
-    const float znear = -PM(3, 2) / PM(2, 2);
-    const float zfar = -PM(3, 2) / (PM(2, 2) - 1.0f);
-    if (!COMPRESSED) {
-        out->key = __float_as_uint(zfar - pos2d[2]);
-    } else {
-        const float kf = 16777215.0f - (pos2d[2] - znear) / (zfar - znear) * 16777215.0f;
-        uint32_t k = 0u;
-        if (kf > 0.0f) k = (kf >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t)kf;
-        out->key = k;
-    }
+    out->key = k1_depth_key<COMPRESSED>(p, pos2d[2]);
 
     // 16x16-tile rectangle of the kept ellipse a <= 2*CUTOFF (gaussian.wgsl:40-64), derived from the
     // f16-ROUNDED splat so that binning and blending agree on coverage.
@@ -227,8 +282,8 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
         const float cx = (h2f(h4) * 0.5f + 0.5f) * vw;
         const float cy = (0.5f - h2f(h5) * 0.5f) * vh;
         const float rad = 2.1697873f * 1.00001f;  // sqrt(2*CUTOFF), padded
-        const float exx = rad * sqrtf(m00 * m00 + m01 * m01) + 1e-3f;
-        const float eyy = rad * sqrtf(m10 * m10 + m11 * m11) + 1e-3f;
+        const float exx = rad * qsqrt(m00 * m00 + m01 * m01) + 1e-3f;
+        const float eyy = rad * qsqrt(m10 * m10 + m11 * m11) + 1e-3f;
         uint2 rect = make_uint2(1u, 0u);  // empty
         const bool ok = (fabsf(det) > 0.0f) && (fabsf(det) < 3.0e38f) && (fabsf(cx) < 1.0e9f) && (fabsf(cy) < 1.0e9f) &&
                         (exx < 1.0e9f) && (eyy < 1.0e9f);
@@ -315,79 +370,95 @@ __device__ __forceinline__ bool k1_project(const K1Params& p, const float xyz[3]
     return !culled;
 }
 
-// Back end for one survivor: fetch covariance + SH, run the maths, produce the Splat / key / rect.
-template <bool COMPRESSED>
-__device__ __forceinline__ void k1_back(const K1Params& p, const K1Buffers& b, uint32_t idx, const Front& f,
-                                        SplatOut* so) {
-    float camspace[4], pos2d[4];
-    (void)k1_project<COMPRESSED>(p, f.xyz, camspace, pos2d);  // same instruction sequence as the front end
+// Raw back-end words of one uncompressed Gaussian: covariance plane + up to six SH planes.
+struct RawBack {
+    uint4 c1;
+    uint4 sh[6];
+};
+
+// Issue the back-end loads of one Gaussian.  UNCONDITIONAL on purpose: a load inside a divergent branch makes
+// the compiler drain vmcnt at the join, which serialises the items of a thread on HBM latency.  Lanes that were
+// culled read the record of `safe_idx` (a line the wave has already touched) and ignore the result.
+__device__ __forceinline__ void k1_back_load(const K1Params& p, const K1Buffers& b, uint32_t idx, RawBack* rb) {
     const uint32_t n = p.num_points;
+    rb->c1 = b.planes[(size_t)1 * n + idx];
+    // SH planes 2..7: 48 halves, element e = 3*coef + channel.  Only the planes the active degree needs are
+    // fetched: deg0 -> 1 plane, deg1 -> 2, deg2 -> 4, deg3 -> 6 (uniform branch).
+    const uint32_t deg = p.rs.max_sh_deg;
+    const int nplanes = deg == 0u ? 1 : (deg == 1u ? 2 : (deg == 2u ? 4 : 6));
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        rb->sh[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (q < nplanes) rb->sh[q] = b.planes[(size_t)(2 + q) * n + idx];
+    }
+}
+
+__device__ __forceinline__ void k1_back_math(const K1Params& p, const Front& f, const RawBack& rb, SplatOut* so) {
+    float camspace[4], pos2d[4];
+    (void)k1_project<false>(p, f.xyz, camspace, pos2d);  // same instruction sequence as the front end
     float cov6[6];
-    float opacity;
+    cov6[0] = h2f(rb.c1.x);
+    cov6[1] = h2f(rb.c1.x >> 16);
+    cov6[2] = h2f(rb.c1.y);
+    cov6[3] = h2f(rb.c1.y >> 16);
+    cov6[4] = h2f(rb.c1.z);
+    cov6[5] = h2f(rb.c1.z >> 16);
+    uint32_t hw[24];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        hw[q * 4 + 0] = rb.sh[q].x;
+        hw[q * 4 + 1] = rb.sh[q].y;
+        hw[q * 4 + 2] = rb.sh[q].z;
+        hw[q * 4 + 3] = rb.sh[q].w;
+    }
+    Sh16 sh;
+#pragma unroll
+    for (int e = 0; e < 48; ++e) sh.c[e / 3][e % 3] = h2f(hw[e / 2] >> ((e & 1) * 16));
+    k1_math<false>(p, f.xyz, camspace, pos2d, h2f(f.w3), cov6, sh, so);
+}
+
+// Back end for one survivor of the COMPRESSED layout: de-quantise, gather the codebooks, run the maths.
+__device__ __forceinline__ void k1_back_compressed(const K1Params& p, const K1Buffers& b, const Front& f, SplatOut* so) {
+    float camspace[4], pos2d[4];
+    (void)k1_project<true>(p, f.xyz, camspace, pos2d);
+    float cov6[6];
     Sh16 sh;
 #pragma unroll
     for (int c = 0; c < 16; ++c) sh.c[c][0] = sh.c[c][1] = sh.c[c][2] = 0.0f;
-    if (!COMPRESSED) {
-        opacity = h2f(f.w3);
-        const uint4 c1 = b.planes[(size_t)1 * n + idx];
-        cov6[0] = h2f(c1.x);
-        cov6[1] = h2f(c1.x >> 16);
-        cov6[2] = h2f(c1.y);
-        cov6[3] = h2f(c1.y >> 16);
-        cov6[4] = h2f(c1.z);
-        cov6[5] = h2f(c1.z >> 16);
-        // SH planes 2..7: 48 halves, element e = 3*coef + channel.  Only the planes the active degree
-        // needs are fetched: deg0 -> 1 plane, deg1 -> 2, deg2 -> 4, deg3 -> 6.
-        const uint32_t deg = p.rs.max_sh_deg;
-        const int nplanes = deg == 0u ? 1 : (deg == 1u ? 2 : (deg == 2u ? 4 : 6));
-        uint32_t hw[24];
+    // preprocess_compressed.wgsl:236-242
+    const int op_i8 = (int)(signed char)(f.w3 & 0xFFu);
+    const int sc_i8 = (int)(signed char)((f.w3 >> 8) & 0xFFu);
+    const float opacity = ((float)op_i8 - (float)p.quant.opacity.zero_point) * p.quant.opacity.scale;
+    const float scaling_factor =
+        expf(((float)sc_i8 - (float)p.quant.scaling_factor.zero_point) * p.quant.scaling_factor.scale);
+    const float s2 = scaling_factor * scaling_factor;
+    const uint32_t* cv = reinterpret_cast<const uint32_t*>(b.covars + (size_t)f.geometry_idx * 12);
+    const uint32_t c0 = cv[0], c1 = cv[1], c2 = cv[2];
+    cov6[0] = h2f(c0) * s2;
+    cov6[1] = h2f(c0 >> 16) * s2;
+    cov6[2] = h2f(c1) * s2;
+    cov6[3] = h2f(c1 >> 16) * s2;
+    cov6[4] = h2f(c2) * s2;
+    cov6[5] = h2f(c2 >> 16) * s2;
+    // int8 SH record: 3*ncoef bytes, packed back to back, NOT 4-aligned
+    // (preprocess_compressed.wgsl:147-171).  unpack4x8snorm(x)*127 maps -128 to -127.
+    const uint32_t ncoef = p.sh_deg_layout;
+    uint32_t use = (p.rs.max_sh_deg + 1u) * (p.rs.max_sh_deg + 1u);
+    if (use > ncoef) use = ncoef;
+    const signed char* rec = reinterpret_cast<const signed char*>(b.sh_bytes) + (size_t)3 * ((size_t)f.sh_idx * ncoef);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (q < nplanes) v = b.planes[(size_t)(2 + q) * n + idx];
-            hw[q * 4 + 0] = v.x;
-            hw[q * 4 + 1] = v.y;
-            hw[q * 4 + 2] = v.z;
-            hw[q * 4 + 3] = v.w;
-        }
+    for (int c = 0; c < 16; ++c) {
+        if ((uint32_t)c < use) {
+            const float zp = (float)(c == 0 ? p.quant.color_dc.zero_point : p.quant.color_rest.zero_point);
+            const float sc = (c == 0 ? p.quant.color_dc.scale : p.quant.color_rest.scale);
 #pragma unroll
-        for (int e = 0; e < 48; ++e) sh.c[e / 3][e % 3] = h2f(hw[e / 2] >> ((e & 1) * 16));
-    } else {
-        // preprocess_compressed.wgsl:236-242
-        const int op_i8 = (int)(signed char)(f.w3 & 0xFFu);
-        const int sc_i8 = (int)(signed char)((f.w3 >> 8) & 0xFFu);
-        opacity = ((float)op_i8 - (float)p.quant.opacity.zero_point) * p.quant.opacity.scale;
-        const float scaling_factor =
-            expf(((float)sc_i8 - (float)p.quant.scaling_factor.zero_point) * p.quant.scaling_factor.scale);
-        const float s2 = scaling_factor * scaling_factor;
-        const uint32_t* cv = reinterpret_cast<const uint32_t*>(b.covars + (size_t)f.geometry_idx * 12);
-        const uint32_t c0 = cv[0], c1 = cv[1], c2 = cv[2];
-        cov6[0] = h2f(c0) * s2;
-        cov6[1] = h2f(c0 >> 16) * s2;
-        cov6[2] = h2f(c1) * s2;
-        cov6[3] = h2f(c1 >> 16) * s2;
-        cov6[4] = h2f(c2) * s2;
-        cov6[5] = h2f(c2 >> 16) * s2;
-        // int8 SH record: 3*ncoef bytes, packed back to back, NOT 4-aligned
-        // (preprocess_compressed.wgsl:147-171).  unpack4x8snorm(x)*127 maps -128 to -127.
-        const uint32_t ncoef = p.sh_deg_layout;
-        uint32_t use = (p.rs.max_sh_deg + 1u) * (p.rs.max_sh_deg + 1u);
-        if (use > ncoef) use = ncoef;
-        const signed char* rec = reinterpret_cast<const signed char*>(b.sh_bytes) + (size_t)3 * ((size_t)f.sh_idx * ncoef);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            if ((uint32_t)c < use) {
-                const float zp = (float)(c == 0 ? p.quant.color_dc.zero_point : p.quant.color_rest.zero_point);
-                const float sc = (c == 0 ? p.quant.color_dc.scale : p.quant.color_rest.scale);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float raw = fmaxf((float)rec[c * 3 + j] / 127.0f, -1.0f) * 127.0f;
-                    sh.c[c][j] = (raw - zp) * sc;
-                }
+            for (int j = 0; j < 3; ++j) {
+                const float raw = fmaxf((float)rec[c * 3 + j] / 127.0f, -1.0f) * 127.0f;
+                sh.c[c][j] = (raw - zp) * sc;
             }
         }
     }
-    k1_math<COMPRESSED>(p, f.xyz, camspace, pos2d, opacity, cov6, sh, so);
+    k1_math<true>(p, f.xyz, camspace, pos2d, opacity, cov6, sh, so);
 }
 
 // One workgroup = one ticket = K1_ITEMS x 256 consecutive Gaussians (1024): a single device-wide atomic per
@@ -414,10 +485,9 @@ __global__ __launch_bounds__(K1_THREADS) void k_preprocess(const K1Params p, con
     uint32_t lane_rank[K1_ITEMS];
 #pragma unroll
     for (int it = 0; it < K1_ITEMS; ++it) {
+        // unconditional (index clamped): four position loads in flight per lane, no vmcnt drain at a branch join
         const uint32_t idx = block_base + it * K1_THREADS + tid;
-        fr[it].xyz[0] = fr[it].xyz[1] = fr[it].xyz[2] = 0.0f;
-        fr[it].w3 = fr[it].geometry_idx = fr[it].sh_idx = 0u;
-        if (idx < n) k1_load_front<COMPRESSED>(b, idx, &fr[it]);
+        k1_load_front<COMPRESSED>(b, idx < n ? idx : n - 1u, &fr[it]);
     }
 #pragma unroll
     for (int it = 0; it < K1_ITEMS; ++it) {
@@ -451,7 +521,27 @@ __global__ __launch_bounds__(K1_THREADS) void k_preprocess(const K1Params p, con
         so[it].w[0] = so[it].w[1] = so[it].w[2] = so[it].w[3] = so[it].w[4] = 0u;
         so[it].key = 0u;
         so[it].rect = make_uint2(1u, 0u);
-        if (vis[it]) k1_back<COMPRESSED>(p, b, block_base + it * K1_THREADS + tid, fr[it], &so[it]);
+    }
+    if (!COMPRESSED) {
+        const uint32_t safe_idx = block_base < n ? block_base : 0u;  // culled lanes re-read this (cached) record
+#pragma unroll
+        for (int pair = 0; pair < K1_ITEMS; pair += 2) {
+            RawBack rb[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int it = pair + u;
+                k1_back_load(p, b, vis[it] ? block_base + it * K1_THREADS + tid : safe_idx, &rb[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int it = pair + u;
+                if (vis[it]) k1_back_math(p, fr[it], rb[u], &so[it]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < K1_ITEMS; ++it)
+            if (vis[it]) k1_back_compressed(p, b, fr[it], &so[it]);
     }
 
     // ---- ordered compaction, part 2: look-back (wave 0) and scatter ----------------------------------------

@@ -312,6 +312,166 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
     }
 }
 
+// ---- k_blend_q: one WAVE per 8x8 quadrant, no LDS, no barriers -------------------------------------------
+// Measured on MI355X (profiles/): the 256-thread kernel above is bound by the serial latency of one tile (two
+// barriers per 256-splat batch, three dependent LDS reads per splat), not by VALU (26 % busy) or LDS bandwidth.
+// Here every 8x8 quadrant is an independent 64-lane workgroup: lane l decodes entry l of the current 64-entry
+// chunk into registers, a ballot keeps only the splats whose padded bounding box touches the quadrant, and the
+// survivors are broadcast one at a time with v_readlane into SGPRs, which VALU instructions take as operands
+// directly.  No __syncthreads, early-out per quadrant, the next chunk's gathers are in flight while the current
+// chunk is composited.  The four quadrants of a tile are mapped to the same XCD (same L2) and dispatched
+// close together, so the entry list and the Splat records are fetched from HBM once.
+struct StagedSplat {
+    float cx, cy, i00, i01, i10, i11, alpha, r, g, b;
+    bool touch;
+};
+
+__device__ __forceinline__ StagedSplat decode_splat(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4,
+                                                    float W, float H, float qx_lo, float qy_lo, bool valid) {
+    StagedSplat s;
+    const float v1x = h2f(w0), v1y = h2f(w0 >> 16), v2x = h2f(w1), v2y = h2f(w1 >> 16);
+    const float m00 = v1x * W, m01 = v2x * W;
+    const float m10 = -v1y * H, m11 = -v2y * H;
+    const float det = m00 * m11 - m01 * m10;
+    const float inv = 1.0f / det;
+    s.cx = (h2f(w2) * 0.5f + 0.5f) * W;
+    s.cy = (0.5f - h2f(w2 >> 16) * 0.5f) * H;
+    s.i00 = m11 * inv;
+    s.i01 = -m01 * inv;
+    s.i10 = -m10 * inv;
+    s.i11 = m00 * inv;
+    s.alpha = h2f(w4 >> 16);
+    s.r = h2f(w3);
+    s.g = h2f(w3 >> 16);
+    s.b = h2f(w4);
+    const float rad = 2.1697873f * 1.00001f;
+    const float exx = rad * sqrtf(m00 * m00 + m01 * m01) + 1e-3f;
+    const float eyy = rad * sqrtf(m10 * m10 + m11 * m11) + 1e-3f;
+    // pixel centres of the quadrant span [q_lo, q_lo + 7]
+    s.touch = valid && (s.cx + exx >= qx_lo) && (s.cx - exx <= qx_lo + 7.0f) && (s.cy + eyy >= qy_lo) &&
+              (s.cy - eyy <= qy_lo + 7.0f);
+    return s;
+}
+
+__device__ __forceinline__ float bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <int FORMAT>
+__global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
+    // blockIdx -> (tile, quadrant): workgroup b runs on XCD b % 8 (observed; used for locality only)
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u, j = b >> 3;
+    const uint32_t q = j & 3u;
+    const uint32_t tile = (j >> 2) * 8u + xcd;
+    const uint32_t ntiles = p.tiles_x * p.tiles_y;
+    if (tile >= ntiles) return;
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int lane = threadIdx.x;
+    const uint32_t px = tx * TILE + (q & 1u) * 8u + (lane & 7);
+    const uint32_t py = ty * TILE + (q >> 1) * 8u + (lane >> 3);
+    const bool inside = px < p.width && py < p.height;
+    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    const float qx_lo = (float)(tx * TILE + (q & 1u) * 8u) + 0.5f;
+    const float qy_lo = (float)(ty * TILE + (q >> 1) * 8u) + 0.5f;
+    const float W = (float)p.width, H = (float)p.height;
+
+    const uint2 range = p.tile_ranges[tile];
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    bool done = !inside;
+
+    // Two-deep software pipeline over 64-entry chunks, walked from the END of the range (near) to its start (far):
+    // while chunk c is composited, the Splat gather of chunk c+1 and the entry-index load of chunk c+2 are in
+    // flight.  All loads are UNCONDITIONAL (addresses clamped into the range, validity tracked separately) so the
+    // loop body stays one basic block and the compiler can use counted s_waitcnt instead of draining vmcnt.
+    if (range.y > range.x) {
+    // entry index of this lane in the chunk that ends at hi_ (lane 0 = nearest); hi_ is clamped so the address
+    // is always inside [range.x, range.y)
+    auto entry_at = [&](uint32_t hi_) -> uint32_t {
+        const uint32_t h = hi_ > range.x ? hi_ : range.x + 1u;
+        const uint32_t nbb = (h - range.x) < 64u ? (h - range.x) : 64u;
+        const uint32_t off = (uint32_t)lane < nbb ? (uint32_t)lane : nbb - 1u;
+        return p.entry_vals[h - 1u - off];
+    };
+    auto chunk_len = [&](uint32_t hi_) -> uint32_t {
+        return hi_ > range.x ? ((hi_ - range.x) < 64u ? (hi_ - range.x) : 64u) : 0u;
+    };
+    uint32_t hi = range.y;                        // chunk being composited ends here
+    uint32_t hi1 = hi - chunk_len(hi);            // next chunk
+    uint32_t idx_cur = entry_at(hi);
+    uint32_t idx_next = entry_at(hi1);
+    uint32_t w0, w1, w2, w3, w4;
+    {
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx_cur * 20);
+        w0 = sp[0];
+        w1 = sp[1];
+        w2 = sp[2];
+        w3 = sp[3];
+        w4 = sp[4];
+    }
+    while (true) {
+        const uint32_t nb = chunk_len(hi);
+        const bool cur_valid = (uint32_t)lane < nb;
+        // issue: Splat gather of the next chunk, entry indices of the one after
+        const uint32_t* spn = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx_next * 20);
+        const uint32_t n0 = spn[0], n1 = spn[1], n2 = spn[2], n3 = spn[3], n4 = spn[4];
+        const uint32_t hi2 = hi1 - chunk_len(hi1);
+        const uint32_t idx_nn = entry_at(hi2);
+
+        const StagedSplat s = decode_splat(w0, w1, w2, w3, w4, W, H, qx_lo, qy_lo, cur_valid);
+        unsigned long long rel = __ballot(s.touch);
+        while (rel) {
+            const int k = __ffsll((long long)rel) - 1;
+            rel &= rel - 1ull;
+            const float dx = fx - bcast(s.cx, k), dy = fy - bcast(s.cy, k);
+            const float p0 = bcast(s.i00, k) * dx + bcast(s.i01, k) * dy;
+            const float p1 = bcast(s.i10, k) * dx + bcast(s.i11, k) * dy;
+            const float a = p0 * p0 + p1 * p1;
+            if (a <= CUT_A && !done) {
+                const float bb = fminf(0.99f, __expf(-a) * bcast(s.alpha, k));
+                const float wgt = bb * T;
+                cr += wgt * bcast(s.r, k);
+                cg += wgt * bcast(s.g, k);
+                cb += wgt * bcast(s.b, k);
+                T *= (1.0f - bb);
+                if (T < T_MIN) done = true;
+            }
+        }
+        if (__ballot(!done) == 0ull) break;  // the whole quadrant is saturated
+        if (hi1 <= range.x) break;           // that was the last chunk
+        hi = hi1;
+        hi1 = hi2;
+        idx_next = idx_nn;
+        w0 = n0;
+        w1 = n1;
+        w2 = n2;
+        w3 = n3;
+        w4 = n4;
+    }
+    }  // non-empty tile
+
+    if (inside) {
+        const float r = cr + p.background[0] * T;
+        const float g = cg + p.background[1] * T;
+        const float bch = cb + p.background[2] * T;
+        const float al = (1.0f - T) + p.background[3] * T;
+        char* row = reinterpret_cast<char*>(p.out) + (size_t)py * p.pitch;
+        if (FORMAT == WS_FORMAT_RGBA32_FLOAT) {
+            reinterpret_cast<float4*>(row)[px] = make_float4(r, g, bch, al);
+        } else if (FORMAT == WS_FORMAT_RGBA16_FLOAT) {
+            const uint32_t lo = (uint32_t)__half_as_ushort(__float2half_rn(r)) | ((uint32_t)__half_as_ushort(__float2half_rn(g)) << 16);
+            const uint32_t hi2 = (uint32_t)__half_as_ushort(__float2half_rn(bch)) | ((uint32_t)__half_as_ushort(__float2half_rn(al)) << 16);
+            reinterpret_cast<uint2*>(row)[px] = make_uint2(lo, hi2);
+        } else {
+            auto q8 = [](float v) -> uint32_t {
+                v = fminf(fmaxf(v, 0.0f), 1.0f);
+                return (uint32_t)__float2int_rn(v * 255.0f);
+            };
+            reinterpret_cast<uint32_t*>(row)[px] = q8(r) | (q8(g) << 8) | (q8(bch) << 16) | (q8(al) << 24);
+        }
+    }
+}
+
 }  // namespace
 
 uint32_t bin_prefix_blocks(uint32_t max_points) { return (max_points + BIN_ITEMS - 1) / BIN_ITEMS; }
@@ -345,9 +505,26 @@ int launch_tile_ranges(const uint32_t* sorted_keys, const BinBuffers& b, hipStre
 }
 
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
-    (void)variant;
     const uint32_t ntiles = p.tiles_x * p.tiles_y;
     if (ntiles == 0) return WS_OK;
+    if (variant == 1) {  // one wave per 8x8 quadrant (default)
+        const uint32_t groups = ((ntiles + 7u) / 8u) * 8u * 4u;
+        switch (p.format) {
+            case WS_FORMAT_RGBA32_FLOAT:
+                hipLaunchKernelGGL(k_blend_q<WS_FORMAT_RGBA32_FLOAT>, dim3(groups), dim3(64), 0, stream, p);
+                break;
+            case WS_FORMAT_RGBA16_FLOAT:
+                hipLaunchKernelGGL(k_blend_q<WS_FORMAT_RGBA16_FLOAT>, dim3(groups), dim3(64), 0, stream, p);
+                break;
+            case WS_FORMAT_RGBA8_UNORM:
+                hipLaunchKernelGGL(k_blend_q<WS_FORMAT_RGBA8_UNORM>, dim3(groups), dim3(64), 0, stream, p);
+                break;
+            default:
+                return fail(WS_ERR_INVALID, "blend: unknown colour format");
+        }
+        WS_HIP(hipGetLastError());
+        return WS_OK;
+    }
     switch (p.format) {
         case WS_FORMAT_RGBA32_FLOAT:
             hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA32_FLOAT>, dim3(ntiles), dim3(256), 0, stream, p);

@@ -4,6 +4,7 @@
 // PointCloud (pointcloud.rs:72-222) -> ws_pointcloud, GaussianRenderer (renderer.rs:17-283) -> ws_renderer,
 // GPURSSorter + PointCloudSortStuff (gpu_rs.rs:23-175, 865-884) -> ws_sorter.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -514,6 +515,13 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     kp.sh_deg_layout = (r->sh_deg + 1) * (r->sh_deg + 1);
     kp.tiles_x = r->tiles_x;
     kp.tiles_y = r->tiles_y;
+    kp.znear = -kp.cam.proj[3 * 4 + 2] / kp.cam.proj[2 * 4 + 2];
+    kp.zfar = -kp.cam.proj[3 * 4 + 2] / (kp.cam.proj[2 * 4 + 2] - 1.0f);
+    // fade-in (preprocess.wgsl:196-203): dd = 5 |centre - xyz| / extend <= 10 because the centroid lies inside the
+    // bbox and extend >= its radius; beyond walltime 11 s smoothstep(walltime - dd) is exactly 1 for every Gaussian.
+    // (the clip box only removes Gaussians, so the bound holds for user boxes too)
+    kp.fade_done = (kp.rs.walltime >= 11.0f && kp.rs.scene_extend > 0.0f && std::isfinite(kp.rs.scene_extend) &&
+                    !args->has_clipping_box) ? 1u : 0u;
 
     K1Buffers kb;
     kb.planes = pc->planes;

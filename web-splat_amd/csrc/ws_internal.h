@@ -60,6 +60,8 @@ struct K1Params {
     uint32_t sh_deg_layout;  // compressed: number of coefficients per packed SH record, (sh_deg+1)^2
     uint32_t tiles_x, tiles_y;
     uint32_t epoch;          // look-back epoch of this frame (lookback.h)
+    float znear, zfar;       // -proj[3][2]/proj[2][2], -proj[3][2]/(proj[2][2]-1)  (preprocess.wgsl:270-271)
+    uint32_t fade_done;      // walltime is past every Gaussian's fade-in: scale_mod == 1 exactly
 };
 
 // uncompressed point cloud in HBM: eight planes of 16-B chunks, plane p of Gaussian i at
