@@ -153,6 +153,12 @@ typedef struct ws_stage_times {
     float rasterization_ms;
 } ws_stage_times;
 
+/* one kernel launch of the last frame, in launch order (utils.rs:26-134 GPUStopwatch at kernel granularity) */
+typedef struct ws_kernel_time {
+    char name[40];
+    float ms;
+} ws_kernel_time;
+
 /* device-side statistics of the last prepared frame (forces a sync) */
 typedef struct ws_frame_stats {
     uint32_t num_visible;      /* V: renderer.rs:170-189 num_visible_points */
@@ -230,8 +236,11 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
 int ws_renderer_num_visible(ws_renderer* r, uint32_t* out);
 int ws_renderer_frame_stats(ws_renderer* r, ws_frame_stats* out); /* syncs */
 /* GPUStopwatch::take_measurements for the last frame (syncs); needs ws_renderer_enable_timers(r,1) */
+/* enable: 0 = off, 1 = the four stage labels, 2 = additionally one HIP event pair per kernel launch */
 int ws_renderer_enable_timers(ws_renderer* r, int enable);
 int ws_renderer_stage_times(ws_renderer* r, ws_stage_times* out);
+/* per-launch GPU time of the last frame (prepare + render), launch order; *count = launches recorded. Syncs. */
+int ws_renderer_kernel_times(ws_renderer* r, uint32_t capacity, ws_kernel_time* out, uint32_t* count);
 /* parity tooling: also record the original Gaussian index of every store slot (costs 4 B per visible splat) */
 int ws_renderer_enable_capture(ws_renderer* r, int enable);
 /* tuning: capacity of the (tile, splat) entry list; 0 = automatic. Takes effect at the next prepare. */
@@ -242,6 +251,10 @@ int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries);
  * (far -> near).  Any pointer may be NULL.  capacity = number of elements each array can hold. Syncs. */
 int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, uint32_t* keys,
                                uint32_t* src_index, uint32_t* sorted, uint32_t* num_visible);
+/* tuning / analysis read-back: per 16x16 tile, the length of its depth-ordered splat list and (capture mode)
+ * how many of its entries the compositing pass walked before every pixel was saturated.  Syncs. */
+int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t* list_len, uint32_t* consumed,
+                                    uint32_t* num_tiles);
 
 /* ---- GPURSSorter: gpu_rs.rs:65-175, 720-727, 865-884 ------------------------------------------ */
 /* GPURSSorter::new + create_sort_stuff(device, max_n): scratch for sorting up to max_n pairs */

@@ -50,6 +50,38 @@ def c2(ws, oracle, n=1_200_000, viewport=(1200, 799), cam_index=0, n_cams=64, se
     return Scene(ws, oracle, rows, 3, cj, viewport, **kw)
 
 
+# ---- the stated image tolerance (DESIGN.md "Oracle and parity") ---------------------------------
+MAX_ABS = 2e-3    # premultiplied RGBA, f32 target, every pixel ...
+MEAN_ABS = 1e-4
+# ... except cut-off boundary pixels: gaussian.wgsl:61-64 DISCARDS a fragment when a > 2*CUTOFF, a step of
+# exp(-2*CUTOFF) * alpha = 0.00903 * alpha in the fragment's weight.  Two correct f32 evaluations of `a` (the
+# reference's interpolated screen_pos on a GPU, the oracle's explicit M^-1 (pixel - centre), this library's
+# tile-local affine form) differ in the last ulps, so a fragment whose `a` lies within ~1e-6 of the cut-off can be
+# kept by one and discarded by the other.  Such pixels are rare (measured ~2 per 10 k-splat frame) and their error
+# is bounded by ONE boundary fragment: 0.00903 * 0.99 * colour.
+BOUNDARY_STEP = 0.0135            # 0.00903 * 0.99 * colour <= 1.5 (SH colours may exceed 1)
+BOUNDARY_PIXEL_FRACTION = 2e-5    # at most this fraction of the pixels (and never fewer than 4 allowed)
+
+
+def image_close(img, ref, max_abs=MAX_ABS, mean_abs=MEAN_ABS, allow_boundary=True):
+    """Returns (ok, message, max_abs_seen, mean_abs_seen, boundary_pixels)."""
+    d = np.abs(img.astype(np.float64) - ref.astype(np.float64))
+    if not np.isfinite(img).all():
+        return False, "non-finite pixels", float("nan"), float("nan"), 0
+    per_px = d.reshape(-1, d.shape[-1]).max(axis=1)
+    over = per_px > max_abs
+    n_over = int(over.sum())
+    allowed = max(4, int(BOUNDARY_PIXEL_FRACTION * per_px.size)) if allow_boundary else 0
+    mx, mean = float(d.max()), float(d.mean())
+    if n_over > allowed:
+        return False, f"{n_over} pixels above max-abs {max_abs:g} (allowed cut-off boundary pixels: {allowed}); max {mx:.3e}", mx, mean, n_over
+    if n_over and mx > BOUNDARY_STEP:
+        return False, f"max-abs {mx:.3e} exceeds one cut-off boundary fragment ({BOUNDARY_STEP:g})", mx, mean, n_over
+    if mean > mean_abs:
+        return False, f"mean-abs {mean:.3e} > {mean_abs:g}", mx, mean, n_over
+    return True, "", mx, mean, n_over
+
+
 def half_ulp_diff(a_bits, b_bits):
     """Distance in f16 ulps between two arrays of binary16 bit patterns (monotone integer mapping)."""
     def key(x):

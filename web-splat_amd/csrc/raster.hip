@@ -209,106 +209,208 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict_
 
 // ---- k_blend ---------------------------------------------------------------------------------------
 // One workgroup = one 16x16 tile, one pixel per thread; wave w owns the 8x8 quadrant (w&1, w>>1).
-// Splats are staged through LDS 256 at a time in NEAR -> FAR order; a staged record carries the inverse of the
-// 2x2 screen-axes matrix so that a = |M^-1 (pixel - centre)|^2 is exactly gaussian.wgsl:60's
-// dot(screen_pos, screen_pos) with affinely interpolated screen_pos.
+// Splats are staged through LDS 256 at a time in NEAR -> FAR order.  A staged record is the affine map
+//   screen_pos * sqrt(log2 e) = I' * pixel_local + c      (I' = sqrt(log2 e) * M^-1, c = -I' * centre_local)
+// in TILE-LOCAL pixel coordinates, so a' = |.|^2 = log2(e) * dot(screen_pos, screen_pos) of gaussian.wgsl:60 costs
+// four FMAs + a multiply-add per pixel and exp(-a) is a bare v_exp_f32 (2^-a').  Measured on MI355X (profiles/):
+// walking all 256 staged records with one dependent LDS read + branch each made the kernel latency-bound
+// (~30 us per batch); here every wave first compacts the staged records to those whose kept ELLIPSE (exact
+// ellipse-vs-square test, not the bounding box) reaches its quadrant -- 4 LDS reads + 4 ballots per batch -- and
+// then walks only those, with the next record's LDS reads in flight while the current one is composited.
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float SQRT_LOG2E = 1.2011224087864498f;
+constexpr float CUT_A2 = CUT_A * LOG2E;  // gaussian.wgsl:61 cut-off, in the exp2 domain
+
+// min over y in [y0, y1] of the quadratic form A X^2 + B2 X y + C y^2 (C > 0), X fixed
+__device__ __forceinline__ float qform_min_on_edge(float A, float B2, float C, float rcpC, float X, float y0, float y1) {
+    const float ys = fminf(fmaxf(-0.5f * B2 * X * rcpC, y0), y1);
+    return (A * X + B2 * ys) * X + C * ys * ys;
+}
+
+// Does the kept ellipse {d : |N d|^2 <= cut} (centre at the origin) reach the square [x0,x1] x [y0,y1]?
+// Conservative by a relative 1e-4 margin (the per-pixel test is exact; this only prunes work).
+__device__ __forceinline__ bool ellipse_reaches_box(float A, float B2, float C, float rcpA, float rcpC, float x0,
+                                                    float x1, float y0, float y1, float cut) {
+    if (x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f) return true;
+    float q = qform_min_on_edge(A, B2, C, rcpC, x0, y0, y1);
+    q = fminf(q, qform_min_on_edge(A, B2, C, rcpC, x1, y0, y1));
+    q = fminf(q, qform_min_on_edge(C, B2, A, rcpA, y0, x0, x1));
+    q = fminf(q, qform_min_on_edge(C, B2, A, rcpA, y1, x0, x1));
+    return q <= cut * 1.0001f + 1e-4f;
+}
+
+// blockIdx -> tile.  4x4-tile blocks (64x64 px) are dealt round-robin to the 8 XCDs (workgroup b runs on XCD
+// b % 8 -- observed, used for locality only): a splat's tiles mostly share a block, so its 20-B record and the
+// neighbouring entry lists are served by ONE L2, while every XCD gets blocks from all over the image.
+__device__ __forceinline__ bool blend_tile_of_block(uint32_t b, uint32_t tiles_x, uint32_t tiles_y, uint32_t* tx,
+                                                    uint32_t* ty) {
+    const uint32_t nbx = (tiles_x + 3u) >> 2, nby = (tiles_y + 3u) >> 2;
+    const uint32_t xcd = b & 7u, j = b >> 3;
+    const uint32_t blk = (j >> 4) * 8u + xcd;
+    if (blk >= nbx * nby) return false;
+    const uint32_t bx = blk % nbx, by = blk / nbx;
+    *tx = bx * 4u + (j & 3u);
+    *ty = by * 4u + ((j >> 2) & 3u);
+    return *tx < tiles_x && *ty < tiles_y;
+}
+__host__ __device__ inline uint32_t blend_grid_blocks(uint32_t tiles_x, uint32_t tiles_y) {
+    const uint32_t nb = ((tiles_x + 3u) >> 2) * ((tiles_y + 3u) >> 2);
+    return ((nb + 7u) / 8u) * 8u * 16u;
+}
+
+template <int FORMAT>
+__device__ __forceinline__ void store_pixel(const BlendParams& p, uint32_t px, uint32_t py, float r, float g, float b,
+                                            float al) {
+    char* row = reinterpret_cast<char*>(p.out) + (size_t)py * p.pitch;
+    if (FORMAT == WS_FORMAT_RGBA32_FLOAT) {
+        reinterpret_cast<float4*>(row)[px] = make_float4(r, g, b, al);
+    } else if (FORMAT == WS_FORMAT_RGBA16_FLOAT) {
+        const uint32_t lo = (uint32_t)__half_as_ushort(__float2half_rn(r)) | ((uint32_t)__half_as_ushort(__float2half_rn(g)) << 16);
+        const uint32_t hi2 = (uint32_t)__half_as_ushort(__float2half_rn(b)) | ((uint32_t)__half_as_ushort(__float2half_rn(al)) << 16);
+        reinterpret_cast<uint2*>(row)[px] = make_uint2(lo, hi2);
+    } else {
+        auto q8 = [](float v) -> uint32_t {
+            v = fminf(fmaxf(v, 0.0f), 1.0f);
+            return (uint32_t)__float2int_rn(v * 255.0f);
+        };
+        reinterpret_cast<uint32_t*>(row)[px] = q8(r) | (q8(g) << 8) | (q8(b) << 16) | (q8(al) << 24);
+    }
+}
+
+// raw words of one staged entry: the 20-B Splat record (pointcloud.rs:352-358)
+struct RawSplat {
+    uint32_t w0, w1, w2, w3, w4;
+};
+// Unconditional gather of this thread's entry of the batch that ends at `hi` (slot 0 = nearest).  The address
+// is clamped into the tile's range, so the loads never depend on a branch and can be issued a whole batch ahead.
+__device__ __forceinline__ RawSplat blend_fetch_raw(const BlendParams& p, uint2 range, uint32_t hi, int tid) {
+    const uint32_t h = hi > range.x ? hi : range.x + 1u;
+    const uint32_t nb = (h - range.x) < 256u ? (h - range.x) : 256u;
+    const uint32_t off = (uint32_t)tid < nb ? (uint32_t)tid : nb - 1u;
+    const uint32_t idx = p.entry_vals[h - 1u - off];
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx * 20);
+    RawSplat r;
+    r.w0 = sp[0];
+    r.w1 = sp[1];
+    r.w2 = sp[2];
+    r.w3 = sp[3];
+    r.w4 = sp[4];
+    return r;
+}
+
 template <int FORMAT>
 __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
-    __shared__ float4 s_a[256];  // cx, cy, i00, i01
-    __shared__ float4 s_b[256];  // i10, i11, alpha, quadrant mask (bits)
-    __shared__ float4 s_c[256];  // r, g, b, -
+    __shared__ float4 s_g[256];        // i00', i01', c0, alpha
+    __shared__ float4 s_h[256];        // i10', i11', c1, r
+    __shared__ float2 s_c[256];        // g, b
+    __shared__ uint32_t s_m[256];      // quadrant bits of the staged record (0 = slot unused)
+    __shared__ uint32_t s_list[4][260];  // per wave: staged slots that reach its quadrant, near -> far (+ pad)
 
-    const uint32_t tile = blockIdx.x;
-    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    uint32_t tx, ty;
+    if (!blend_tile_of_block(blockIdx.x, p.tiles_x, p.tiles_y, &tx, &ty)) return;  // block-uniform
+    const uint32_t tile = ty * p.tiles_x + tx;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int qx = wave & 1, qy = wave >> 1;
+    const float lx = (float)(qx * 8 + (lane & 7)) + 0.5f;  // tile-local pixel centre
+    const float ly = (float)(qy * 8 + (lane >> 3)) + 0.5f;
     const uint32_t px = tx * TILE + qx * 8 + (lane & 7);
     const uint32_t py = ty * TILE + qy * 8 + (lane >> 3);
     const bool inside = px < p.width && py < p.height;
-    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     const uint32_t qbit = 1u << wave;
 
     const uint2 range = p.tile_ranges[tile];
-    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    bool done = !inside;
+    // Pixels outside the image start with T = 0: they accumulate nothing and count as saturated.  There is no
+    // per-pixel "done" flag in the inner loop: a pixel below T_MIN keeps accumulating (its contributions are
+    // below T_MIN, the reference has no cut-off at all); T only decides when a wave / the tile may stop.
+    float T = inside ? 1.0f : 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
     const float W = (float)p.width, H = (float)p.height;
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
+    uint32_t* my_list = s_list[wave];
 
-    for (uint32_t hi = range.y; hi > range.x;) {
+    uint32_t hi = range.y;
+    RawSplat raw = blend_fetch_raw(p, range, hi, tid);
+    while (hi > range.x) {
         const uint32_t nb = (hi - range.x) < 256u ? (hi - range.x) : 256u;
+        uint32_t mask = 0u;
         if ((uint32_t)tid < nb) {
-            const uint32_t idx = p.entry_vals[hi - 1u - (uint32_t)tid];  // staged slot 0 = nearest
-            const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx * 20);
-            const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3], w4 = sp[4];
-            const float v1x = h2f(w0), v1y = h2f(w0 >> 16), v2x = h2f(w1), v2y = h2f(w1 >> 16);
+            const float v1x = h2f(raw.w0), v1y = h2f(raw.w0 >> 16), v2x = h2f(raw.w1), v2y = h2f(raw.w1 >> 16);
             const float m00 = v1x * W, m01 = v2x * W;
             const float m10 = -v1y * H, m11 = -v2y * H;
             const float det = m00 * m11 - m01 * m10;
-            const float inv = 1.0f / det;
-            const float cx = (h2f(w2) * 0.5f + 0.5f) * W;
-            const float cy = (0.5f - h2f(w2 >> 16) * 0.5f) * H;
-            // quadrant mask from the padded bounding box of the kept ellipse (same padding as K1's rect)
-            const float rad = 2.1697873f * 1.00001f;
-            const float exx = rad * sqrtf(m00 * m00 + m01 * m01) + 1e-3f;
-            const float eyy = rad * sqrtf(m10 * m10 + m11 * m11) + 1e-3f;
-            uint32_t mask = 0u;
+            const float inv = SQRT_LOG2E / det;
+            const float cxl = (h2f(raw.w2) * 0.5f + 0.5f) * W - tile_x0;  // centre, tile-local pixels
+            const float cyl = (0.5f - h2f(raw.w2 >> 16) * 0.5f) * H - tile_y0;
+            const float i00 = m11 * inv, i01 = -m01 * inv, i10 = -m10 * inv, i11 = m00 * inv;
+            const float c0 = -(i00 * cxl + i01 * cyl), c1 = -(i10 * cxl + i11 * cyl);
+            // a'(d) = A dx^2 + B2 dx dy + C dy^2 around the centre
+            const float A = i00 * i00 + i10 * i10, C = i01 * i01 + i11 * i11, B2 = 2.0f * (i00 * i01 + i10 * i11);
+            const float rcpA = __builtin_amdgcn_rcpf(A), rcpC = __builtin_amdgcn_rcpf(C);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float x_lo = tile_x0 + (float)((q & 1) * 8) + 0.5f, x_hi = x_lo + 7.0f;
-                const float y_lo = tile_y0 + (float)((q >> 1) * 8) + 0.5f, y_hi = y_lo + 7.0f;
-                if (cx + exx >= x_lo && cx - exx <= x_hi && cy + eyy >= y_lo && cy - eyy <= y_hi) mask |= 1u << q;
+                // pixel centres of quadrant q span [q*8 + 0.5, q*8 + 7.5] in tile-local coordinates
+                const float x0 = (float)((q & 1) * 8) + 0.5f - cxl, y0 = (float)((q >> 1) * 8) + 0.5f - cyl;
+                if (ellipse_reaches_box(A, B2, C, rcpA, rcpC, x0, x0 + 7.0f, y0, y0 + 7.0f, CUT_A2)) mask |= 1u << q;
             }
-            s_a[tid] = make_float4(cx, cy, m11 * inv, -m01 * inv);
-            s_b[tid] = make_float4(-m10 * inv, m00 * inv, h2f(w4 >> 16), __uint_as_float(mask));
-            s_c[tid] = make_float4(h2f(w3), h2f(w3 >> 16), h2f(w4), 0.0f);
+            s_g[tid] = make_float4(i00, i01, c0, h2f(raw.w4 >> 16));
+            s_h[tid] = make_float4(i10, i11, c1, h2f(raw.w3));
+            s_c[tid] = make_float2(h2f(raw.w3 >> 16), h2f(raw.w4));
         }
+        s_m[tid] = mask;
+        // the next batch's gathers (entry index -> Splat record, two dependent round trips) fly while this batch
+        // is composited; wasted only when the tile saturates first
+        const uint32_t hi_next = hi - nb;
+        raw = blend_fetch_raw(p, range, hi_next, tid);
         __syncthreads();
-        // a wave whose 64 pixels are all saturated has nothing left to add: it only keeps staging
-        const uint32_t nk = (__ballot(!done) == 0ull) ? 0u : nb;
-        for (uint32_t k = 0; k < nk; ++k) {
-            const float4 b4 = s_b[k];
-            if (!(__float_as_uint(b4.w) & qbit)) continue;  // wave-uniform
-            const float4 a4 = s_a[k];
-            const float dx = fx - a4.x, dy = fy - a4.y;
-            const float p0 = a4.z * dx + a4.w * dy;
-            const float p1 = b4.x * dx + b4.y * dy;
-            const float a = p0 * p0 + p1 * p1;
-            if (a <= CUT_A && !done) {
-                const float4 c4 = s_c[k];
-                const float b = fminf(0.99f, __expf(-a) * b4.z);
-                const float wgt = b * T;
-                cr += wgt * c4.x;
-                cg += wgt * c4.y;
-                cb += wgt * c4.z;
-                T *= (1.0f - b);
-                if (T < T_MIN) done = true;
+        if (__ballot(T >= T_MIN) != 0ull) {  // a wave whose 64 pixels are saturated only keeps staging
+            // wave-private compaction: slots whose kept ellipse reaches this quadrant, in near -> far order
+            uint32_t n = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool t = (s_m[r * 64 + lane] & qbit) != 0u;
+                const unsigned long long bal = __ballot(t);
+                const uint32_t pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (t) my_list[pos] = (uint32_t)(r * 64 + lane);
+                n += (uint32_t)__popcll(bal);
+            }
+            if (n > 0u) {
+                // two-deep pipeline: slot index of record i+2 and the record i+1 are in flight while i is composited
+                uint32_t k_next = my_list[n > 1u ? 1u : 0u];
+                uint32_t k_cur = my_list[0];
+                float4 g4 = s_g[k_cur], h4 = s_h[k_cur];
+                float2 c2 = s_c[k_cur];
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t i2 = (i + 2u < n) ? i + 2u : n - 1u;
+                    const uint32_t k_nn = my_list[i2];
+                    const float4 gn = s_g[k_next], hn = s_h[k_next];
+                    const float2 cn = s_c[k_next];
+                    const float p0 = fmaf(g4.x, lx, fmaf(g4.y, ly, g4.z));
+                    const float p1 = fmaf(h4.x, lx, fmaf(h4.y, ly, h4.z));
+                    const float a = fmaf(p0, p0, p1 * p1);
+                    if (a <= CUT_A2) {
+                        const float b = fminf(0.99f, __builtin_amdgcn_exp2f(-a) * g4.w);
+                        const float wgt = b * T;
+                        cr = fmaf(wgt, h4.w, cr);
+                        cg = fmaf(wgt, c2.x, cg);
+                        cb = fmaf(wgt, c2.y, cb);
+                        T -= wgt;
+                    }
+                    k_next = k_nn;
+                    g4 = gn;
+                    h4 = hn;
+                    c2 = cn;
+                }
             }
         }
-        hi -= nb;
-        if (__syncthreads_and(done ? 1 : 0)) break;
+        hi = hi_next;
+        if (__syncthreads_and(T < T_MIN ? 1 : 0)) break;
     }
+    if (p.debug_consumed && tid == 0) p.debug_consumed[tile] = range.y - hi;
 
     if (inside) {
         // begin_render_pass(clear = background) then "over": dst = src + dst * (1 - src.a), all four channels
-        const float r = cr + p.background[0] * T;
-        const float g = cg + p.background[1] * T;
-        const float b = cb + p.background[2] * T;
-        const float al = (1.0f - T) + p.background[3] * T;
-        char* row = reinterpret_cast<char*>(p.out) + (size_t)py * p.pitch;
-        if (FORMAT == WS_FORMAT_RGBA32_FLOAT) {
-            reinterpret_cast<float4*>(row)[px] = make_float4(r, g, b, al);
-        } else if (FORMAT == WS_FORMAT_RGBA16_FLOAT) {
-            const uint32_t lo = (uint32_t)__half_as_ushort(__float2half_rn(r)) | ((uint32_t)__half_as_ushort(__float2half_rn(g)) << 16);
-            const uint32_t hi2 = (uint32_t)__half_as_ushort(__float2half_rn(b)) | ((uint32_t)__half_as_ushort(__float2half_rn(al)) << 16);
-            reinterpret_cast<uint2*>(row)[px] = make_uint2(lo, hi2);
-        } else {
-            auto q8 = [](float v) -> uint32_t {
-                v = fminf(fmaxf(v, 0.0f), 1.0f);
-                return (uint32_t)__float2int_rn(v * 255.0f);
-            };
-            reinterpret_cast<uint32_t*>(row)[px] = q8(r) | (q8(g) << 8) | (q8(b) << 16) | (q8(al) << 24);
-        }
+        store_pixel<FORMAT>(p, px, py, cr + p.background[0] * T, cg + p.background[1] * T, cb + p.background[2] * T,
+                            (1.0f - T) + p.background[3] * T);
     }
 }
 
@@ -437,8 +539,10 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
                 if (T < T_MIN) done = true;
             }
         }
-        if (__ballot(!done) == 0ull) break;  // the whole quadrant is saturated
-        if (hi1 <= range.x) break;           // that was the last chunk
+        if (__ballot(!done) == 0ull || hi1 <= range.x) {  // quadrant saturated, or that was the last chunk
+            if (p.debug_consumed && lane == 0) atomicMax(p.debug_consumed + tile, range.y - hi1);
+            break;
+        }
         hi = hi1;
         hi1 = hi2;
         idx_next = idx_nn;
@@ -525,15 +629,16 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
         WS_HIP(hipGetLastError());
         return WS_OK;
     }
+    const uint32_t grid = blend_grid_blocks(p.tiles_x, p.tiles_y);
     switch (p.format) {
         case WS_FORMAT_RGBA32_FLOAT:
-            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA32_FLOAT>, dim3(ntiles), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA32_FLOAT>, dim3(grid), dim3(256), 0, stream, p);
             break;
         case WS_FORMAT_RGBA16_FLOAT:
-            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA16_FLOAT>, dim3(ntiles), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA16_FLOAT>, dim3(grid), dim3(256), 0, stream, p);
             break;
         case WS_FORMAT_RGBA8_UNORM:
-            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA8_UNORM>, dim3(ntiles), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA8_UNORM>, dim3(grid), dim3(256), 0, stream, p);
             break;
         default:
             return fail(WS_ERR_INVALID, "blend: unknown colour format");

@@ -320,20 +320,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 template <int KPT>
 int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout,
                     const uint32_t* d_count, uint32_t n, int begin_bit, int npass, bool implicit_iota,
-                    bool first_tile_hist_ready, uint32_t epoch, hipStream_t stream, uint32_t** fk, uint32_t** fv) {
+                    bool first_tile_hist_ready, uint32_t epoch, hipStream_t stream, uint32_t** fk, uint32_t** fv,
+                    KernelMarks* km, const char* const* names) {
     constexpr uint32_t TILE_N = SORT_THREADS * KPT;
     const uint32_t tiles = (n + TILE_N - 1) / TILE_N;
     for (int p = 0; p < npass; ++p) {
         const int shift = begin_bit + p * RADIX_BITS;
         const int iota = (implicit_iota && p == 0) ? 1 : 0;
-        if (!(p == 0 && first_tile_hist_ready))
+        if (!(p == 0 && first_tile_hist_ready)) {
             hipLaunchKernelGGL(k_sort_tile_hist<KPT>, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift,
                                sc.tile_sums, sc.tiles_cap);
+            km_mark(km, names[0]);
+        }
         hipLaunchKernelGGL(k_sort_col_scan, dim3(RADIX), dim3(SORT_THREADS), 0, stream, d_count, n, TILE_N, sc.tile_sums,
                            sc.tiles_cap, sc.hist + p * RADIX);
+        km_mark(km, names[1]);
         hipLaunchKernelGGL((k_sort_scatter<false, KPT>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout,
                            d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr, (uint32_t*)nullptr,
                            sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr);
+        km_mark(km, names[2]);
         WS_HIP(hipGetLastError());
         uint32_t* tk = kin;
         kin = kout;
@@ -353,7 +358,15 @@ uint32_t sort_tile_size(uint32_t n) { return n <= SORT_SMALL_MAX ? SORT_THREADS 
 
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
-                      uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals) {
+                      uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km,
+                      const char* tag) {
+    // labels of the per-kernel timers: "<tag>k_sort_..." with tag = "depth:" / "tiles:"
+    const bool depth = tag && tag[0] == 'd';
+    static const char* const N_DEPTH[4] = {"depth:k_sort_tile_hist", "depth:k_sort_col_scan", "depth:k_sort_scatter",
+                                           "depth:k_sort_hist"};
+    static const char* const N_TILES[4] = {"tiles:k_sort_tile_hist", "tiles:k_sort_col_scan", "tiles:k_sort_scatter",
+                                           "tiles:k_sort_hist"};
+    const char* const* names = depth ? N_DEPTH : N_TILES;
     if (out_keys) *out_keys = keys;
     if (out_vals) *out_vals = vals;
     if (n == 0) return WS_OK;
@@ -372,10 +385,10 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
         int rc;
         if (sort_tile_size(n) == SORT_TILE)
             rc = run_passes_scan<SORT_KPT>(sc, kin, vin, kout, vout, d_count, n, begin_bit, npass, implicit_iota,
-                                           first_tile_hist_ready, epoch, stream, &kin, &vin);
+                                           first_tile_hist_ready, epoch, stream, &kin, &vin, km, names);
         else
             rc = run_passes_scan<SORT_KPT_SMALL>(sc, kin, vin, kout, vout, d_count, n, begin_bit, npass, implicit_iota,
-                                                 first_tile_hist_ready, epoch, stream, &kin, &vin);
+                                                 first_tile_hist_ready, epoch, stream, &kin, &vin, km, names);
         if (rc) return rc;
     } else {
         const uint32_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
@@ -384,6 +397,7 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
         if (hist_blocks > 1024) hist_blocks = 1024;
         hipLaunchKernelGGL(k_sort_hist, dim3(hist_blocks), dim3(SORT_THREADS), 0, stream, kin, d_count, n, begin_bit,
                            npass, sc.hist);
+        km_mark(km, names[3]);
         WS_HIP(hipGetLastError());
         for (int p = 0; p < npass; ++p) {
             const int shift = begin_bit + p * RADIX_BITS;
@@ -392,6 +406,7 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                                kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX,
                                sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr, 0u,
                                epoch, sc.error);
+            km_mark(km, names[2]);
             WS_HIP(hipGetLastError());
             uint32_t* tk = kin;
             kin = kout;

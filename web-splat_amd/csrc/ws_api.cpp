@@ -45,6 +45,31 @@ static void dfree(T*& p) {
     p = nullptr;
 }
 
+int KernelMarks::create() {
+    if (created) return WS_OK;
+    for (auto& e : ev) WS_HIP(hipEventCreate(&e));
+    created = true;
+    return WS_OK;
+}
+void KernelMarks::destroy() {
+    if (!created) return;
+    for (auto& e : ev)
+        if (e) (void)hipEventDestroy(e);
+    created = false;
+}
+void KernelMarks::begin(hipStream_t s, bool restart) {
+    stream = s;
+    if (restart) n = 0;
+    // render() continues the frame prepare() started: ev[n] already closes the previous interval
+    if (n == 0) (void)hipEventRecord(ev[0], s);
+}
+void KernelMarks::mark(const char* what) {
+    if (n >= MAX) return;
+    label[n] = what;
+    (void)hipEventRecord(ev[n + 1], stream);
+    ++n;
+}
+
 }  // namespace ws
 
 using namespace ws;
@@ -101,7 +126,9 @@ struct ws_renderer {
     hipStream_t last_stream = nullptr;
 
     bool capture = false;
+    uint32_t* debug_consumed = nullptr;  // [tiles], capture mode only
     bool timers = false;
+    KernelMarks marks;               // per-kernel events, timers level 2
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_prepare_valid = false, ev_render_valid = false;
 };
@@ -153,6 +180,7 @@ static void renderer_free_scratch(ws_renderer* r) {
     dfree(r->ekeys_b);
     dfree(r->evals_a);
     dfree(r->evals_b);
+    dfree(r->debug_consumed);
     if (r->zero) (void)hipFree(r->zero);
     r->zero = nullptr;
     r->tile_ranges = nullptr;
@@ -201,6 +229,7 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     if ((rc = dmalloc(&r->emit_start, (size_t)r->entry_cap / EMIT_TILE + 4))) return rc;
     r->tiles_x = (vw + TILE - 1) / TILE;
     r->tiles_y = (vh + TILE - 1) / TILE;
+    if ((rc = dmalloc(&r->debug_consumed, (size_t)r->tiles_x * r->tiles_y))) return rc;
     // the per-frame zero arena: counters | depth histograms | tile histograms | tile ranges
     r->zero_bytes = sizeof(FrameZero) + (size_t)r->tiles_x * r->tiles_y * sizeof(uint2);
     WS_HIP(hipMalloc(reinterpret_cast<void**>(&r->zero), r->zero_bytes));
@@ -464,6 +493,7 @@ void ws_renderer_destroy(ws_renderer* r) {
     renderer_free_scratch(r);
     for (auto& e : r->ev)
         if (e) (void)hipEventDestroy(e);
+    r->marks.destroy();
     delete r;
 }
 
@@ -473,6 +503,13 @@ int ws_renderer_enable_timers(ws_renderer* r, int enable) {
     if (!r) return fail(WS_ERR_INVALID, "ws_renderer_enable_timers: null renderer");
     r->timers = enable != 0;
     r->ev_prepare_valid = r->ev_render_valid = false;
+    r->marks.active = false;
+    r->marks.n = 0;
+    if (enable >= 2) {  // per-kernel events
+        int rc = r->marks.create();
+        if (rc) return rc;
+        r->marks.active = true;
+    }
     return WS_OK;
 }
 
@@ -547,14 +584,17 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     // GPURSSorter::record_reset_indirect_buffer (gpu_rs.rs:720-727): keys_size = 0, dispatch = 0 -- here ONE
     // memset clears the counters, every ticket, both sorts' digit histograms and the tile ranges
     WS_HIP(hipMemsetAsync(r->zero, 0, r->zero_bytes, stream));
+    KernelMarks* km = r->marks.active ? &r->marks : nullptr;
+    if (km) km->begin(stream, true);
     if (r->timers) WS_HIP(hipEventRecord(r->ev[0], stream));
     if ((rc = launch_preprocess(kp, kb, pc->compressed, stream))) return rc;
+    km_mark(km, pc->compressed ? "k_preprocess<compressed>" : "k_preprocess");
     if (r->timers) WS_HIP(hipEventRecord(r->ev[1], stream));
 
     // depth sort: V (key, store index) pairs, 4 x 8 bit, values start as iota (preprocess.wgsl:274)
     uint32_t *sk = nullptr, *sv = nullptr;
     if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
-                                true, false, r->ctx->sort_algo, r->epoch, stream, &sk, &sv)))
+                                true, false, r->ctx->sort_algo, r->epoch, stream, &sk, &sv, km, "depth:")))
         return rc;
     r->sorted_idx = sv;
     if (r->timers) WS_HIP(hipEventRecord(r->ev[2], stream));
@@ -582,16 +622,20 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     bb.tile_hist = fused_hist ? r->sort_tiles.tile_sums : nullptr;
     bb.tile_hist_pitch = r->sort_tiles.tiles_cap;
     if ((rc = launch_bin_prefix(bb, stream))) return rc;
+    km_mark(km, "k_bin_prefix");
     if ((rc = launch_bin_emit(bb, stream))) return rc;
+    km_mark(km, "k_bin_emit");
     const uint32_t ntiles = r->tiles_x * r->tiles_y;
     int tile_bits = 8;
     while ((1ull << tile_bits) < ntiles) tile_bits += 8;
     uint32_t *ek = nullptr, *evv = nullptr;
     if ((rc = launch_sort_pairs(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap, 0,
-                                tile_bits, false, fused_hist, r->ctx->sort_algo, r->epoch, stream, &ek, &evv)))
+                                tile_bits, false, fused_hist, r->ctx->sort_algo, r->epoch, stream, &ek, &evv, km,
+                                "tiles:")))
         return rc;
     r->entries_sorted = evv;
     if ((rc = launch_tile_ranges(ek, bb, stream))) return rc;
+    km_mark(km, "k_tile_ranges");
     if (r->timers) {
         WS_HIP(hipEventRecord(r->ev[3], stream));
         r->ev_prepare_valid = true;
@@ -624,9 +668,15 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.out = d_rgba_out;
     bp.pitch = row_pitch_bytes;
     bp.format = (int)r->format;
+    bp.debug_consumed = r->capture ? r->debug_consumed : nullptr;
+    if (bp.debug_consumed)
+        WS_HIP(hipMemsetAsync(r->debug_consumed, 0, (size_t)r->tiles_x * r->tiles_y * sizeof(uint32_t), stream));
+    KernelMarks* km = r->marks.active ? &r->marks : nullptr;
+    if (km) km->begin(stream, false);
     if (r->timers) WS_HIP(hipEventRecord(r->ev[4], stream));
     int rc = launch_blend(bp, r->ctx->blend_variant, stream);
     if (rc) return rc;
+    km_mark(km, "k_blend");
     if (r->timers) {
         WS_HIP(hipEventRecord(r->ev[5], stream));
         r->ev_render_valid = true;
@@ -669,6 +719,41 @@ int ws_renderer_stage_times(ws_renderer* r, ws_stage_times* out) {
         WS_HIP(hipEventSynchronize(r->ev[5]));
         WS_HIP(hipEventElapsedTime(&out->rasterization_ms, r->ev[4], r->ev[5]));
     }
+    return WS_OK;
+}
+
+int ws_renderer_kernel_times(ws_renderer* r, uint32_t capacity, ws_kernel_time* out, uint32_t* count) {
+    if (!r || !count) return fail(WS_ERR_INVALID, "ws_renderer_kernel_times: null argument");
+    if (!r->marks.active) return fail(WS_ERR_STATE, "ws_renderer_kernel_times: needs ws_renderer_enable_timers(r, 2)");
+    const KernelMarks& km = r->marks;
+    *count = (uint32_t)km.n;
+    if (km.n == 0) return WS_OK;
+    WS_HIP(hipEventSynchronize(km.ev[km.n]));
+    for (int i = 0; i < km.n && (uint32_t)i < capacity && out; ++i) {
+        std::memset(&out[i], 0, sizeof out[i]);
+        std::strncpy(out[i].name, km.label[i] ? km.label[i] : "?", sizeof(out[i].name) - 1);
+        WS_HIP(hipEventElapsedTime(&out[i].ms, km.ev[i], km.ev[i + 1]));
+    }
+    return WS_OK;
+}
+
+int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t* list_len, uint32_t* consumed,
+                                    uint32_t* num_tiles) {
+    if (!r) return fail(WS_ERR_INVALID, "ws_renderer_download_tile_stats: null renderer");
+    if (!r->prepared) return fail(WS_ERR_STATE, "ws_renderer_download_tile_stats: no prepared frame");
+    const uint32_t nt = r->tiles_x * r->tiles_y;
+    if (num_tiles) *num_tiles = nt;
+    if (!list_len && !consumed) return WS_OK;
+    if (capacity < nt) return fail(WS_ERR_INVALID, "ws_renderer_download_tile_stats: capacity smaller than the tile count");
+    if (consumed && !r->capture)
+        return fail(WS_ERR_STATE, "ws_renderer_download_tile_stats: consumed needs ws_renderer_enable_capture before render");
+    WS_HIP(hipStreamSynchronize(r->last_stream));
+    if (list_len) {
+        std::vector<uint2> rg(nt);
+        WS_HIP(hipMemcpy(rg.data(), r->tile_ranges, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < nt; ++i) list_len[i] = rg[i].y - rg[i].x;
+    }
+    if (consumed) WS_HIP(hipMemcpy(consumed, r->debug_consumed, (size_t)nt * 4, hipMemcpyDeviceToHost));
     return WS_OK;
 }
 

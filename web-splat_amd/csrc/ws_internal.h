@@ -69,6 +69,26 @@ struct K1Params {
 // planes 2..7 = the 96-B SH record ([[f16;3];16]) in 16-B pieces.
 constexpr int PC_PLANES = 8;
 
+// ---- per-launch GPU timestamps (the reference's GPUStopwatch, utils.rs:26-134, at kernel granularity) --------
+// HIP events recorded on the launch stream between the kernels of one frame; only when the caller asked for
+// per-kernel times (ws_renderer_enable_timers(r, 2)): the events themselves perturb a throughput run.
+struct KernelMarks {
+    static constexpr int MAX = 48;
+    hipEvent_t ev[MAX + 1] = {};
+    const char* label[MAX] = {};
+    int n = 0;
+    bool created = false;
+    bool active = false;
+    hipStream_t stream = nullptr;
+    int create();
+    void destroy();
+    void begin(hipStream_t s, bool restart);
+    void mark(const char* what);
+};
+inline void km_mark(KernelMarks* km, const char* what) {
+    if (km && km->active) km->mark(what);
+}
+
 // ---- sort ---------------------------------------------------------------------------------------
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_KPT = 16;                          // keys per thread
@@ -101,7 +121,8 @@ struct SortScratch {
 // *out_keys / *out_vals receive the final pointers.
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
-                      uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals);
+                      uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals,
+                      KernelMarks* km = nullptr, const char* tag = "");
 
 // ---- preprocess ---------------------------------------------------------------------------------
 struct K1Buffers {
@@ -154,6 +175,7 @@ struct BlendParams {
     void* out;
     size_t pitch;
     int format;
+    uint32_t* debug_consumed;   // nullptr, or [tiles]: entries of each tile's list the blend walked (capture mode)
 };
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
 

@@ -95,6 +95,10 @@ class ws_stage_times(C.Structure):
                 ("rasterization_ms", C.c_float)]
 
 
+class ws_kernel_time(C.Structure):
+    _fields_ = [("name", C.c_char * 40), ("ms", C.c_float)]
+
+
 class ws_frame_stats(C.Structure):
     _fields_ = [("num_visible", C.c_uint32), ("num_tile_entries", C.c_uint32),
                 ("tile_entries_capacity", C.c_uint32), ("overflow", C.c_uint32)]
@@ -151,6 +155,8 @@ SIGNATURES = {
     "ws_renderer_frame_stats": (C.c_int, [_P, C.POINTER(ws_frame_stats)]),
     "ws_renderer_enable_timers": (C.c_int, [_P, C.c_int]),
     "ws_renderer_stage_times": (C.c_int, [_P, C.POINTER(ws_stage_times)]),
+    "ws_renderer_kernel_times": (C.c_int, [_P, C.c_uint32, C.POINTER(ws_kernel_time), _u32p]),
+    "ws_renderer_download_tile_stats": (C.c_int, [_P, C.c_uint32, _P, _P, _u32p]),
     "ws_renderer_enable_capture": (C.c_int, [_P, C.c_int]),
     "ws_renderer_set_tile_entry_capacity": (C.c_int, [_P, C.c_uint64]),
     "ws_renderer_download_frame": (C.c_int, [_P, C.c_uint32, _P, _P, _P, _P, _u32p]),

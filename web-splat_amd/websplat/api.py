@@ -345,7 +345,25 @@ class GaussianRenderer:
         return self.color_format_name
 
     def enable_timers(self, on=True):
+        """0/False = off, 1/True = stage times, 2 = additionally per-kernel times."""
         check(lib.ws_renderer_enable_timers(self.handle, int(on)))
+
+    def kernel_times(self):
+        """[(label, ms)] of every kernel launch of the last frame, launch order (needs enable_timers(2))."""
+        n = C.c_uint32()
+        buf = (L.ws_kernel_time * 64)()
+        check(lib.ws_renderer_kernel_times(self.handle, 64, buf, C.byref(n)))
+        return [(buf[i].name.decode(), buf[i].ms) for i in range(min(n.value, 64))]
+
+    def tile_stats(self, with_consumed=False):
+        nt = C.c_uint32()
+        check(lib.ws_renderer_download_tile_stats(self.handle, 0, None, None, C.byref(nt)))
+        ll = np.empty(nt.value, dtype=np.uint32)
+        cons = np.empty(nt.value, dtype=np.uint32) if with_consumed else None
+        check(lib.ws_renderer_download_tile_stats(
+            self.handle, nt.value, ll.ctypes.data_as(C.c_void_p),
+            cons.ctypes.data_as(C.c_void_p) if cons is not None else None, C.byref(nt)))
+        return {"list_len": ll, "consumed": cons}
 
     def enable_capture(self, on=True):
         check(lib.ws_renderer_enable_capture(self.handle, int(on)))
