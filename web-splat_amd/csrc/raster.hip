@@ -13,7 +13,7 @@
 //   k_bin_emit    : entry-parallel: every workgroup produces exactly EMIT_TILE (tile id, splat) entries, whatever
 //                   the footprint of the splats they come from (LDS binary search over the splat offsets)
 //   (radix sort of the entries by tile id: sort.hip, 2 passes, stable -> depth order kept inside a tile)
-//   k_tile_ranges : [begin,end) of every tile in the sorted entry list
+//   (the last sort pass also records [begin,end) of every tile in the sorted entry list)
 //   k_blend       : 16x16 pixels per workgroup, splats staged through LDS 256 at a time, early-out on T
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
@@ -135,6 +135,14 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
 }
 
 // ---- k_bin_emit: (tile id, splat) entries in draw order, EMIT_TILE entries per workgroup ---------------
+// Every entry needs its owner: the draw position k with off[k] <= e < off[k] + cnt[k].  Measured on MI355X
+// (profiles/): a per-entry binary search over the offsets in LDS is 12 dependent, bank-conflicting LDS reads per
+// entry and made this kernel the most VALU-expensive one after K1.  Here the owners are found for the whole slice
+// at once: every owning position drops its index on its first entry (atomicMax, so that zero-footprint positions,
+// which share an offset with their successor, lose), and an inclusive max-scan spreads it over the entries.
+constexpr int EMIT_COPIES = 2;
+__device__ __forceinline__ uint32_t emit_pad(uint32_t i) { return i + (i >> 4); }  // 16-entry blocks, bank-skewed
+
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __restrict__ sorted_idx,
                                                          const uint2* __restrict__ rects_sorted,
                                                          const uint32_t* __restrict__ offsets,
@@ -144,14 +152,19 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
                                                          const FrameCounters* __restrict__ counters,
                                                          uint32_t tiles_x, uint32_t* __restrict__ tile_hist,
                                                          uint32_t tile_hist_pitch) {
-    constexpr int COPIES = 8;
+    constexpr int EPT = EMIT_TILE / BIN_THREADS;  // 16 entries per thread in the scan
+    static_assert(EPT == 16, "emit_pad() assumes 16-entry blocks");
     __shared__ uint32_t s_off[EMIT_TILE + 2];
-    __shared__ uint32_t s_hist[RADIX * COPIES];
+    __shared__ uint32_t s_own[EMIT_TILE + EMIT_TILE / 16];
+    __shared__ uint32_t s_hist[RADIX * EMIT_COPIES];
+    __shared__ uint32_t s_wmax[BIN_THREADS / 64];
     const uint32_t d = counters->num_entries;
     const uint32_t v = counters->num_visible;
     const uint32_t e0 = blockIdx.x * EMIT_TILE;
     if (e0 >= d) return;
     const uint32_t e1 = (d - e0) < (uint32_t)EMIT_TILE ? d : e0 + EMIT_TILE;
+    const uint32_t ne = e1 - e0;
+    const int tid = threadIdx.x;
     // draw positions [s_lo, s_hi] own the entries [e0, e1)
     const uint32_t s_lo = emit_start[blockIdx.x];
     const uint32_t s_hi = (e1 < d) ? emit_start[blockIdx.x + 1] : (v - 1u);
@@ -160,50 +173,85 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
     // number: normally the offsets fit the LDS window, otherwise the search runs on global memory (rare).
     const uint32_t ns = s_hi - s_lo + 1u;
     const bool in_lds = ns <= (uint32_t)EMIT_TILE + 2u;  // block-uniform
-    if (in_lds)
-        for (uint32_t k = threadIdx.x; k < ns; k += BIN_THREADS) s_off[k] = offsets[s_lo + k];
-    for (int k = threadIdx.x; k < RADIX * COPIES; k += BIN_THREADS) s_hist[k] = 0u;
-    const uint32_t copy = threadIdx.x & (COPIES - 1);
-    __syncthreads();
+    for (int k = tid; k < RADIX * EMIT_COPIES; k += BIN_THREADS) s_hist[k] = 0u;
+    const uint32_t copy = (uint32_t)tid & (EMIT_COPIES - 1);
     const uint32_t* goff = offsets + s_lo;
-    for (uint32_t e = e0 + threadIdx.x; e < e1; e += BIN_THREADS) {
-        // largest k in [0, ns) with off[k] <= e  (zero-footprint positions share their successor's offset and
-        // are skipped by taking the LAST such k)
-        uint32_t lo = 0, hi = ns;
-        while (hi - lo > 1u) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const uint32_t ov = in_lds ? s_off[mid] : goff[mid];
-            if (ov <= e) lo = mid; else hi = mid;
+    if (in_lds) {
+        for (uint32_t k = tid; k < ns; k += BIN_THREADS) s_off[k] = goff[k];
+        for (uint32_t i = tid; i < (uint32_t)(EMIT_TILE + EMIT_TILE / 16); i += BIN_THREADS) s_own[i] = 0u;
+        __syncthreads();
+        for (uint32_t k = tid; k < ns; k += BIN_THREADS) {
+            const uint32_t o = s_off[k];
+            const uint32_t f = o > e0 ? o - e0 : 0u;  // first entry of position k inside the slice
+            if (f < ne) atomicMax(&s_own[emit_pad(f)], k);
+        }
+        __syncthreads();
+        // inclusive max-scan over the slice, 16 consecutive entries per thread
+        uint32_t own[EPT];
+        uint32_t run = 0u;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            run = max(run, s_own[tid * (EPT + 1) + j]);
+            own[j] = run;
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl = max(incl, t);
+        }
+        if (lane == 63) s_wmax[wave] = incl;
+        uint32_t prefix = __shfl_up(incl, 1, 64);
+        if (lane == 0) prefix = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < BIN_THREADS / 64; ++w)
+            if (w < wave) prefix = max(prefix, s_wmax[w]);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) s_own[tid * (EPT + 1) + j] = max(own[j], prefix);
+        __syncthreads();
+    } else {
+        __syncthreads();
+    }
+    for (uint32_t el = tid; el < ne; el += BIN_THREADS) {
+        const uint32_t e = e0 + el;
+        uint32_t lo;
+        if (in_lds) {
+            lo = s_own[emit_pad(el)];
+        } else {
+            // largest k in [0, ns) with off[k] <= e  (zero-footprint positions share their successor's offset and
+            // are skipped by taking the LAST such k)
+            uint32_t hi = ns;
+            lo = 0;
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (goff[mid] <= e) lo = mid; else hi = mid;
+            }
         }
         const uint32_t pos = s_lo + lo;
         const uint2 r = rects_sorted[pos];
         const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu;
         const uint32_t w = x1 - x0 + 1u;
         const uint32_t k = e - (in_lds ? s_off[lo] : goff[lo]);
-        const uint32_t ty = y0 + k / w, tx = x0 + k % w;
-        const uint32_t key = ty * tiles_x + tx;
+        // k / w without the integer-division sequence: k < 2^24 always (a rectangle has at most 2^16 x 2^16 tiles
+        // but the entry capacity is below 2^30 and rows are at most 65535 wide; one correction step covers rounding)
+        uint32_t q = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
+        uint32_t rem = k - q * w;
+        if ((int32_t)rem < 0) { q -= 1u; rem += w; }
+        if (rem >= w) { q += 1u; rem -= w; }
+        if (k >= (1u << 23)) { q = k / w; rem = k % w; }  // exactness of the float path ends at 2^23
+        const uint32_t key = (y0 + q) * tiles_x + (x0 + rem);
         entry_keys[e] = key;
         entry_vals[e] = sorted_idx[pos];
-        atomicAdd(&s_hist[(key & (RADIX - 1)) * COPIES + copy], 1u);
+        atomicAdd(&s_hist[(key & (RADIX - 1)) * EMIT_COPIES + copy], 1u);
     }
     if (tile_hist) {  // digit counts of sort tile blockIdx.x for the tile-id sort's first pass ([digit][tile])
         __syncthreads();
         uint32_t c = 0;
 #pragma unroll
-        for (int r = 0; r < COPIES; ++r) c += s_hist[threadIdx.x * COPIES + r];
-        tile_hist[(size_t)threadIdx.x * tile_hist_pitch + blockIdx.x] = c;
-    }
-}
-
-// ---- k_tile_ranges ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict__ keys, uint2* __restrict__ ranges,
-                                                    const FrameCounters* __restrict__ counters, uint32_t ntiles) {
-    const uint32_t d = counters->num_entries;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < d; i += gridDim.x * 256) {
-        const uint32_t k = keys[i];
-        if (k >= ntiles) continue;  // cannot happen; guards the store
-        if (i == 0 || keys[i - 1] != k) ranges[k].x = i;
-        if (i == d - 1 || keys[i + 1] != k) ranges[k].y = i + 1;
+        for (int r = 0; r < EMIT_COPIES; ++r) c += s_hist[tid * EMIT_COPIES + r];
+        tile_hist[(size_t)tid * tile_hist_pitch + blockIdx.x] = c;
     }
 }
 
@@ -319,7 +367,8 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
     const bool inside = px < p.width && py < p.height;
     const uint32_t qbit = 1u << wave;
 
-    const uint2 range = p.tile_ranges[tile];
+    uint2 range = p.tile_ranges[tile];
+    range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
     // Pixels outside the image start with T = 0: they accumulate nothing and count as saturated.  There is no
     // per-pixel "done" flag in the inner loop: a pixel below T_MIN keeps accumulating (its contributions are
     // below T_MIN, the reference has no cut-off at all); T only decides when a wave / the tile may stop.
@@ -329,7 +378,8 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
     uint32_t* my_list = s_list[wave];
 
     uint32_t hi = range.y;
-    RawSplat raw = blend_fetch_raw(p, range, hi, tid);
+    RawSplat raw = {0u, 0u, 0u, 0u, 0u};
+    if (hi > range.x) raw = blend_fetch_raw(p, range, hi, tid);  // (an empty tile must not touch the entry list)
     while (hi > range.x) {
         const uint32_t nb = (hi - range.x) < 256u ? (hi - range.x) : 256u;
         uint32_t mask = 0u;
@@ -478,7 +528,8 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
     const float qy_lo = (float)(ty * TILE + (q >> 1) * 8u) + 0.5f;
     const float W = (float)p.width, H = (float)p.height;
 
-    const uint2 range = p.tile_ranges[tile];
+    uint2 range = p.tile_ranges[tile];
+    range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
     float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
     bool done = !inside;
 
@@ -594,16 +645,6 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     if (blocks == 0) return WS_OK;
     hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx, b.rects_sorted, b.offsets,
                        b.emit_start, b.entry_keys, b.entry_vals, b.counters, b.tiles_x, b.tile_hist, b.tile_hist_pitch);
-    WS_HIP(hipGetLastError());
-    return WS_OK;
-}
-
-int launch_tile_ranges(const uint32_t* sorted_keys, const BinBuffers& b, hipStream_t stream) {
-    const uint32_t ntiles = b.tiles_x * b.tiles_y;
-    uint32_t blocks = (b.entry_cap + 256 * 8 - 1) / (256 * 8);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_tile_ranges, dim3(blocks), dim3(256), 0, stream, sorted_keys, b.tile_ranges, b.counters, ntiles);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }

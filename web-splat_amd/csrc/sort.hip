@@ -152,7 +152,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* 
 }
 
 // ---- one digit pass: rank, cross-tile prefix (look-back or precomputed), LDS reorder, scatter ----------
-template <bool LOOKBACK, int KPT>
+// RANGES (last pass of the tile-id sort only): the sorted keys themselves are never read again -- what the
+// compositing pass needs is [begin, end) of every key value in the sorted order.  Equal keys of one workgroup are
+// a contiguous run of its LDS-ordered tile, so run boundaries are found there and merged across workgroups with
+// two atomicMax per (workgroup, key) pair on ranges[key] = (0xFFFFFFFF - begin, end), zero = empty.  This
+// replaces a separate pass over the sorted keys and the final 4-B-per-entry key write.
+template <bool LOOKBACK, int KPT, bool RANGES>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ d_count, uint32_t n, int shift, int iota,
@@ -160,7 +165,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     uint64_t* __restrict__ status,         // [tiles][256] epoch-tagged look-back words      (LOOKBACK)
     uint32_t* __restrict__ ticket,         // tile dispenser, zero on entry                  (LOOKBACK)
     const uint32_t* __restrict__ tile_off, // [256][tiles_cap] exclusive offsets per digit   (!LOOKBACK)
-    uint32_t tiles_cap, uint32_t epoch, uint32_t* __restrict__ error_word) {
+    uint32_t tiles_cap, uint32_t epoch, uint32_t* __restrict__ error_word, uint2* __restrict__ ranges,
+    uint32_t nranges) {
     constexpr int TILE_N = SORT_THREADS * KPT;
     __shared__ uint32_t s_wave_hist[WAVES][RADIX];
     __shared__ uint32_t s_local_excl[RADIX];
@@ -304,7 +310,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         const uint32_t kk = s_data[lp];
         const uint32_t d = (kk >> shift) & (RADIX - 1);
         gpos[k] = s_global_base[d] + lp;
-        if (lp < valid) keys_out[gpos[k]] = kk;
+        if (!RANGES) {
+            if (lp < valid) keys_out[gpos[k]] = kk;
+        } else if (lp < valid && kk < nranges) {
+            const uint32_t prev = lp > 0u ? s_data[lp - 1u] : ~kk;
+            const uint32_t next = lp + 1u < valid ? s_data[lp + 1u] : ~kk;
+            if (prev != kk) atomicMax(&ranges[kk].x, 0xFFFFFFFFu - gpos[k]);
+            if (next != kk) atomicMax(&ranges[kk].y, gpos[k] + 1u);
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -321,7 +334,7 @@ template <int KPT>
 int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout,
                     const uint32_t* d_count, uint32_t n, int begin_bit, int npass, bool implicit_iota,
                     bool first_tile_hist_ready, uint32_t epoch, hipStream_t stream, uint32_t** fk, uint32_t** fv,
-                    KernelMarks* km, const char* const* names) {
+                    KernelMarks* km, const char* const* names, uint2* ranges, uint32_t nranges) {
     constexpr uint32_t TILE_N = SORT_THREADS * KPT;
     const uint32_t tiles = (n + TILE_N - 1) / TILE_N;
     for (int p = 0; p < npass; ++p) {
@@ -335,9 +348,15 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
         hipLaunchKernelGGL(k_sort_col_scan, dim3(RADIX), dim3(SORT_THREADS), 0, stream, d_count, n, TILE_N, sc.tile_sums,
                            sc.tiles_cap, sc.hist + p * RADIX);
         km_mark(km, names[1]);
-        hipLaunchKernelGGL((k_sort_scatter<false, KPT>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout,
-                           d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                           sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr);
+        if (ranges && p == npass - 1)
+            hipLaunchKernelGGL((k_sort_scatter<false, KPT, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
+                               kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr,
+                               (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr, ranges, nranges);
+        else
+            hipLaunchKernelGGL((k_sort_scatter<false, KPT, false>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
+                               kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr,
+                               (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr,
+                               (uint2*)nullptr, 0u);
         km_mark(km, names[2]);
         WS_HIP(hipGetLastError());
         uint32_t* tk = kin;
@@ -359,7 +378,7 @@ uint32_t sort_tile_size(uint32_t n) { return n <= SORT_SMALL_MAX ? SORT_THREADS 
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
                       uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km,
-                      const char* tag) {
+                      const char* tag, uint2* ranges, uint32_t nranges) {
     // labels of the per-kernel timers: "<tag>k_sort_..." with tag = "depth:" / "tiles:"
     const bool depth = tag && tag[0] == 'd';
     static const char* const N_DEPTH[4] = {"depth:k_sort_tile_hist", "depth:k_sort_col_scan", "depth:k_sort_scatter",
@@ -385,10 +404,10 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
         int rc;
         if (sort_tile_size(n) == SORT_TILE)
             rc = run_passes_scan<SORT_KPT>(sc, kin, vin, kout, vout, d_count, n, begin_bit, npass, implicit_iota,
-                                           first_tile_hist_ready, epoch, stream, &kin, &vin, km, names);
+                                           first_tile_hist_ready, epoch, stream, &kin, &vin, km, names, ranges, nranges);
         else
             rc = run_passes_scan<SORT_KPT_SMALL>(sc, kin, vin, kout, vout, d_count, n, begin_bit, npass, implicit_iota,
-                                                 first_tile_hist_ready, epoch, stream, &kin, &vin, km, names);
+                                                 first_tile_hist_ready, epoch, stream, &kin, &vin, km, names, ranges, nranges);
         if (rc) return rc;
     } else {
         const uint32_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
@@ -402,10 +421,16 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
         for (int p = 0; p < npass; ++p) {
             const int shift = begin_bit + p * RADIX_BITS;
             const int iota = (implicit_iota && p == 0) ? 1 : 0;
-            hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
-                               kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX,
-                               sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr, 0u,
-                               epoch, sc.error);
+            if (ranges && p == npass - 1)
+                hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
+                                   vin, kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX,
+                                   sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
+                                   0u, epoch, sc.error, ranges, nranges);
+            else
+                hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, false>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
+                                   vin, kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX,
+                                   sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
+                                   0u, epoch, sc.error, (uint2*)nullptr, 0u);
             km_mark(km, names[2]);
             WS_HIP(hipGetLastError());
             uint32_t* tk = kin;

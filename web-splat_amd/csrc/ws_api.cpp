@@ -631,11 +631,9 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     uint32_t *ek = nullptr, *evv = nullptr;
     if ((rc = launch_sort_pairs(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap, 0,
                                 tile_bits, false, fused_hist, r->ctx->sort_algo, r->epoch, stream, &ek, &evv, km,
-                                "tiles:")))
+                                "tiles:", r->tile_ranges, ntiles)))
         return rc;
-    r->entries_sorted = evv;
-    if ((rc = launch_tile_ranges(ek, bb, stream))) return rc;
-    km_mark(km, "k_tile_ranges");
+    r->entries_sorted = evv;  // the last pass wrote the per-tile ranges instead of the sorted tile ids
     if (r->timers) {
         WS_HIP(hipEventRecord(r->ev[3], stream));
         r->ev_prepare_valid = true;
@@ -751,7 +749,7 @@ int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t*
     if (list_len) {
         std::vector<uint2> rg(nt);
         WS_HIP(hipMemcpy(rg.data(), r->tile_ranges, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < nt; ++i) list_len[i] = rg[i].y - rg[i].x;
+        for (uint32_t i = 0; i < nt; ++i) list_len[i] = rg[i].y ? rg[i].y - (0xFFFFFFFFu - rg[i].x) : 0u;
     }
     if (consumed) WS_HIP(hipMemcpy(consumed, r->debug_consumed, (size_t)nt * 4, hipMemcpyDeviceToHost));
     return WS_OK;

@@ -117,12 +117,14 @@ struct SortScratch {
 //   first_tile_hist_ready (algo 0): the producer of the keys already wrote the first pass's per-tile digit
 //     counts into sc.tile_sums (layout [digit][tiles_cap], tile = sort_tile_size(n) consecutive keys).
 //   algo 1 needs sc.hist and sc.tickets zero on entry (the renderer zeroes them with the frame arena).
+//   ranges != nullptr: the LAST pass does not write the sorted keys; instead ranges[key] (key < nranges, zero on
+//     entry) receives (0xFFFFFFFF - begin, end) of that key's run in the sorted order (see k_sort_scatter).
 // The result lands in (keys, vals) if the pass count is even, else in (scratch.keys_alt, vals_alt);
 // *out_keys / *out_vals receive the final pointers.
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
                       uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals,
-                      KernelMarks* km = nullptr, const char* tag = "");
+                      KernelMarks* km = nullptr, const char* tag = "", uint2* ranges = nullptr, uint32_t nranges = 0);
 
 // ---- preprocess ---------------------------------------------------------------------------------
 struct K1Buffers {
@@ -163,13 +165,12 @@ struct BinBuffers {
 };
 int launch_bin_prefix(const BinBuffers& b, hipStream_t stream);
 int launch_bin_emit(const BinBuffers& b, hipStream_t stream);
-int launch_tile_ranges(const uint32_t* sorted_keys, const BinBuffers& b, hipStream_t stream);
 uint32_t bin_prefix_blocks(uint32_t max_points);
 
 struct BlendParams {
     const uint8_t* splats;      // [V] x 20 B
     const uint32_t* entry_vals; // sorted by tile, far -> near inside a tile
-    const uint2* tile_ranges;
+    const uint2* tile_ranges;   // (0xFFFFFFFF - begin, end) per tile, (0, 0) = empty  (written by the tile-id sort)
     uint32_t width, height, tiles_x, tiles_y;
     float background[4];
     void* out;
