@@ -141,7 +141,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
 // at once: every owning position drops its index on its first entry (atomicMax, so that zero-footprint positions,
 // which share an offset with their successor, lose), and an inclusive max-scan spreads it over the entries.
 constexpr int EMIT_COPIES = 2;
-__device__ __forceinline__ uint32_t emit_pad(uint32_t i) { return i + (i >> 4); }  // 16-entry blocks, bank-skewed
+constexpr int EMIT_EPT = EMIT_TILE / BIN_THREADS;  // entries per thread in the scan
+__device__ __forceinline__ uint32_t emit_pad(uint32_t i) { return i + i / EMIT_EPT; }  // per-thread blocks, bank-skewed
 
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __restrict__ sorted_idx,
                                                          const uint2* __restrict__ rects_sorted,
@@ -152,22 +153,22 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
                                                          const FrameCounters* __restrict__ counters,
                                                          uint32_t tiles_x, uint32_t* __restrict__ tile_hist,
                                                          uint32_t tile_hist_pitch) {
-    constexpr int EPT = EMIT_TILE / BIN_THREADS;  // 16 entries per thread in the scan
-    static_assert(EPT == 16, "emit_pad() assumes 16-entry blocks");
+    constexpr int EPT = EMIT_EPT;
     __shared__ uint32_t s_off[EMIT_TILE + 2];
-    __shared__ uint32_t s_own[EMIT_TILE + EMIT_TILE / 16];
+    __shared__ uint32_t s_own[EMIT_TILE + BIN_THREADS];
     __shared__ uint32_t s_hist[RADIX * EMIT_COPIES];
     __shared__ uint32_t s_wmax[BIN_THREADS / 64];
     const uint32_t d = counters->num_entries;
     const uint32_t v = counters->num_visible;
-    const uint32_t e0 = blockIdx.x * EMIT_TILE;
-    if (e0 >= d) return;
+    const int tid = threadIdx.x;
+    // capped grid, workgroups stride over the 4096-entry slices (the host only knows the capacity, not D)
+    for (uint32_t slice = blockIdx.x; (uint64_t)slice * EMIT_TILE < d; slice += gridDim.x) {
+    const uint32_t e0 = slice * EMIT_TILE;
     const uint32_t e1 = (d - e0) < (uint32_t)EMIT_TILE ? d : e0 + EMIT_TILE;
     const uint32_t ne = e1 - e0;
-    const int tid = threadIdx.x;
     // draw positions [s_lo, s_hi] own the entries [e0, e1)
-    const uint32_t s_lo = emit_start[blockIdx.x];
-    const uint32_t s_hi = (e1 < d) ? emit_start[blockIdx.x + 1] : (v - 1u);
+    const uint32_t s_lo = emit_start[slice];
+    const uint32_t s_hi = (e1 < d) ? emit_start[slice + 1] : (v - 1u);
     // Positions that own entries of this slice number at most EMIT_TILE + 1, but visible splats with an EMPTY
     // tile rectangle (centre inside the 1.2x cull bounds, footprint off screen) can sit in between in any
     // number: normally the offsets fit the LDS window, otherwise the search runs on global memory (rare).
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
     const uint32_t* goff = offsets + s_lo;
     if (in_lds) {
         for (uint32_t k = tid; k < ns; k += BIN_THREADS) s_off[k] = goff[k];
-        for (uint32_t i = tid; i < (uint32_t)(EMIT_TILE + EMIT_TILE / 16); i += BIN_THREADS) s_own[i] = 0u;
+        for (uint32_t i = tid; i < (uint32_t)(EMIT_TILE + BIN_THREADS); i += BIN_THREADS) s_own[i] = 0u;
         __syncthreads();
         for (uint32_t k = tid; k < ns; k += BIN_THREADS) {
             const uint32_t o = s_off[k];
@@ -251,7 +252,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
         uint32_t c = 0;
 #pragma unroll
         for (int r = 0; r < EMIT_COPIES; ++r) c += s_hist[tid * EMIT_COPIES + r];
-        tile_hist[(size_t)tid * tile_hist_pitch + blockIdx.x] = c;
+        tile_hist[(size_t)tid * tile_hist_pitch + slice] = c;
+    }
+    __syncthreads();  // LDS is reused by the next slice
     }
 }
 
@@ -641,8 +644,9 @@ int launch_bin_prefix(const BinBuffers& b, hipStream_t stream) {
 }
 
 int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
-    const uint32_t blocks = (b.entry_cap + EMIT_TILE - 1) / EMIT_TILE;
+    uint32_t blocks = (b.entry_cap + EMIT_TILE - 1) / EMIT_TILE;
     if (blocks == 0) return WS_OK;
+    if (blocks > 2048u) blocks = 2048u;  // slices are strided over; surplus workgroups are not free
     hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx, b.rects_sorted, b.offsets,
                        b.emit_start, b.entry_keys, b.entry_vals, b.counters, b.tiles_x, b.tile_hist, b.tile_hist_pitch);
     WS_HIP(hipGetLastError());

@@ -28,6 +28,8 @@
 
 namespace ws {
 
+uint32_t sort_grid(uint32_t tiles);
+
 namespace {
 
 constexpr int WAVES = SORT_THREADS / 64;
@@ -38,6 +40,18 @@ __device__ __forceinline__ uint32_t device_count(const uint32_t* d_count, uint32
     if (!d_count) return n;
     const uint32_t c = *d_count;
     return c < n ? c : n;
+}
+
+// Tile owned by linear work item L (= blockIdx.x + i * gridDim.x, gridDim.x a multiple of 8).  Workgroup b runs on
+// XCD b % 8 (observed; used for speed only), so XCD x gets the CONTIGUOUS tile range [x * tpx, (x + 1) * tpx):
+// the digit runs that neighbouring tiles write are adjacent in memory (a few dozen bytes each), and with both
+// tiles on one XCD the partial cache lines meet in that XCD's L2 instead of being written back separately by
+// two non-coherent L2s.  Returns false when the item has no tile.
+__device__ __forceinline__ bool xcd_tile(uint32_t L, uint32_t ntiles, uint32_t* t) {
+    const uint32_t tpx = (ntiles + 7u) >> 3;
+    const uint32_t j = L >> 3;
+    *t = (L & 7u) * tpx + j;
+    return j < tpx && *t < ntiles;
 }
 
 // exclusive scan of one value per thread over a 256-thread block
@@ -113,22 +127,34 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t*
     constexpr int TILE_N = SORT_THREADS * KPT;
     __shared__ uint32_t sh[RADIX * HIST_COPIES];
     const uint32_t count = device_count(d_count, n);
-    const uint32_t t = blockIdx.x;
-    if ((uint64_t)t * TILE_N >= count) return;
-    for (int i = threadIdx.x; i < RADIX * HIST_COPIES; i += SORT_THREADS) sh[i] = 0u;
-    __syncthreads();
-    const uint32_t base = t * TILE_N;
     const uint32_t copy = threadIdx.x & (HIST_COPIES - 1);
+    // the grid is capped (sort_grid): the host only knows the bound n, and workgroups that find nothing to do
+    // still cost a dispatch slot each -- with n = 4 x count they made this kernel launch-rate bound
+    const uint32_t ntiles = (count + TILE_N - 1) / TILE_N;
+    for (uint32_t L = blockIdx.x; (L >> 3) < ((ntiles + 7u) >> 3); L += gridDim.x) {
+        uint32_t t;
+        if (!xcd_tile(L, ntiles, &t)) continue;  // block-uniform
+        for (int i = threadIdx.x; i < RADIX * HIST_COPIES; i += SORT_THREADS) sh[i] = 0u;
+        __syncthreads();
+        const uint32_t base = t * TILE_N;
+        uint32_t k[KPT];
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-        const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
-        if (pos < count) atomicAdd(&sh[((keys[pos] >> shift) & (RADIX - 1)) * HIST_COPIES + copy], 1u);
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
+            k[j] = keys[pos < count ? pos : count - 1u];
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
+            if (pos < count) atomicAdd(&sh[((k[j] >> shift) & (RADIX - 1)) * HIST_COPIES + copy], 1u);
+        }
+        __syncthreads();
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < HIST_COPIES; ++r) c += sh[threadIdx.x * HIST_COPIES + r];
+        tile_sums[(size_t)threadIdx.x * tiles_cap + t] = c;
+        __syncthreads();
     }
-    __syncthreads();
-    uint32_t c = 0;
-#pragma unroll
-    for (int r = 0; r < HIST_COPIES; ++r) c += sh[threadIdx.x * HIST_COPIES + r];
-    tile_sums[(size_t)threadIdx.x * tiles_cap + t] = c;
 }
 
 // One workgroup per digit: exclusive scan of that digit's row over the tiles (in place), total -> hist[digit].
@@ -171,7 +197,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     __shared__ uint32_t s_wave_hist[WAVES][RADIX];
     __shared__ uint32_t s_local_excl[RADIX];
     __shared__ uint32_t s_global_base[RADIX];
-    __shared__ uint32_t s_data[TILE_N];
+    __shared__ uint32_t s_keys[TILE_N];
+    __shared__ uint32_t s_vals[TILE_N];
     __shared__ uint32_t s_tmp[WAVES];
     __shared__ uint32_t s_tile;
 
@@ -180,14 +207,22 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const int wave = tid >> 6;
 
     const uint32_t count = device_count(d_count, n);
-    // The grid is sized for the host-side bound n; only ceil(count / TILE) workgroups have work.  The surplus
-    // ones leave BEFORE touching the ticket, so exactly the needed number of tickets 0..ntiles-1 is drawn.
-    if ((uint64_t)blockIdx.x * TILE_N >= count) return;  // block-uniform
+    // first output position of every digit: the same for all tiles of this pass
+    const uint32_t digit_base = block_exclusive_scan(hist[tid], s_tmp, nullptr);
+    // Scan path: the grid is capped (sort_grid) and workgroups stride over the tiles.  One-sweep path: the grid is
+    // sized for the host-side bound n, only ceil(count / TILE) workgroups have work; the surplus ones leave BEFORE
+    // touching the ticket, so exactly the needed number of tickets 0..ntiles-1 is drawn, one tile per workgroup.
+    const uint32_t ntiles = (count + TILE_N - 1) / TILE_N;
+    for (uint32_t L = blockIdx.x; LOOKBACK ? ((uint64_t)L * TILE_N < count) : ((L >> 3) < ((ntiles + 7u) >> 3));
+         L += gridDim.x) {
+    uint32_t t;
     if (LOOKBACK) {
         if (tid == 0) s_tile = atomicAdd(ticket, 1u);
         __syncthreads();
+        t = s_tile;
+    } else if (!xcd_tile(L, ntiles, &t)) {
+        continue;  // block-uniform
     }
-    const uint32_t t = LOOKBACK ? s_tile : blockIdx.x;
     const uint32_t tile_base = t * TILE_N;
     const uint32_t valid = (count - tile_base) < (uint32_t)TILE_N ? (count - tile_base) : (uint32_t)TILE_N;
 
@@ -205,12 +240,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         const uint32_t pos = wave_base + j * 64;
         val[j] = iota ? pos : (pos < count ? vals_in[pos] : 0u);
     }
+    uint32_t my_tile_off = 0u;  // issued early: needed only after the ranking
+    if (!LOOKBACK) my_tile_off = tile_off[(size_t)tid * tiles_cap + t];
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) s_wave_hist[w][tid] = 0u;
     __syncthreads();
 
-    // ---- rank inside the wave with ballots; per-wave digit counters live in LDS ---------------------
-    uint32_t rank[KPT];
+    // ---- rank inside the wave.  Phase 1, registers only: 8 ballots per key give the set of lanes holding the same
+    // digit -> number of such lanes below this one, their count, and the lowest of them (the leader).  Phase 2: the
+    // leaders add the counts to the wave's LDS digit counters, ALL keys' atomics issued back to back (one lane per
+    // distinct digit, so no two lanes of an instruction hit the same word; LDS executes a wave's instructions in
+    // order, so key j+1 sees key j: deterministic and stable).  Phase 3: the old counter value travels from the
+    // leader to its group.  Two LDS round trips per tile instead of one dependent read-modify-write per key.
+    uint32_t info[KPT];  // below | leader << 8 | count << 16 (count only on the leader lane, else 0)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
@@ -223,16 +265,20 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             m &= b ? bal : ~bal;
         }
         const uint32_t below = (uint32_t)__popcll(m & lt_mask);
-        const uint32_t cnt = (uint32_t)__popcll(m);
-        const int leader = __ffsll((long long)m) - 1;
-        uint32_t prev = 0u;
-        if (lane == leader) {  // one lane per distinct digit: plain read-modify-write, deterministic
-            prev = s_wave_hist[wave][d];
-            s_wave_hist[wave][d] = prev + cnt;
-        }
-        prev = __shfl(prev, leader, 64);
-        rank[j] = prev + below;
+        const uint32_t leader = (uint32_t)(__ffsll((long long)m) - 1);
+        const uint32_t cnt = (below == 0u) ? (uint32_t)__popcll(m) : 0u;  // below == 0 <=> this lane is the leader
+        info[j] = below | (leader << 8) | (cnt << 16);
     }
+    uint32_t prev[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const uint32_t d = (key[j] >> shift) & (RADIX - 1);
+        prev[j] = 0u;
+        if (info[j] >> 16) prev[j] = atomicAdd(&s_wave_hist[wave][d], info[j] >> 16);
+    }
+    uint32_t rank[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) rank[j] = __shfl(prev[j], (int)((info[j] >> 8) & 63u), 64) + (info[j] & 63u);
     __syncthreads();
 
     // ---- per digit (thread d = digit d): prefix over waves, tile count --------------------------------
@@ -251,7 +297,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         lb::st(my_status, lb::pack(epoch, t == 0 ? lb::FLAG_INCL : lb::FLAG_AGG, pub_cnt));
         const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp, nullptr);
         s_local_excl[tid] = local_excl;
-        const uint32_t digit_base = block_exclusive_scan(hist[tid], s_tmp, nullptr);
         uint32_t prev_sum = 0;
         if (t > 0) {
             int64_t i = (int64_t)t - 1;  // next predecessor to consume
@@ -289,44 +334,40 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     } else {
         const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp, nullptr);
         s_local_excl[tid] = local_excl;
-        const uint32_t digit_base = block_exclusive_scan(hist[tid], s_tmp, nullptr);
-        s_global_base[tid] = digit_base + tile_off[(size_t)tid * tiles_cap + t] - local_excl;
+        s_global_base[tid] = digit_base + my_tile_off - local_excl;
     }
     __syncthreads();
 
-    // ---- reorder keys through LDS, write contiguous digit runs ----------------------------------------
-    uint32_t lpos[KPT];
+    // ---- reorder keys AND values through LDS (one barrier), write contiguous digit runs -------------------
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const uint32_t d = (key[j] >> shift) & (RADIX - 1);
-        lpos[j] = s_local_excl[d] + s_wave_hist[wave][d] + rank[j];
-        s_data[lpos[j]] = key[j];
+        const uint32_t lpos = s_local_excl[d] + s_wave_hist[wave][d] + rank[j];
+        s_keys[lpos] = key[j];
+        s_vals[lpos] = val[j];
     }
     __syncthreads();
-    uint32_t gpos[KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const uint32_t lp = k * SORT_THREADS + tid;
-        const uint32_t kk = s_data[lp];
+        const uint32_t kk = s_keys[lp];
+        const uint32_t vv = s_vals[lp];
         const uint32_t d = (kk >> shift) & (RADIX - 1);
-        gpos[k] = s_global_base[d] + lp;
-        if (!RANGES) {
-            if (lp < valid) keys_out[gpos[k]] = kk;
-        } else if (lp < valid && kk < nranges) {
-            const uint32_t prev = lp > 0u ? s_data[lp - 1u] : ~kk;
-            const uint32_t next = lp + 1u < valid ? s_data[lp + 1u] : ~kk;
-            if (prev != kk) atomicMax(&ranges[kk].x, 0xFFFFFFFFu - gpos[k]);
-            if (next != kk) atomicMax(&ranges[kk].y, gpos[k] + 1u);
+        const uint32_t gpos = s_global_base[d] + lp;
+        if (lp < valid) {
+            vals_out[gpos] = vv;
+            if (!RANGES) {
+                keys_out[gpos] = kk;
+            } else if (kk < nranges) {
+                const uint32_t prev_k = lp > 0u ? s_keys[lp - 1u] : ~kk;
+                const uint32_t next_k = lp + 1u < valid ? s_keys[lp + 1u] : ~kk;
+                if (prev_k != kk) atomicMax(&ranges[kk].x, 0xFFFFFFFFu - gpos);
+                if (next_k != kk) atomicMax(&ranges[kk].y, gpos + 1u);
+            }
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) s_data[lpos[j]] = val[j];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        const uint32_t lp = k * SORT_THREADS + tid;
-        if (lp < valid) vals_out[gpos[k]] = s_data[lp];
+    if (LOOKBACK) break;  // one ticket per workgroup
+    __syncthreads();      // LDS is reused by the next tile
     }
 }
 
@@ -336,7 +377,7 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
                     bool first_tile_hist_ready, uint32_t epoch, hipStream_t stream, uint32_t** fk, uint32_t** fv,
                     KernelMarks* km, const char* const* names, uint2* ranges, uint32_t nranges) {
     constexpr uint32_t TILE_N = SORT_THREADS * KPT;
-    const uint32_t tiles = (n + TILE_N - 1) / TILE_N;
+    const uint32_t tiles = sort_grid((n + TILE_N - 1) / TILE_N);
     for (int p = 0; p < npass; ++p) {
         const int shift = begin_bit + p * RADIX_BITS;
         const int iota = (implicit_iota && p == 0) ? 1 : 0;
@@ -372,6 +413,14 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
 }
 
 }  // namespace
+
+// Grid cap of the tile-strided kernels: 8 workgroups per CU on a 256-CU part; enough to fill the chip at any
+// residency these kernels reach, small enough that surplus workgroups (count << n) cost nothing measurable.
+// A multiple of 8, so that a workgroup stays on its XCD's tile range across iterations (xcd_tile).
+uint32_t sort_grid(uint32_t tiles) {
+    const uint32_t g = ((tiles + 7u) / 8u) * 8u;
+    return g < 2048u ? (g ? g : 8u) : 2048u;
+}
 
 uint32_t sort_tile_size(uint32_t n) { return n <= SORT_SMALL_MAX ? SORT_THREADS * SORT_KPT_SMALL : SORT_TILE; }
 

@@ -91,8 +91,11 @@ inline void km_mark(KernelMarks* km, const char* what) {
 
 // ---- sort ---------------------------------------------------------------------------------------
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_KPT = 16;                          // keys per thread
-constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;    // 4096 keys per work tile
+#ifndef WS_SORT_KPT
+#define WS_SORT_KPT 8
+#endif
+constexpr int SORT_KPT = WS_SORT_KPT;                 // keys per thread
+constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;    // keys per work tile
 constexpr int SORT_KPT_SMALL = 4;                     // small inputs: 1024-key tiles -> 4x the workgroups
 constexpr uint32_t SORT_SMALL_MAX = 2u << 20;         // host-side bound n up to which the small tile is used
 uint32_t sort_tile_size(uint32_t n);                  // tile size the scan path (algo 0) uses for bound n
@@ -143,7 +146,7 @@ int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, hi
 uint32_t preprocess_blocks(uint32_t n);
 
 // ---- binning + blend ----------------------------------------------------------------------------
-constexpr int EMIT_TILE = 4096;  // tile entries produced per workgroup of the emit kernel
+constexpr int EMIT_TILE = SORT_TILE;  // tile entries produced per workgroup of the emit kernel (= the sort's tile)
 
 struct BinBuffers {
     const uint32_t* sorted_idx;  // [V] store indices in draw order (far -> near)

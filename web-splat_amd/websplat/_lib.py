@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libwebsplat_hip.so")
+# WEBSPLAT_LIB selects another build of the SAME library (kernel tuning A/B runs); there is still no fallback.
+LIB_PATH = os.environ.get("WEBSPLAT_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libwebsplat_hip.so")
 
 
 class WebSplatError(RuntimeError):
