@@ -6,9 +6,12 @@
 
 A "step" is one frame = one pass of the hot path (K1 preprocess -> depth radix sort -> tile binning ->
 tile blend) over one camera view of the synthetic scene, inputs resident in HBM, output left in HBM.
-Procedure = the reference's bin/measure.rs:98-153: frames are enqueued back-to-back on one stream with a
-single sync at the end (throughput, not latency).  The scene is replicated on every GPU and views are
-sharded view i -> rank i mod N (no data-path collective; "scaling": "weak": every rank renders K frames).
+Procedure = the reference's bin/measure.rs:98-153: frames are enqueued back-to-back with a single sync at the
+end (throughput, not latency).  The views of a batch are independent, so `--streams` frames (default 4) are in
+flight per GPU, each on its own HIP stream with its own renderer scratch and target, sharing the resident scene;
+the one-frame-at-a-time rate is reported beside it (config.single_stream_fps).  The scene is replicated on every
+GPU and views are sharded view i -> rank i mod N (no data-path collective; "scaling": "weak": every rank
+renders K frames).
 
 Workloads (BASELINE.json configs):
   c2  (default) bonsai-like synthetic, 1.2 M Gaussians, 1200x799 -- configs[1]; the real bonsai .ply is not
@@ -87,8 +90,9 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--views", type=int, default=64)
     ap.add_argument("--format", default="rgba32float")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("WS_BENCH_STREAMS", "1")),
-                    help="frames in flight per GPU: one renderer (private scratch) + one HIP stream each")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("WS_BENCH_STREAMS", "4")),
+                    help="frames in flight per GPU: one renderer (private scratch) + one HIP stream each "
+                         "(the views of a batch are independent; 1 = strictly one frame at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -148,57 +152,101 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # RCCL: the only collective, off the data path
         elapsed = float(t.item())
 
-    # ---- per-stage kernel time (HIP events on the launch stream) for the roofline block, rank 0 only ----
+    # ---- rank 0: single-stream rate, then per-kernel time (HIP events on the launch stream) for the roofline ----
     out = None
     if rank == 0:
         torch.cuda.synchronize()
-        nstreams = 1  # stage timing: one frame at a time on renderer 0
-        r.enable_timers(True)
-        acc = {"preprocess": 0.0, "sorting": 0.0, "binning": 0.0, "rasterization": 0.0}
-        stat_acc = {"num_visible": 0, "num_tile_entries": 0}
+        inflight = nstreams
+        nstreams = 1  # from here on: one frame at a time on renderer 0 / stream 0
+        ks = max(20, a.steps // 2)
+        for i in range(5):
+            frame(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(ks):
+            frame(i)
+        torch.cuda.synchronize()
+        single_stream_fps = ks / (time.perf_counter() - t1)
+
+        r.enable_timers(2)  # HIP event pairs around every kernel launch, on the launch stream
         reps = min(len(my_views), 16)
+        per_kernel = {}      # label -> [total ms over reps, launches over reps]
+        stage_acc = {"preprocess": 0.0, "sorting": 0.0, "binning": 0.0, "rasterization": 0.0}
+        stat_acc = {"num_visible": 0, "num_tile_entries": 0}
+        frame(0)
+        r.kernel_times()
         for i in range(reps):
             frame(i)
+            for label, ms in r.kernel_times():
+                e = per_kernel.setdefault(label, [0.0, 0])
+                e[0] += ms
+                e[1] += 1
             st = r.stage_times()
             fs = r.frame_stats()
-            for k in acc:
-                acc[k] += st[k] / reps
+            for k in stage_acc:
+                stage_acc[k] += st[k] / reps
             for k in stat_acc:
                 stat_acc[k] += fs[k] / reps
         overflow = r.frame_stats()["overflow"]
+        r.enable_timers(0)
         n = gpc.num_points
         V, D = stat_acc["num_visible"], stat_acc["num_tile_entries"]
-        # algorithmic bytes per launch (DESIGN.md "Roofline accounting")
-        bytes_k1 = n * 124 + V * 28
-        bytes_sort = 68 * V
-        bytes_blend = D * 24 + w * h * 16
-        stages = {
-            "preprocess": {"ms": acc["preprocess"], "alg_bytes": bytes_k1},
-            "sorting": {"ms": acc["sorting"], "alg_bytes": bytes_sort},
-            "binning": {"ms": acc["binning"], "alg_bytes": V * 20 + D * 8 + 2 * (4 * D + 2 * 16 * D)},
-            "rasterization": {"ms": acc["rasterization"], "alg_bytes": bytes_blend},
+        tile_bits = 8
+        while (1 << tile_bits) < ((w + 15) // 16) * ((h + 15) // 16):
+            tile_bits += 8
+        tile_passes = tile_bits // 8
+        # ALGORITHMIC bytes per launch (DESIGN.md "Roofline accounting"): N Gaussians, V visible,
+        # D (tile, splat) entries.  A radix pass over M pairs reads and writes 8 B per pair: 16*M; the histogram
+        # kernels read 4*M; the last tile-id pass does not write the keys (12*D).
+        alg = {
+            "k_preprocess": n * 124 + V * 28,
+            "depth:k_sort_tile_hist": 4 * V, "depth:k_sort_col_scan": None, "depth:k_sort_scatter": 16 * V,
+            "depth:k_sort_hist": 4 * V,
+            "k_bin_prefix": V * (4 + 8) + V * (8 + 4),
+            "k_bin_emit": V * 12 + D * 8,
+            "tiles:k_sort_tile_hist": 4 * D, "tiles:k_sort_col_scan": None, "tiles:k_sort_hist": 4 * D,
+            "tiles:k_sort_scatter": (16 * D * (tile_passes - 1) + 12 * D) / tile_passes,
+            "k_blend": D * 24 + w * h * 16,
         }
-        for s in stages.values():
-            s["GBps"] = (s["alg_bytes"] / (s["ms"] * 1e-3) / 1e9) if s["ms"] > 0 else 0.0
-            s["frac_hbm_peak"] = s["GBps"] / HBM_PEAK_GBS
-        dominant = max(stages, key=lambda k: stages[k]["ms"])
-        # K1 ("preprocess") is a single kernel launch, so its event time IS the kernel's duration; it is the
-        # HBM-streaming kernel the metric names ("achieved HBM GB/s for the sort and projection passes")
-        k1 = stages["preprocess"]
-        roofline = {"kernel": "k_preprocess<false>", "bound": "hbm", "achieved": k1["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": k1["frac_hbm_peak"], "traffic": None,
-                    "alg_bytes_per_launch": bytes_k1, "avg_launch_ms": k1["ms"],
-                    "dominant_stage_by_time": dominant}
+        kernels = {}
+        for label, (tot, cnt) in per_kernel.items():
+            launches = cnt / reps
+            avg_ms = tot / cnt
+            ab = alg.get(label)
+            kernels[label] = {"launches_per_frame": launches, "avg_launch_ms": avg_ms, "ms_per_frame": tot / reps,
+                              "alg_bytes_per_launch": ab,
+                              "GBps": (ab / (avg_ms * 1e-3) / 1e9) if ab else None}
+        # dominant kernel = the launch label with the most GPU time per frame (the same kernel symbols rocprofv3
+        # --stats lists: the depth sort and the tile-id sort instantiate k_sort_scatter with different tile sizes)
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_frame"])
+        dk = kernels[dom]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{a.workload}.json")
+        if os.path.exists(tpath):  # PMC pass of the same command (scripts/pmc_traffic.sh), bytes per launch
+            traffic = json.load(open(tpath)).get(dom)
+        bound = "hbm"
+        roofline = {"kernel": dom, "bound": bound, "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (dk["GBps"] / HBM_PEAK_GBS) if dk["GBps"] else None, "traffic": traffic,
+                    "alg_bytes_per_launch": dk["alg_bytes_per_launch"], "avg_launch_ms": dk["avg_launch_ms"],
+                    "launches_per_frame": dk["launches_per_frame"],
+                    "limited_by": "valu" if dom == "k_blend" else "hbm",
+                    "note": "dominant = most GPU time per frame summed over its launches; HIP events around every "
+                            "launch on the launch stream, one frame in flight.  No stage is a dense contraction, so "
+                            "MFMA is unused and every kernel is priced against HBM; k_blend is bound by VALU issue "
+                            "(DESIGN.md 3.3) and early-out makes its real traffic a fraction of the algorithmic bytes"}
+        stages = {k: {"ms": v} for k, v in stage_acc.items()}
         fps = world * a.steps / elapsed
         out = {
             "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {n} Gaussians (sh_deg 3), {w}x{h}, {a.format} target, "
-                                   f"{len(views)} orbit views sharded view i -> rank i mod N, {a.streams} frame(s) in flight per GPU",
-                       "gaussians": n, "width": w, "height": h, "views": len(views), "streams": a.streams,
-                       "avg_visible": V, "avg_tile_entries": D, "overflow": overflow},
+                                   f"{len(views)} orbit views sharded view i -> rank i mod N, {inflight} frame(s) in flight per GPU",
+                       "gaussians": n, "width": w, "height": h, "views": len(views), "frames_in_flight": inflight,
+                       "avg_visible": V, "avg_tile_entries": D, "overflow": overflow,
+                       "single_stream_fps": single_stream_fps},
             "roofline": roofline,
+            "kernels": kernels,
             "stages": stages,
         }
         if not a.no_cpu_baseline and world == 1:

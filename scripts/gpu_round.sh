@@ -1,33 +1,36 @@
 #!/bin/bash
-# One scripted GPU batch (run through gpurun): tests -> smoke -> bench -> rocprofv3.  Everything lands in gpurun_out/.
+# One scripted GPU batch (run through gpurun): tests -> smoke -> PMC traffic -> bench -> rocprofv3 stats.
+# Everything lands in gpurun_out/; copy what should be judged into profiles/.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-STEPS=${STEPS:-200}
+STEPS=${STEPS:-400}
 WORKLOAD=${WORKLOAD:-c2}
-WHAT=${WHAT:-tests,smoke,bench,prof}
+WHAT=${WHAT:-tests,smoke,traffic,bench,prof}
+rm -f $OUT/summary.txt
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9|Compute Unit" | head -6 > $OUT/device.txt
 nproc >> $OUT/device.txt
 if [[ $WHAT == *tests* ]]; then
-  for f in tests/test_gpu_sort.py tests/test_gpu_preprocess.py tests/test_gpu_render.py; do
-    timeout 600 python -m pytest $f -m gpu -q --timeout 300 -p no:cacheprovider 2>&1 | tail -60 > $OUT/$(basename $f .py).log
-    echo "$f exit=$?" >> $OUT/summary.txt
-    tail -3 $OUT/$(basename $f .py).log >> $OUT/summary.txt
-  done
+  timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider 2>&1 | tail -30 > $OUT/tests_gpu.log
+  echo "tests exit=$?" >> $OUT/summary.txt; tail -2 $OUT/tests_gpu.log >> $OUT/summary.txt
 fi
 if [[ $WHAT == *smoke* ]]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit=$?" >> $OUT/summary.txt
+fi
+if [[ $WHAT == *traffic* ]]; then
+  bash scripts/pmc_traffic.sh $WORKLOAD > $OUT/traffic.log 2>&1; echo "traffic exit=$?" >> $OUT/summary.txt
+  mkdir -p profiles; cp $OUT/traffic_$WORKLOAD.json profiles/traffic_$WORKLOAD.json 2>/dev/null  # bench.py reads it
 fi
 if [[ $WHAT == *bench* ]]; then
   timeout 900 python bench.py --steps $STEPS --warmup 20 --workload $WORKLOAD > $OUT/bench_$WORKLOAD.json 2> $OUT/bench_$WORKLOAD.err; echo "bench exit=$?" >> $OUT/summary.txt
 fi
 if [[ $WHAT == *prof* ]]; then
   rm -rf $OUT/prof_$WORKLOAD
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$WORKLOAD -o prof -- python bench.py --steps 50 --warmup 5 --workload $WORKLOAD --no-cpu-baseline > $OUT/prof_$WORKLOAD.log 2>&1; echo "prof exit=$?" >> $OUT/summary.txt
-  find $OUT/prof_$WORKLOAD -name "*kernel_stats*" | head -3 >> $OUT/summary.txt
-  # keep the traces small: drop the per-dispatch trace, keep the stats
-  find $OUT/prof_$WORKLOAD -name "*kernel_trace*" -size +20M -delete
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$WORKLOAD -o prof -- python bench.py --steps 50 --warmup 5 --streams 1 --workload $WORKLOAD --no-cpu-baseline > $OUT/prof_$WORKLOAD.log 2>&1; echo "prof exit=$?" >> $OUT/summary.txt
+  python scripts/frame_timeline.py $OUT/prof_$WORKLOAD/prof_kernel_trace.csv > $OUT/prof_${WORKLOAD}_timeline.txt 2>&1
+  # keep the merge small: drop the per-dispatch trace, keep the stats
+  find $OUT/prof_$WORKLOAD -name "*kernel_trace*" -size +8M -delete
 fi
 cat $OUT/summary.txt

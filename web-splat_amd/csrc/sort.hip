@@ -253,21 +253,28 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     // order, so key j+1 sees key j: deterministic and stable).  Phase 3: the old counter value travels from the
     // leader to its group.  Two LDS round trips per tile instead of one dependent read-modify-write per key.
     uint32_t info[KPT];  // below | leader << 8 | count << 16 (count only on the leader lane, else 0)
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // The match works on the two 32-bit halves of the ballot directly: per digit bit one compare (the ballot, an
+    // SGPR pair that is consumed at once), one sign-extended bit extract and two xnor/and pairs.  The scheduling
+    // barrier after each key keeps the compiler from hoisting all 8 x KPT ballots first: 128 live SGPRs do not
+    // exist, and the resulting v_writelane/v_readlane spill code was a fifth of this kernel's VALU time (profiles/).
+    const uint32_t lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xFFFFFFFFu;
+    const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const uint32_t d = (key[j] >> shift) & (RADIX - 1);
-        unsigned long long m = ~0ull;
+        uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
 #pragma unroll
         for (int bit = 0; bit < RADIX_BITS; ++bit) {
-            const bool b = (d >> bit) & 1u;
-            const unsigned long long bal = __ballot(b);
-            m &= b ? bal : ~bal;
+            const uint32_t B = (uint32_t)(-(int32_t)((d >> bit) & 1u));  // all ones if the bit is set
+            const unsigned long long bal = __ballot(B != 0u);
+            mlo &= ~((uint32_t)bal ^ B);
+            mhi &= ~((uint32_t)(bal >> 32) ^ B);
         }
-        const uint32_t below = (uint32_t)__popcll(m & lt_mask);
-        const uint32_t leader = (uint32_t)(__ffsll((long long)m) - 1);
-        const uint32_t cnt = (below == 0u) ? (uint32_t)__popcll(m) : 0u;  // below == 0 <=> this lane is the leader
+        const uint32_t below = (uint32_t)__popc(mlo & lt_lo) + (uint32_t)__popc(mhi & lt_hi);
+        const uint32_t leader = mlo ? (uint32_t)(__ffs((int)mlo) - 1) : 32u + (uint32_t)(__ffs((int)mhi) - 1);
+        const uint32_t cnt = (below == 0u) ? (uint32_t)(__popc(mlo) + __popc(mhi)) : 0u;  // below == 0 <=> leader
         info[j] = below | (leader << 8) | (cnt << 16);
+        __builtin_amdgcn_sched_barrier(0);
     }
     uint32_t prev[KPT];
 #pragma unroll
