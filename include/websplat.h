@@ -206,6 +206,33 @@ int ws_pointcloud_stats(const void* gaussians, uint32_t n, uint32_t stride, cons
 /* io/mod.rs:45-61 GenericGaussianPointCloud::load for a binary PLY file, then PointCloud::new */
 int ws_pointcloud_load_ply(ws_context* ctx, const char* path, ws_pointcloud** out);
 
+/* io/npz.rs:59-225 NpzReader::read: a c3dgs .npz decoded into the loader's byte blobs (HOST memory, owned by the
+ * returned object): GaussianCompressed 24 B x N, packed int8 SH records 3*(sh_deg+1)^2 B, Covariance3D 12 B x M,
+ * the 64-B quantisation block and the optional scalars.  No GPU needed. */
+typedef struct ws_npz_cloud {
+    uint32_t num_points;
+    uint32_t sh_deg;
+    const void* gaussians;
+    size_t gaussians_bytes;
+    const void* sh_coefs;
+    size_t sh_coefs_bytes;
+    const void* covars;
+    size_t covars_bytes;
+    ws_gaussian_quantization quantization;
+    int32_t has_kernel_size;
+    float kernel_size;
+    int32_t has_mip_splatting;
+    int32_t mip_splatting;
+    int32_t has_background_color;
+    float background_color[3];
+} ws_npz_cloud;
+int ws_npz_read(const char* path, ws_npz_cloud** out);
+void ws_npz_free(ws_npz_cloud* pc);
+/* NpzReader::read + GenericGaussianPointCloud::new_compressed (io/mod.rs:107-150) + PointCloud::new */
+int ws_pointcloud_load_npz(ws_context* ctx, const char* path, ws_pointcloud** out);
+/* io/mod.rs:45-61 GenericGaussianPointCloud::load: reader chosen by magic bytes ("ply" / "PK\3\4") */
+int ws_pointcloud_load(ws_context* ctx, const char* path, ws_pointcloud** out);
+
 /* ---- PointCloud: pointcloud.rs:99-222, 336-349 ------------------------------------------------ */
 int ws_pointcloud_create(ws_context* ctx, const ws_pointcloud_desc* desc, ws_pointcloud** out);
 void ws_pointcloud_destroy(ws_pointcloud* pc);
@@ -255,6 +282,57 @@ int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, 
  * how many of its entries the compositing pass walked before every pixel was saturated.  Syncs. */
 int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t* list_len, uint32_t* consumed,
                                     uint32_t* num_tiles);
+
+/* ---- Scene: scene.rs:13-24, 113-194 (host only) ----------------------------------------------------- */
+#define WS_SPLIT_ALL (-1)
+#define WS_SPLIT_TRAIN 0 /* scene.rs:63-67 Split::Train */
+#define WS_SPLIT_TEST 1  /* Split::Test: every 8th camera of the file (scene.rs:143-151) */
+typedef struct ws_scene ws_scene; /* scene.rs:113-118 Scene */
+/* scene.rs:13-24 SceneCamera; rotation = the 3 rows of cameras.json's 3x3 (camera-to-world) */
+typedef struct ws_scene_camera {
+    uint32_t id;
+    char img_name[128];
+    uint32_t width, height;
+    float position[3];
+    float rotation[9];
+    float fx, fy;
+    int32_t split;
+} ws_scene_camera;
+int ws_scene_load_json(const char* path, ws_scene** out);                        /* Scene::from_json */
+int ws_scene_from_json_text(const char* text, size_t len, ws_scene** out);
+void ws_scene_destroy(ws_scene* s);
+uint32_t ws_scene_num_cameras(const ws_scene* s);
+float ws_scene_extend(const ws_scene* s);                                        /* max camera-to-camera distance */
+/* Scene::cameras(split), sorted by id; returns the number of matching cameras, fills at most `capacity` */
+uint32_t ws_scene_cameras(const ws_scene* s, int split, uint32_t capacity, ws_scene_camera* out);
+int ws_scene_get_camera(const ws_scene* s, uint32_t id, ws_scene_camera* out);   /* Scene::camera; 1 if Some */
+int ws_scene_nearest_camera(const ws_scene* s, const float pos[3], int split, uint32_t* id); /* 1 if Some */
+
+/* ---- offline front-ends: bin/render.rs, bin/measure.rs, renderer.rs:417-583 Display ------------------- */
+/* bin/render.rs:187-246 download_texture: device image (format of the renderer) -> host RGBA8, each channel
+ * clamp(v, 0, 1) * 255 TRUNCATED (`as u8`); unorm8 images are copied. out = width*height*4 bytes. Syncs. */
+int ws_download_texture_rgba8(ws_context* ctx, const void* d_image, ws_color_format format, uint32_t width,
+                              uint32_t height, size_t row_pitch_bytes, uint8_t* out, void* stream);
+/* `image` crate save (bin/render.rs:127): RGBA8 PNG */
+int ws_png_write_rgba8(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba, size_t row_stride_bytes);
+/* bin/render.rs:33-128 render_views: every camera of `split` (sorted by id) at its own resolution capped to 1600 px
+ * wide (height rescaled with truncation), Rgba16Float target cleared to TRANSPARENT, fit_near_far, walltime 100 s,
+ * max_sh_deg = pc.sh_deg  ->  <out_dir>/<train|test>/<index:05>.png.  *rendered = images written. */
+int ws_render_views(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, int split, const char* out_dir,
+                    uint32_t* rendered);
+/* bin/measure.rs:27-154 render_views: 2048x2048 Rgba8Unorm target, one warm-up frame of camera 0, then num_samples
+ * (reference: 10) frames of every TRAIN camera back to back, one sync; *fps = 1 / (elapsed / (cameras*num_samples))
+ * with the clock started BEFORE the warm-up frame, as the reference does.  frames_in_flight > 1 (not in the
+ * reference) gives every in-flight frame its own renderer scratch, target and HIP stream. */
+int ws_measure(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, uint32_t num_samples,
+               uint32_t frames_in_flight, float* fps);
+/* Display::render (renderer.rs:548-582) + display.wgsl:37-55: the splat image (premultiplied RGBA, renderer
+ * format) composited with PREMULTIPLIED_ALPHA_BLENDING over a surface cleared to `background`, written as 8-bit
+ * unorm in the surface's channel order (lib.rs:184-243 picks the surface format and strips the sRGB suffix). */
+typedef enum ws_surface_format { WS_SURFACE_RGBA8_UNORM = 0, WS_SURFACE_BGRA8_UNORM = 1 } ws_surface_format;
+int ws_display_composite(ws_context* ctx, const void* d_src, ws_color_format src_format, size_t src_pitch_bytes,
+                         uint32_t width, uint32_t height, const float background[4], ws_surface_format dst_format,
+                         void* d_dst, size_t dst_pitch_bytes, void* stream);
 
 /* ---- GPURSSorter: gpu_rs.rs:65-175, 720-727, 865-884 ------------------------------------------ */
 /* GPURSSorter::new + create_sort_stuff(device, max_n): scratch for sorting up to max_n pairs */

@@ -341,11 +341,13 @@ float wso_sigmoid(float x) {
 void wso_build_cov(const float q[4], const float scale[3], float out[6]) {
     float r[9], l[9], m[9];
     wso_quat_to_mat3(q, r);
-    /* r * s with s diagonal: column k scaled by scale[k] (sum over k of r[k]*s[c][k], other terms are *0) */
+    /* r * s with s = from_diagonal(scale): cgmath Matrix3 * Matrix3 = row(rr).dot(column c of s), and
+     * Vector3::dot = x*x' + y*y' + z*z' (no leading zero: the *0 terms decide the SIGN of an exact zero) */
     for (int c = 0; c < 3; c++)
         for (int rr = 0; rr < 3; rr++) {
-            float s = 0.0f;
-            for (int k = 0; k < 3; k++) s += M3(r, k, rr) * (k == c ? scale[c] : 0.0f);
+            float s = M3(r, 0, rr) * (0 == c ? scale[c] : 0.0f);
+            s += M3(r, 1, rr) * (1 == c ? scale[c] : 0.0f);
+            s += M3(r, 2, rr) * (2 == c ? scale[c] : 0.0f);
             M3(l, c, rr) = s;
         }
     /* m = l * l^T : m[c][r] = sum_k l[k][r] * lT[c][k] = sum_k l[k][r] * l[k][c] */

@@ -1,0 +1,171 @@
+"""CPU tests of the callers' side of the hot path: c3dgs .npz reader, cameras.json scenes, PNG
+write-out -- the library's native host code against the numpy oracle (oracle/ws_oracle_io.py) on generated files."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from websplat import synth
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import ws_oracle_io as oio  # noqa: E402
+
+
+def _quant_tuple(q):
+    return {n: (getattr(q, n).zero_point, np.float32(getattr(q, n).scale)) for n in ("color_dc", "color_rest", "opacity", "scaling_factor")}
+
+
+@pytest.mark.parametrize("compressed,with_sf,with_idx,sh_deg", [(True, True, True, 3), (False, True, True, 2),
+                                                                (True, False, False, 1), (True, True, False, 0)])
+def test_npz_reader_matches_oracle(ws, tmp_path, compressed, with_sf, with_idx, sh_deg):
+    """io/npz.rs:59-225: DEFLATE and stored members, with and without the scaling-factor / codebook-index arrays."""
+    a = synth.c3dgs_arrays(n=20_000, n_geometry=500, n_sh=333, seed=11 + sh_deg, sh_deg=sh_deg,
+                           with_scaling_factor=with_sf, with_indices=with_idx)
+    path = str(tmp_path / "scene.npz")
+    synth.write_npz(path, a, compressed=compressed, kernel_size=np.array(0.1, dtype=np.float32),
+                    mip_splatting=np.array(True), background_color=np.array([0.1, 0.2, 0.3], dtype=np.float32))
+    got = ws.read_npz(path)
+    ref = oio.npz_decode(path)
+    assert got.compressed and got.num_points == ref["num_points"] == 20_000 and got.sh_deg == ref["sh_deg"] == sh_deg
+    assert np.array_equal(got.gaussians, ref["gaussians"])          # GaussianCompressed records, byte-exact
+    assert np.array_equal(got.sh_coefs, ref["sh"])                  # packed int8 SH records
+    gc, rc = got.covars.view(np.uint16), ref["covars"].view(np.uint16)
+    if with_sf:
+        assert np.array_equal(gc, rc)                               # no libm call on this path: bit-exact f16
+    else:
+        # exp() comes from glibc on one side and numpy's SIMD kernel on the other (1 f32 ulp apart at most); the
+        # off-diagonal terms cancel, so the bound is one f16 ulp of the LARGEST element of the matrix
+        gf, rf = got.covars.view(np.float16).astype(np.float64), ref["covars"].view(np.float16).astype(np.float64)
+        tol = np.abs(rf).max(axis=1, keepdims=True) * 2.0 ** -10
+        assert (np.abs(gf - rf) <= tol).all() and (gc == rc).mean() > 0.99
+    gq = _quant_tuple(got.quantization)
+    for name, (zp, sc) in ref["quant"].items():
+        assert gq[name][0] == zp and gq[name][1] == np.float32(sc), name
+    assert got.kernel_size == pytest.approx(0.1) and got.mip_splatting is True
+    assert np.allclose(got.background_color, [0.1, 0.2, 0.3])
+    # new_compressed (io/mod.rs:107-150): bbox grown from the unit cube
+    assert all(lo <= -1.0 for lo in got.aabb.min) and all(hi >= 1.0 for hi in got.aabb.max)
+
+
+def test_npz_reader_scalar_dtypes_and_optionals(ws, tmp_path):
+    """python floats / ints saved through np.savez arrive as float64 / int64; optional scalars may be absent."""
+    a = synth.c3dgs_arrays(n=1000, n_geometry=50, n_sh=40, seed=5, sh_deg=1)
+    a["opacity_scale"] = np.array(0.5)            # float64
+    a["features_dc_zero_point"] = np.array(7)     # int64
+    path = str(tmp_path / "s.npz")
+    synth.write_npz(path, a, compressed=False)
+    got = ws.read_npz(path)
+    assert got.quantization.opacity.scale == 0.5 and got.quantization.color_dc.zero_point == 7
+    assert got.kernel_size is None and got.mip_splatting is None and got.background_color is None
+
+
+def test_npz_reader_errors(ws, tmp_path):
+    a = synth.c3dgs_arrays(n=500, n_geometry=20, n_sh=20, seed=1, sh_deg=1)
+    del a["rotation"]
+    p1 = str(tmp_path / "missing.npz")
+    synth.write_npz(p1, a)
+    with pytest.raises(ws.WebSplatError, match="rotation missing"):
+        ws.read_npz(p1)
+    p2 = str(tmp_path / "garbage.npz")
+    open(p2, "wb").write(b"PK\x03\x04" + b"\x00" * 100)
+    with pytest.raises(ws.WebSplatError):
+        ws.read_npz(p2)
+    a = synth.c3dgs_arrays(n=500, n_geometry=20, n_sh=20, seed=1, sh_deg=1)
+    p3 = str(tmp_path / "ok.npz")
+    synth.write_npz(p3, a)
+    raw = open(p3, "rb").read()
+    p4 = str(tmp_path / "corrupt.npz")
+    bad = bytearray(raw)
+    bad[1000] ^= 0xFF  # inside the DEFLATE stream of xyz.npy: inflate or the CRC-32 must notice
+    open(p4, "wb").write(bytes(bad))
+    with pytest.raises(ws.WebSplatError):
+        ws.read_npz(p4)
+    with pytest.raises(ws.WebSplatError, match="cannot open"):
+        ws.read_npz(str(tmp_path / "nope.npz"))
+
+
+def _cams_json(n=19, seed=3):
+    rng = np.random.default_rng(seed)
+    cams = [c.to_json() for c in synth.orbit_cameras(n, 640, 480, 500.0, 510.0)]
+    ids = rng.permutation(n) * 3 + 1                    # ids are neither dense nor in file order
+    for c, i in zip(cams, ids):
+        c["id"] = int(i)
+        c["img_name"] = f"img_{int(i):04d}"
+    cams[5]["id"] = cams[2]["id"]                       # duplicate id: the later entry wins (scene.rs:126-133)
+    cams[5]["width"] = 999
+    return json.dumps(cams)
+
+
+def test_scene_from_json_matches_oracle(ws):
+    """scene.rs:113-194: split by FILE position (every 8th = test), cameras() sorted by id, extend, nearest_camera."""
+    text = _cams_json()
+    sc = ws.Scene.from_json_text(text)
+    ref = oio.scene_from_json(text)
+    try:
+        assert sc.num_cameras() == len(ref["cameras"]) == 18
+        assert np.float32(sc.extend()) == ref["extend"]
+        for split in (None, "train", "test"):
+            got, want = sc.cameras(split), oio.scene_cameras(ref, split)
+            assert [c.id for c in got] == [c["id"] for c in want]
+            assert [c.split for c in got] == [c["split"] for c in want]
+            for g, w in zip(got, want):
+                assert (g.img_name, g.width, g.height) == (w["img_name"], w["width"], w["height"])
+                assert np.array_equal(np.float32(g.position), np.float32(w["position"]))
+                assert np.array_equal(np.float32(g.rotation), np.float32(w["rotation"]))
+                assert (np.float32(g.fx), np.float32(g.fy)) == (np.float32(w["fx"]), np.float32(w["fy"]))
+        dup = json.loads(text)[2]["id"]
+        assert sc.camera(dup).width == 999 and sc.camera(10_000) is None
+        rng = np.random.default_rng(0)
+        for _ in range(20):
+            p = rng.uniform(-5, 5, size=3)
+            for split in (None, "train", "test"):
+                assert sc.nearest_camera(p, split) == oio.scene_nearest(ref, p, split)
+        # SceneCamera -> PerspectiveCamera (scene.rs:85-108) keeps working on parsed cameras
+        cam = sc.cameras("train")[0].to_perspective()
+        assert cam.fovx > 0 and cam.znear == pytest.approx(0.01) and cam.zfar == pytest.approx(100.0)
+    finally:
+        sc.close()
+
+
+@pytest.mark.parametrize("text", ["", "{}", "[{\"id\": 1}]", "[1, 2", "[{\"id\":0,\"img_name\":\"a\",\"width\":1,\"height\":1,"
+                                  "\"position\":[0,0],\"rotation\":[[1,0,0],[0,1,0],[0,0,1]],\"fx\":1,\"fy\":1}]"])
+def test_scene_json_errors(ws, text):
+    with pytest.raises(ws.WebSplatError):
+        ws.Scene.from_json_text(text)
+
+
+def test_scene_file_and_empty(ws, tmp_path):
+    p = str(tmp_path / "cameras.json")
+    synth.write_cameras_json(p, synth.orbit_cameras(9, 320, 240, 300.0, 300.0))
+    sc = ws.Scene.from_json(p)
+    assert sc.num_cameras() == 9 and len(sc.cameras("test")) == 2 and len(sc.cameras("train")) == 7
+    sc.close()
+    empty = ws.Scene.from_json_text("[]")
+    assert empty.num_cameras() == 0 and empty.extend() == 0.0 and empty.nearest_camera([0, 0, 0]) is None
+    empty.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (7, 13), (240, 320)])
+def test_png_roundtrip(ws, tmp_path, shape):
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, size=(shape[0], shape[1], 4), dtype=np.uint8)
+    p = str(tmp_path / "x.png")
+    ws.write_png(p, img)
+    assert np.array_equal(oio.png_read_rgba8(p), img)
+
+
+def test_oracle_io_closed_forms():
+    """Pin the numpy restatement itself: identity quaternion -> diag(s^2); texture read-back truncates; the display
+    composite is `src + bg * (1 - a)` rounded to nearest."""
+    q = np.array([[1.0, 0, 0, 0]], dtype=np.float32)
+    s = np.array([[0.5, 2.0, 3.0]], dtype=np.float32)
+    assert np.allclose(oio.build_cov(q, s), [[0.25, 0, 0, 4.0, 0, 9.0]])
+    q90 = np.array([[np.sqrt(0.5), 0, 0, np.sqrt(0.5)]], dtype=np.float32)   # 90 degrees about z: x <-> y
+    assert np.allclose(oio.build_cov(q90, s), [[4.0, 0, 0, 0.25, 0, 9.0]], atol=1e-6)
+    img = np.array([[[0.999, 1.5, -0.2, 0.5]]], dtype=np.float16)
+    assert oio.download_texture_u8(img).tolist() == [[[254, 255, 0, 127]]]
+    src = np.array([[[0.25, 0.0, 0.5, 0.5]]], dtype=np.float32)
+    assert oio.display_composite(src, (1.0, 1.0, 0.0, 1.0)).tolist() == [[[191, 128, 128, 255]]]
+    assert oio.display_composite(src, (1.0, 1.0, 0.0, 1.0), bgra=True).tolist() == [[[128, 128, 191, 255]]]

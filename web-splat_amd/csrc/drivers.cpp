@@ -1,0 +1,212 @@
+// drivers.cpp -- the reference's offline front-ends on top of the C ABI (SURVEY 8f, N2 + N4).
+//
+// Mirrors src/bin/render.rs:33-128 (render_views: resolution cap, fit_near_far, SplattingArgs of the offline
+// callers, Rgba16Float target cleared to TRANSPARENT, PNG per view), :187-246 (download_texture: f16 -> clamp ->
+// * 255 -> `as u8`), src/bin/measure.rs:27-154 (fixed 2048x2048 Rgba8Unorm target, 1 + 10 x cameras frames, one
+// wait, "average FPS") and src/renderer.rs:548-582 (Display::render).  Everything here only CALLS the hot path
+// through the public entry points (ws_renderer_prepare / ws_renderer_render); nothing is re-implemented.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ws_internal.h"
+
+using namespace ws;
+
+namespace ws {
+int launch_display(const void* src, int src_format, size_t src_pitch, uint32_t w, uint32_t h, const float bg[4],
+                   int dst_format, void* dst, size_t dst_pitch, hipStream_t stream);
+}
+
+namespace {
+
+size_t texel_bytes(ws_color_format f) { return f == WS_FORMAT_RGBA8_UNORM ? 4 : (f == WS_FORMAT_RGBA16_FLOAT ? 8 : 16); }
+
+// SplattingArgs of the offline callers (bin/render.rs:88-103, bin/measure.rs:63-78)
+void offline_args(const ws_scene_camera& sc, const ws_pointcloud* pc, uint32_t vw, uint32_t vh, ws_splatting_args* a) {
+    std::memset(a, 0, sizeof *a);
+    ws_camera_from_scene(sc.position, sc.rotation, sc.fx, sc.fy, sc.width, sc.height, &a->camera);
+    ws_aabb box;
+    ws_pointcloud_bbox(pc, &box);
+    ws_camera_fit_near_far(&a->camera, &box);
+    a->viewport[0] = vw;
+    a->viewport[1] = vh;
+    a->gaussian_scaling = 1.0f;
+    a->max_sh_deg = ws_pointcloud_sh_deg(pc);
+    a->walltime_secs = 100.0;
+    // background_color: TRANSPARENT (all zero)
+}
+
+bool make_dir(const std::string& p) {
+    struct stat st;
+    if (stat(p.c_str(), &st) == 0) return S_ISDIR(st.st_mode);
+    return mkdir(p.c_str(), 0777) == 0;
+}
+bool make_dirs(const std::string& p) {  // create_dir_all
+    for (size_t i = 1; i < p.size(); ++i)
+        if (p[i] == '/' && !make_dir(p.substr(0, i))) return false;
+    return make_dir(p);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ws_download_texture_rgba8(ws_context* ctx, const void* d_image, ws_color_format format, uint32_t width,
+                              uint32_t height, size_t row_pitch_bytes, uint8_t* out, void* stream_v) {
+    if (!ctx || !d_image || !out || width == 0 || height == 0) return fail(WS_ERR_INVALID, "ws_download_texture_rgba8: bad argument");
+    const size_t tb = texel_bytes(format);
+    if (row_pitch_bytes < tb * width) return fail(WS_ERR_INVALID, "ws_download_texture_rgba8: row pitch too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    std::vector<uint8_t> raw;
+    try {
+        raw.resize(row_pitch_bytes * height);
+    } catch (...) {
+        return fail(WS_ERR_OOM, "ws_download_texture_rgba8: host allocation failed");
+    }
+    WS_HIP(hipMemcpyAsync(raw.data(), d_image, raw.size(), hipMemcpyDeviceToHost, stream));
+    WS_HIP(hipStreamSynchronize(stream));
+    for (uint32_t y = 0; y < height; ++y) {
+        const uint8_t* row = raw.data() + (size_t)y * row_pitch_bytes;
+        uint8_t* o = out + (size_t)y * width * 4;
+        for (uint32_t i = 0; i < width * 4; ++i) {
+            if (format == WS_FORMAT_RGBA8_UNORM) {
+                o[i] = row[i];
+                continue;
+            }
+            float v;
+            if (format == WS_FORMAT_RGBA16_FLOAT) {
+                uint16_t h;
+                std::memcpy(&h, row + (size_t)i * 2, 2);
+                v = host_f16_to_f32(h);
+            } else {
+                std::memcpy(&v, row + (size_t)i * 4, 4);
+            }
+            // f32::clamp(0., 1.) * 255. as u8  (bin/render.rs:232; NaN -> 0 like Rust's saturating cast)
+            v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+            const float s = v * 255.0f;
+            o[i] = (s != s) ? 0 : (uint8_t)s;
+        }
+    }
+    return WS_OK;
+}
+
+int ws_render_views(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, int split, const char* out_dir,
+                    uint32_t* rendered) {
+    if (!ctx || !pc || !scene || !out_dir) return fail(WS_ERR_INVALID, "ws_render_views: null argument");
+    if (split != WS_SPLIT_TRAIN && split != WS_SPLIT_TEST) return fail(WS_ERR_INVALID, "ws_render_views: split must be train or test");
+    if (rendered) *rendered = 0;
+    const std::string dir = std::string(out_dir) + "/" + (split == WS_SPLIT_TEST ? "test" : "train");
+    if (!make_dirs(dir)) return fail(WS_ERR_IO, "ws_render_views: cannot create " + dir);
+    const uint32_t n = ws_scene_cameras(scene, split, 0, nullptr);
+    std::vector<ws_scene_camera> cams(n);
+    ws_scene_cameras(scene, split, n, cams.data());
+    ws_renderer* r = nullptr;
+    int rc = ws_renderer_create(ctx, WS_FORMAT_RGBA16_FLOAT, ws_pointcloud_sh_deg(pc), ws_pointcloud_compressed(pc), &r);
+    if (rc) return rc;
+    void* target = nullptr;
+    size_t target_bytes = 0;
+    std::vector<uint8_t> rgba;
+    const float clear[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < n && rc == WS_OK; ++i) {
+        uint32_t w = cams[i].width, h = cams[i].height;
+        if (w > 1600) {  // bin/render.rs:58-62
+            const float s = (float)w / 1600.0f;
+            w = 1600;
+            h = (uint32_t)((float)h / s);
+        }
+        if (w == 0 || h == 0) {
+            rc = fail(WS_ERR_INVALID, "ws_render_views: camera with an empty image");
+            break;
+        }
+        const size_t need = (size_t)w * h * 8;
+        if (need > target_bytes) {
+            if (target) ws_device_free(ctx, target);
+            target = nullptr;
+            if ((rc = ws_device_malloc(ctx, need, &target))) break;
+            target_bytes = need;
+        }
+        ws_splatting_args a;
+        offline_args(cams[i], pc, w, h, &a);
+        if ((rc = ws_renderer_prepare(r, pc, &a, nullptr))) break;
+        if ((rc = ws_renderer_render(r, pc, clear, target, (size_t)w * 8, nullptr))) break;
+        rgba.resize((size_t)w * h * 4);
+        if ((rc = ws_download_texture_rgba8(ctx, target, WS_FORMAT_RGBA16_FLOAT, w, h, (size_t)w * 8, rgba.data(), nullptr))) break;
+        char name[32];
+        std::snprintf(name, sizeof name, "/%05u.png", i);
+        if ((rc = ws_png_write_rgba8((dir + name).c_str(), w, h, rgba.data(), (size_t)w * 4))) break;
+        if (rendered) *rendered = i + 1;
+    }
+    if (target) ws_device_free(ctx, target);
+    ws_renderer_destroy(r);
+    return rc;
+}
+
+int ws_measure(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, uint32_t num_samples,
+               uint32_t frames_in_flight, float* fps) {
+    if (!ctx || !pc || !scene || !fps) return fail(WS_ERR_INVALID, "ws_measure: null argument");
+    if (num_samples == 0) num_samples = 10;  // bin/measure.rs:98
+    if (frames_in_flight == 0) frames_in_flight = 1;
+    const uint32_t n = ws_scene_cameras(scene, WS_SPLIT_TRAIN, 0, nullptr);
+    if (n == 0) return fail(WS_ERR_INVALID, "ws_measure: the scene has no training cameras");
+    std::vector<ws_scene_camera> cams(n);
+    ws_scene_cameras(scene, WS_SPLIT_TRAIN, n, cams.data());
+    const uint32_t W = 2048, H = 2048;  // bin/measure.rs:34
+    std::vector<ws_renderer*> rs(frames_in_flight, nullptr);
+    std::vector<void*> targets(frames_in_flight, nullptr);
+    std::vector<hipStream_t> streams(frames_in_flight, nullptr);
+    int rc = WS_OK;
+    for (uint32_t k = 0; k < frames_in_flight && rc == WS_OK; ++k) {
+        rc = ws_renderer_create(ctx, WS_FORMAT_RGBA8_UNORM, ws_pointcloud_sh_deg(pc), ws_pointcloud_compressed(pc), &rs[k]);
+        if (rc == WS_OK) rc = ws_device_malloc(ctx, (size_t)W * H * 4, &targets[k]);
+        if (rc == WS_OK && k > 0 && hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) != hipSuccess)
+            rc = fail(WS_ERR_HIP, "ws_measure: hipStreamCreate failed");
+    }
+    const float clear[4] = {0, 0, 0, 0};
+    if (rc == WS_OK) {
+        const auto start = std::chrono::steady_clock::now();  // before the warm-up frame (bin/measure.rs:50)
+        ws_splatting_args a;
+        offline_args(cams[0], pc, W, H, &a);
+        rc = ws_renderer_prepare(rs[0], pc, &a, streams[0]);  // "first render to lazy init sorter stuff"
+        if (rc == WS_OK) rc = ws_renderer_render(rs[0], pc, clear, targets[0], (size_t)W * 4, streams[0]);
+        uint32_t f = 0;
+        for (uint32_t i = 0; i < n && rc == WS_OK; ++i) {
+            offline_args(cams[i], pc, W, H, &a);
+            for (uint32_t s = 0; s < num_samples && rc == WS_OK; ++s, ++f) {
+                const uint32_t k = f % frames_in_flight;
+                rc = ws_renderer_prepare(rs[k], pc, &a, streams[k]);
+                if (rc == WS_OK) rc = ws_renderer_render(rs[k], pc, clear, targets[k], (size_t)W * 4, streams[k]);
+            }
+        }
+        if (rc == WS_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(WS_ERR_HIP, "ws_measure: device sync failed");  // device.poll(Wait)
+        const float secs = std::chrono::duration<float>(std::chrono::steady_clock::now() - start).count();
+        if (rc == WS_OK) *fps = 1.0f / (secs / ((float)n * (float)num_samples));
+    }
+    for (uint32_t k = 0; k < frames_in_flight; ++k) {
+        if (rs[k]) ws_renderer_destroy(rs[k]);
+        if (targets[k]) ws_device_free(ctx, targets[k]);
+        if (streams[k]) (void)hipStreamDestroy(streams[k]);
+    }
+    return rc;
+}
+
+int ws_display_composite(ws_context* ctx, const void* d_src, ws_color_format src_format, size_t src_pitch_bytes,
+                         uint32_t width, uint32_t height, const float background[4], ws_surface_format dst_format,
+                         void* d_dst, size_t dst_pitch_bytes, void* stream) {
+    if (!ctx || !d_src || !d_dst || width == 0 || height == 0) return fail(WS_ERR_INVALID, "ws_display_composite: bad argument");
+    if (src_pitch_bytes < texel_bytes(src_format) * width || dst_pitch_bytes < (size_t)width * 4 ||
+        (src_pitch_bytes % texel_bytes(src_format)) != 0 || (dst_pitch_bytes % 4) != 0)
+        return fail(WS_ERR_INVALID, "ws_display_composite: row pitch does not fit the format");
+    if (dst_format != WS_SURFACE_RGBA8_UNORM && dst_format != WS_SURFACE_BGRA8_UNORM)
+        return fail(WS_ERR_INVALID, "ws_display_composite: unknown surface format");
+    const float zero[4] = {0, 0, 0, 0};
+    return launch_display(d_src, (int)src_format, src_pitch_bytes, width, height, background ? background : zero,
+                          (int)dst_format, d_dst, dst_pitch_bytes, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

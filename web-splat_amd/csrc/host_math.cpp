@@ -183,14 +183,19 @@ float sigmoid(float x) {  // utils.rs:206-212
     return std::exp(x) / (1.0f + std::exp(x));
 }
 
+void build_cov_impl(const float q[4], const float scale[3], float out[6]);
+
 // utils.rs:194-203 build_cov: l = R * diag(s); m = l * l^T; upper triangle
-void build_cov(const float q[4], const float scale[3], float out[6]) {
+void build_cov_impl(const float q[4], const float scale[3], float out[6]) {
     const Mat3 r = quat_to_mat3(q);
     Mat3 l;
     for (int c = 0; c < 3; ++c)
         for (int rr = 0; rr < 3; ++rr) {
-            float s = 0.0f;  // full product with the (diagonal) scale matrix, zero terms included
-            for (int k = 0; k < 3; ++k) s += r.at(k, rr) * (k == c ? scale[c] : 0.0f);
+            // cgmath Matrix3 * Matrix3 = row.dot(column), Vector3::dot = x*x' + y*y' + z*z': the full product with the
+            // diagonal scale matrix, zero terms included and no leading zero (they decide the sign of an exact 0)
+            float s = r.at(0, rr) * (0 == c ? scale[c] : 0.0f);
+            s += r.at(1, rr) * (1 == c ? scale[c] : 0.0f);
+            s += r.at(2, rr) * (2 == c ? scale[c] : 0.0f);
             l.at(c, rr) = s;
         }
     Mat3 m;
@@ -210,6 +215,8 @@ void build_cov(const float q[4], const float scale[3], float out[6]) {
 }
 
 }  // namespace
+
+void build_cov(const float q[4], const float scale[3], float out[6]) { build_cov_impl(q, scale, out); }
 
 // IEEE binary16, round-to-nearest-even (half::f16::from_f32)
 uint16_t host_f32_to_f16(float f) {

@@ -632,6 +632,66 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
 
 }  // namespace
 
+// ---- k_display: Display::render (renderer.rs:548-582) + display.wgsl:37-55 -------------------------------
+// A full-screen quad samples the splat image at texel centres (identity: source and target have the same size)
+// and PREMULTIPLIED_ALPHA_BLENDING puts it over the surface cleared to `background`:
+//   dst = src + background * (1 - src.a), then the 8-bit unorm store of the surface.  Pure streaming: 4..16 B in,
+// 4 B out per pixel; one thread per pixel, rows are contiguous.
+namespace {
+struct DisplayParams {
+    const void* src;
+    void* dst;
+    size_t src_pitch, dst_pitch;
+    uint32_t w, h;
+    float bg[4];
+    int src_format, dst_format;
+};
+__global__ __launch_bounds__(256) void k_display(const DisplayParams p) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.w || y >= p.h) return;
+    const char* row = reinterpret_cast<const char*>(p.src) + (size_t)y * p.src_pitch;
+    float r, g, b, a;
+    if (p.src_format == WS_FORMAT_RGBA32_FLOAT) {
+        const float4 v = reinterpret_cast<const float4*>(row)[x];
+        r = v.x; g = v.y; b = v.z; a = v.w;
+    } else if (p.src_format == WS_FORMAT_RGBA16_FLOAT) {
+        const uint2 v = reinterpret_cast<const uint2*>(row)[x];
+        r = h2f(v.x); g = h2f(v.x >> 16); b = h2f(v.y); a = h2f(v.y >> 16);
+    } else {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        r = (float)(v & 255u) / 255.0f; g = (float)((v >> 8) & 255u) / 255.0f;
+        b = (float)((v >> 16) & 255u) / 255.0f; a = (float)(v >> 24) / 255.0f;
+    }
+    const float k = 1.0f - a;
+    const float o0 = r + p.bg[0] * k, o1 = g + p.bg[1] * k, o2 = b + p.bg[2] * k, o3 = a + p.bg[3] * k;
+    auto q8 = [](float v) -> uint32_t {
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        return (uint32_t)__float2int_rn(v * 255.0f);
+    };
+    const uint32_t out = p.dst_format == WS_SURFACE_BGRA8_UNORM ? (q8(o2) | (q8(o1) << 8) | (q8(o0) << 16) | (q8(o3) << 24))
+                                                                : (q8(o0) | (q8(o1) << 8) | (q8(o2) << 16) | (q8(o3) << 24));
+    reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(p.dst) + (size_t)y * p.dst_pitch)[x] = out;
+}
+}  // namespace
+
+int launch_display(const void* src, int src_format, size_t src_pitch, uint32_t w, uint32_t h, const float bg[4],
+                   int dst_format, void* dst, size_t dst_pitch, hipStream_t stream) {
+    DisplayParams p;
+    p.src = src;
+    p.dst = dst;
+    p.src_pitch = src_pitch;
+    p.dst_pitch = dst_pitch;
+    p.w = w;
+    p.h = h;
+    for (int i = 0; i < 4; ++i) p.bg[i] = bg[i];
+    p.src_format = src_format;
+    p.dst_format = dst_format;
+    hipLaunchKernelGGL(k_display, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, stream, p);
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
 uint32_t bin_prefix_blocks(uint32_t max_points) { return (max_points + BIN_ITEMS - 1) / BIN_ITEMS; }
 
 int launch_bin_prefix(const BinBuffers& b, hipStream_t stream) {

@@ -186,6 +186,9 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
 // ---- host math (host_math.cpp) ------------------------------------------------------------------
 void build_camera_uniform(const ws_camera& cam, const uint32_t viewport[2], ws_camera_uniform* out);
 
+// utils.rs:194-203 build_cov(rotation quaternion (s,x,y,z), scale) -> upper triangle xx,xy,xz,yy,yz,zz
+void build_cov(const float q[4], const float scale[3], float out[6]);
+
 // ---- half helpers ---------------------------------------------------------------------------------
 uint16_t host_f32_to_f16(float f);
 float host_f16_to_f32(uint16_t h);

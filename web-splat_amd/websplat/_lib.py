@@ -96,6 +96,27 @@ class ws_stage_times(C.Structure):
                 ("rasterization_ms", C.c_float)]
 
 
+class ws_npz_cloud(C.Structure):
+    _fields_ = [("num_points", C.c_uint32), ("sh_deg", C.c_uint32),
+                ("gaussians", C.c_void_p), ("gaussians_bytes", C.c_size_t),
+                ("sh_coefs", C.c_void_p), ("sh_coefs_bytes", C.c_size_t),
+                ("covars", C.c_void_p), ("covars_bytes", C.c_size_t),
+                ("quantization", ws_gaussian_quantization),
+                ("has_kernel_size", C.c_int32), ("kernel_size", C.c_float),
+                ("has_mip_splatting", C.c_int32), ("mip_splatting", C.c_int32),
+                ("has_background_color", C.c_int32), ("background_color", C.c_float * 3)]
+
+
+class ws_scene_camera(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("img_name", C.c_char * 128), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("position", C.c_float * 3), ("rotation", C.c_float * 9), ("fx", C.c_float), ("fy", C.c_float),
+                ("split", C.c_int32)]
+
+
+WS_SPLIT_ALL, WS_SPLIT_TRAIN, WS_SPLIT_TEST = -1, 0, 1
+WS_SURFACE_RGBA8_UNORM, WS_SURFACE_BGRA8_UNORM = 0, 1
+
+
 class ws_kernel_time(C.Structure):
     _fields_ = [("name", C.c_char * 40), ("ms", C.c_float)]
 
@@ -136,6 +157,24 @@ SIGNATURES = {
     "ws_pointcloud_stats": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(ws_aabb), C.POINTER(ws_aabb), _f32p,
                                       C.POINTER(C.c_int32), _f32p]),
     "ws_pointcloud_load_ply": (C.c_int, [_P, C.c_char_p, _PP]),
+    "ws_npz_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(ws_npz_cloud))]),
+    "ws_npz_free": (None, [C.POINTER(ws_npz_cloud)]),
+    "ws_pointcloud_load_npz": (C.c_int, [_P, C.c_char_p, _PP]),
+    "ws_pointcloud_load": (C.c_int, [_P, C.c_char_p, _PP]),
+    "ws_scene_load_json": (C.c_int, [C.c_char_p, _PP]),
+    "ws_scene_from_json_text": (C.c_int, [C.c_char_p, C.c_size_t, _PP]),
+    "ws_scene_destroy": (None, [_P]),
+    "ws_scene_num_cameras": (C.c_uint32, [_P]),
+    "ws_scene_extend": (C.c_float, [_P]),
+    "ws_scene_cameras": (C.c_uint32, [_P, C.c_int, C.c_uint32, C.POINTER(ws_scene_camera)]),
+    "ws_scene_get_camera": (C.c_int, [_P, C.c_uint32, C.POINTER(ws_scene_camera)]),
+    "ws_scene_nearest_camera": (C.c_int, [_P, _f32p, C.c_int, _u32p]),
+    "ws_download_texture_rgba8": (C.c_int, [_P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, _P, _P]),
+    "ws_png_write_rgba8": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _P, C.c_size_t]),
+    "ws_render_views": (C.c_int, [_P, _P, _P, C.c_int, C.c_char_p, _u32p]),
+    "ws_measure": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _f32p]),
+    "ws_display_composite": (C.c_int, [_P, _P, C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, _f32p, C.c_int, _P,
+                                       C.c_size_t, _P]),
     "ws_pointcloud_create": (C.c_int, [_P, C.POINTER(ws_pointcloud_desc), _PP]),
     "ws_pointcloud_destroy": (None, [_P]),
     "ws_pointcloud_num_points": (C.c_uint32, [_P]),

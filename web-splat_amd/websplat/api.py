@@ -213,6 +213,118 @@ class GenericGaussianPointCloud:
         return GenericGaussianPointCloud(g, s, sh_deg, n, aabb, center, up=up, **meta)
 
 
+def read_npz(path: str) -> GenericGaussianPointCloud:
+    """io/npz.rs:59-225 NpzReader::read + io/mod.rs:107-150 new_compressed, through the library's native reader."""
+    pp = C.POINTER(L.ws_npz_cloud)()
+    check(lib.ws_npz_read(str(path).encode(), C.byref(pp)))
+    try:
+        c = pp.contents
+        g = np.ctypeslib.as_array((C.c_uint8 * c.gaussians_bytes).from_address(c.gaussians)).copy().reshape(-1, 24)
+        sh = np.ctypeslib.as_array((C.c_uint8 * c.sh_coefs_bytes).from_address(c.sh_coefs)).copy()
+        cv = np.ctypeslib.as_array((C.c_uint8 * c.covars_bytes).from_address(c.covars)).copy().reshape(-1, 12)
+        q = L.ws_gaussian_quantization()
+        C.memmove(C.byref(q), C.byref(c.quantization), C.sizeof(q))
+        aabb, center, up = pointcloud_stats(g, 24, Aabb([-1, -1, -1], [1, 1, 1]))  # Aabb::unit(), io/mod.rs:119
+        return GenericGaussianPointCloud(
+            g, sh, int(c.sh_deg), int(c.num_points), aabb, center, compressed=True, covars=cv, quantization=q, up=up,
+            kernel_size=c.kernel_size if c.has_kernel_size else None,
+            mip_splatting=bool(c.mip_splatting) if c.has_mip_splatting else None,
+            background_color=list(c.background_color) if c.has_background_color else None)
+    finally:
+        lib.ws_npz_free(pp)
+
+
+def write_png(path: str, rgba: np.ndarray):
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    h, w = rgba.shape[:2]
+    check(lib.ws_png_write_rgba8(str(path).encode(), w, h, rgba.ctypes.data_as(C.c_void_p), w * 4))
+
+
+@dataclass
+class SceneCamera:
+    """scene.rs:13-24."""
+    id: int
+    img_name: str
+    width: int
+    height: int
+    position: Sequence[float]
+    rotation: Sequence[Sequence[float]]
+    fx: float
+    fy: float
+    split: str = "train"
+
+    @staticmethod
+    def from_c(c):
+        rot = [list(c.rotation[3 * k:3 * k + 3]) for k in range(3)]
+        return SceneCamera(c.id, c.img_name.decode(), c.width, c.height, list(c.position), rot, c.fx, c.fy,
+                           "test" if c.split == L.WS_SPLIT_TEST else "train")
+
+    def to_perspective(self) -> "PerspectiveCamera":
+        return PerspectiveCamera.from_scene_camera(self.position, self.rotation, self.fx, self.fy, self.width, self.height)
+
+
+_SPLITS = {None: L.WS_SPLIT_ALL, "train": L.WS_SPLIT_TRAIN, "test": L.WS_SPLIT_TEST}
+
+
+class Scene:
+    """scene.rs:113-194 Scene."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    @staticmethod
+    def from_json(path: str):
+        h = C.c_void_p()
+        check(lib.ws_scene_load_json(str(path).encode(), C.byref(h)))
+        return Scene(h)
+
+    @staticmethod
+    def from_json_text(text: str):
+        raw = text.encode()
+        h = C.c_void_p()
+        check(lib.ws_scene_from_json_text(raw, len(raw), C.byref(h)))
+        return Scene(h)
+
+    def close(self):
+        if self.handle:
+            lib.ws_scene_destroy(self.handle)
+            self.handle = None
+
+    def num_cameras(self):
+        return lib.ws_scene_num_cameras(self.handle)
+
+    def extend(self):
+        return lib.ws_scene_extend(self.handle)
+
+    def cameras(self, split=None):
+        n = lib.ws_scene_cameras(self.handle, _SPLITS[split], 0, None)
+        buf = (L.ws_scene_camera * max(n, 1))()
+        lib.ws_scene_cameras(self.handle, _SPLITS[split], n, buf)
+        return [SceneCamera.from_c(buf[i]) for i in range(n)]
+
+    def camera(self, cam_id: int):
+        c = L.ws_scene_camera()
+        return SceneCamera.from_c(c) if lib.ws_scene_get_camera(self.handle, int(cam_id), C.byref(c)) else None
+
+    def nearest_camera(self, pos, split=None):
+        out = C.c_uint32()
+        return out.value if lib.ws_scene_nearest_camera(self.handle, _f3(pos), _SPLITS[split], C.byref(out)) else None
+
+
+def render_views(ctx: "Context", pc: "PointCloud", scene: Scene, split: str, out_dir: str) -> int:
+    """bin/render.rs:33-128 render_views."""
+    n = C.c_uint32()
+    check(lib.ws_render_views(ctx.handle, pc.handle, scene.handle, _SPLITS[split], str(out_dir).encode(), C.byref(n)))
+    return n.value
+
+
+def measure(ctx: "Context", pc: "PointCloud", scene: Scene, num_samples: int = 10, frames_in_flight: int = 1) -> float:
+    """bin/measure.rs:27-154: average FPS over the training cameras at 2048x2048."""
+    fps = C.c_float()
+    check(lib.ws_measure(ctx.handle, pc.handle, scene.handle, int(num_samples), int(frames_in_flight), C.byref(fps)))
+    return fps.value
+
+
 def pointcloud_stats(gaussians: np.ndarray, stride: int, start: Aabb):
     start_c = start.to_c()
     bbox = L.ws_aabb()
@@ -270,6 +382,19 @@ class PointCloud:
     def load_ply(ctx: Context, path: str):
         h = C.c_void_p()
         check(lib.ws_pointcloud_load_ply(ctx.handle, path.encode(), C.byref(h)))
+        return PointCloud(ctx, _handle=h)
+
+    @staticmethod
+    def load_npz(ctx: Context, path: str):
+        h = C.c_void_p()
+        check(lib.ws_pointcloud_load_npz(ctx.handle, str(path).encode(), C.byref(h)))
+        return PointCloud(ctx, _handle=h)
+
+    @staticmethod
+    def load(ctx: Context, path: str):
+        """io/mod.rs:45-61 GenericGaussianPointCloud::load (magic-byte sniffing) + PointCloud::new."""
+        h = C.c_void_p()
+        check(lib.ws_pointcloud_load(ctx.handle, str(path).encode(), C.byref(h)))
         return PointCloud(ctx, _handle=h)
 
     def close(self):
@@ -391,6 +516,28 @@ class GaussianRenderer:
         bg = (C.c_float * 4)(*[float(x) for x in background])
         check(lib.ws_renderer_render(self.handle, pc.handle, bg, C.c_void_p(target_ptr), pitch, C.c_void_p(stream or 0)))
         return target_ptr
+
+    def download_target_rgba8(self) -> np.ndarray:
+        """bin/render.rs:187-246 download_texture of the renderer-owned target: H x W x 4 uint8 (truncating)."""
+        w, h = self._own_target_shape
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        check(lib.ws_download_texture_rgba8(self.ctx.handle, C.c_void_p(self._own_target), FORMATS[self.color_format_name][0],
+                                            w, h, w * self.texel_bytes, out.ctypes.data_as(C.c_void_p), None))
+        return out
+
+    def display(self, background=(0.0, 0.0, 0.0, 1.0), surface="rgba8unorm") -> np.ndarray:
+        """Display::render (renderer.rs:548-582) of the renderer-owned target into an 8-bit surface: H x W x 4."""
+        w, h = self._own_target_shape
+        dst = self.ctx.malloc(w * h * 4)
+        try:
+            bg = (C.c_float * 4)(*[float(x) for x in background])
+            sf = {"rgba8unorm": L.WS_SURFACE_RGBA8_UNORM, "bgra8unorm": L.WS_SURFACE_BGRA8_UNORM}[surface]
+            check(lib.ws_display_composite(self.ctx.handle, C.c_void_p(self._own_target), FORMATS[self.color_format_name][0],
+                                           w * self.texel_bytes, w, h, bg, sf, C.c_void_p(dst), w * 4, None))
+            self.ctx.sync()
+            return self.ctx.download(dst, (h, w, 4), np.uint8)
+        finally:
+            self.ctx.free(dst)
 
     def download_target(self) -> np.ndarray:
         """download_texture (bin/render.rs:187-246) for the renderer-owned target: H x W x 4."""

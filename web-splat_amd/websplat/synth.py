@@ -184,3 +184,44 @@ def compressed_blobs(n=100_000, n_geometry=4096, n_sh=4096, seed=3, sh_deg=3, ex
     }
     return {"gaussians": g.view(np.uint8).reshape(n, 24), "covars": covars.view(np.uint8).reshape(n_geometry, 12),
             "sh": sh.view(np.uint8).reshape(-1), "quant": quant, "sh_deg": sh_deg, "num_points": n}
+
+
+def c3dgs_arrays(n=100_000, n_geometry=4096, n_sh=4096, seed=3, sh_deg=3, extent=1.0, with_scaling_factor=True,
+                 with_indices=True):
+    """The arrays of a c3dgs .npz (field names / dtypes / shapes of io/npz.rs:61-158): SURVEY 8(d) config C5."""
+    rng = np.random.default_rng(seed)
+    ncoef = (sh_deg + 1) ** 2
+    m = n_geometry if with_indices else n
+    k = n_sh if with_indices else n
+    a = {
+        "xyz": rng.uniform(-extent, extent, size=(n, 3)).astype(np.float16),
+        "opacity": rng.integers(-128, 128, size=(n, 1), dtype=np.int8),
+        "scaling": rng.integers(-128, 128, size=(m, 3), dtype=np.int8),
+        "rotation": rng.integers(-128, 128, size=(m, 4), dtype=np.int8),
+        "features_dc": rng.integers(-128, 128, size=(k, 3), dtype=np.int8),
+        "features_rest": rng.integers(-128, 128, size=(k, ncoef - 1, 3), dtype=np.int8),
+        "opacity_scale": np.array(1.0 / 255.0, dtype=np.float32), "opacity_zero_point": np.array(-128, dtype=np.int32),
+        "rotation_scale": np.array(1.0 / 127.0, dtype=np.float32), "rotation_zero_point": np.array(3, dtype=np.int32),
+        "features_dc_scale": np.array(0.012, dtype=np.float32), "features_dc_zero_point": np.array(3, dtype=np.int32),
+        "features_rest_scale": np.array(0.003, dtype=np.float32), "features_rest_zero_point": np.array(-2, dtype=np.int32),
+    }
+    # a few exactly-zero rotations would normalise to NaN in the reference as well; keep the codebook regular
+    a["rotation"][np.all(a["rotation"] == 3, axis=1)] = np.array([100, 3, 3, 3], dtype=np.int8)
+    if with_scaling_factor:
+        a["scaling_scale"] = np.array(0.01, dtype=np.float32)
+        a["scaling_zero_point"] = np.array(-130, dtype=np.int32)     # (i8 + 130) * 0.01 > 0: a direction to normalise
+        a["scaling_factor"] = rng.integers(-128, 128, size=(n,), dtype=np.int8)
+        a["scaling_factor_scale"] = np.array(0.02, dtype=np.float32)
+        a["scaling_factor_zero_point"] = np.array(200, dtype=np.int32)
+    else:
+        a["scaling_scale"] = np.array(0.02, dtype=np.float32)       # exp((i8 - 100) * 0.02): absolute scales
+        a["scaling_zero_point"] = np.array(100, dtype=np.int32)
+    if with_indices:
+        a["gaussian_indices"] = rng.integers(0, n_geometry, size=(n,), dtype=np.int32)
+        a["feature_indices"] = rng.integers(0, n_sh, size=(n,), dtype=np.int32)
+    return a
+
+
+def write_npz(path, arrays, compressed=True, **extra):
+    """np.savez_compressed (DEFLATE members, what c3dgs writes) or np.savez (stored members)."""
+    (np.savez_compressed if compressed else np.savez)(path, **arrays, **extra)
