@@ -464,8 +464,11 @@ __device__ __forceinline__ void k1_back_compressed(const K1Params& p, const K1Bu
 // One workgroup = one ticket = K1_ITEMS x 256 consecutive Gaussians (1024): a single device-wide atomic per
 // 1024 Gaussians keeps the ticket dispenser (~11 ns per returning atomic on one address) far below the
 // kernel's HBM time.  Store order inside the block is (item, thread) = Gaussian index order.
+#ifndef WS_K1_MINWAVES
+#define WS_K1_MINWAVES 1
+#endif
 template <bool COMPRESSED>
-__global__ __launch_bounds__(K1_THREADS) void k_preprocess(const K1Params p, const K1Buffers b) {
+__global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const K1Params p, const K1Buffers b) {
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_cnt[K1_ITEMS][K1_THREADS / 64];
     __shared__ uint32_t s_base;

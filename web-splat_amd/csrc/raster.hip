@@ -26,7 +26,10 @@ namespace ws {
 namespace {
 
 constexpr int BIN_THREADS = 256;
-constexpr int BIN_IPT = 8;                         // sorted splats per thread
+#ifndef WS_BIN_IPT
+#define WS_BIN_IPT 8
+#endif
+constexpr int BIN_IPT = WS_BIN_IPT;                // sorted splats per thread
 constexpr int BIN_ITEMS = BIN_THREADS * BIN_IPT;   // 2048 per block
 
 __device__ __forceinline__ float h2f(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)(h & 0xFFFFu))); }

@@ -158,6 +158,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t*
 }
 
 // One workgroup per digit: exclusive scan of that digit's row over the tiles (in place), total -> hist[digit].
+// Each thread owns a run of consecutive tiles: sum it, one block scan over the 256 run sums, then write the run's
+// prefixes.  (A chunked loop with a block scan per 256 tiles cost 0.8 us per chunk in barriers: 10 us for the
+// 3 k tiles of the tile-id sort, as much as the histogram kernel in front of it.)
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* __restrict__ d_count, uint32_t n,
                                                                uint32_t tile_n, uint32_t* __restrict__ tile_sums,
                                                                uint32_t tiles_cap, uint32_t* __restrict__ hist) {
@@ -165,16 +168,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* 
     const uint32_t count = device_count(d_count, n);
     const uint32_t ntiles = (count + tile_n - 1) / tile_n;
     uint32_t* row = tile_sums + (size_t)blockIdx.x * tiles_cap;
-    uint32_t running = 0;  // block-uniform
-    for (uint32_t t0 = 0; t0 < ntiles; t0 += SORT_THREADS) {
-        const uint32_t t = t0 + threadIdx.x;
-        const uint32_t c = t < ntiles ? row[t] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan(c, s_tmp, &tot);
-        if (t < ntiles) row[t] = running + ex;
-        running += tot;
+    const uint32_t per = (ntiles + SORT_THREADS - 1) / SORT_THREADS;  // run length, block-uniform
+    const uint32_t t0 = threadIdx.x * per;
+    const uint32_t t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; ++t) sum += row[t];
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(sum, s_tmp, &total);
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = row[t];
+        row[t] = run;
+        run += c;
     }
-    if (threadIdx.x == 0) hist[blockIdx.x] = running;
+    if (threadIdx.x == 0) hist[blockIdx.x] = total;
 }
 
 // ---- one digit pass: rank, cross-tile prefix (look-back or precomputed), LDS reorder, scatter ----------
