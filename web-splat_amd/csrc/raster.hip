@@ -352,13 +352,46 @@ __device__ __forceinline__ RawSplat blend_fetch_raw(const BlendParams& p, uint2 
     return r;
 }
 
+// LDS layout of a staged batch: three planes of 16-B records with the SAME slot stride, so one byte offset
+// (slot * 16, what the per-wave lists store) addresses all three with immediate offsets.  Slot 256 is a null
+// record (a' far beyond the cut-off) that pads the lists to multiples of four.
+constexpr int BLEND_SLOTS = 257;
+struct BlendRec {
+    float4 g;  // i00', i01', c0, alpha
+    float4 h;  // i10', i11', c1, r
+    float2 c;  // g, b
+};
+__device__ __forceinline__ BlendRec blend_load_rec(const float4* s_rec, uint32_t byte_off) {
+    const char* base = reinterpret_cast<const char*>(s_rec) + byte_off;
+    BlendRec r;
+    r.g = *reinterpret_cast<const float4*>(base);
+    r.h = *reinterpret_cast<const float4*>(base + BLEND_SLOTS * 16);
+    r.c = *reinterpret_cast<const float2*>(base + 2 * BLEND_SLOTS * 16);
+    return r;
+}
+// One (pixel, splat) pair: gaussian.wgsl:59-66 in the exp2 domain, front-to-back "over".
+__device__ __forceinline__ void blend_composite(const BlendRec& r, float lx, float ly, float& T, float& cr, float& cg,
+                                                float& cb) {
+    const float p0 = fmaf(r.g.x, lx, fmaf(r.g.y, ly, r.g.z));
+    const float p1 = fmaf(r.h.x, lx, fmaf(r.h.y, ly, r.h.z));
+    const float a = fmaf(p0, p0, p1 * p1);
+    if (a <= CUT_A2) {
+        const float b = fminf(0.99f, __builtin_amdgcn_exp2f(-a) * r.g.w);
+        const float wgt = b * T;
+        // three plain v_fmac: the compiler's v_pk_fma_f32 pairing costs a v_pk_mov and issues at half rate on gfx950
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(cr) : "v"(wgt), "v"(r.h.w));
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(cg) : "v"(wgt), "v"(r.c.x));
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(cb) : "v"(wgt), "v"(r.c.y));
+        T -= wgt;
+    }
+}
+
 template <int FORMAT>
 __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
-    __shared__ float4 s_g[256];        // i00', i01', c0, alpha
-    __shared__ float4 s_h[256];        // i10', i11', c1, r
-    __shared__ float2 s_c[256];        // g, b
-    __shared__ uint32_t s_m[256];      // quadrant bits of the staged record (0 = slot unused)
-    __shared__ uint32_t s_list[4][260];  // per wave: staged slots that reach its quadrant, near -> far (+ pad)
+    __shared__ float4 s_rec[3 * BLEND_SLOTS];
+    __shared__ uint32_t s_m[256];  // quadrant bits of the staged record (0 = slot unused)
+    // per wave: byte offsets of the staged records that reach its quadrant, near -> far, padded with the null record
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[4][272];
 
     uint32_t tx, ty;
     if (!blend_tile_of_block(blockIdx.x, p.tiles_x, p.tiles_y, &tx, &ty)) return;  // block-uniform
@@ -372,6 +405,11 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
     const uint32_t py = ty * TILE + qy * 8 + (lane >> 3);
     const bool inside = px < p.width && py < p.height;
     const uint32_t qbit = 1u << wave;
+    if (tid == 0) {  // the null record: a' = 1e18, never inside the cut-off (visible after the first barrier)
+        s_rec[256] = make_float4(0.0f, 0.0f, 1.0e9f, 0.0f);
+        s_rec[BLEND_SLOTS + 256] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_rec[2 * BLEND_SLOTS + 256] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
 
     uint2 range = p.tile_ranges[tile];
     range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
@@ -408,9 +446,9 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
                 const float x0 = (float)((q & 1) * 8) + 0.5f - cxl, y0 = (float)((q >> 1) * 8) + 0.5f - cyl;
                 if (ellipse_reaches_box(A, B2, C, rcpA, rcpC, x0, x0 + 7.0f, y0, y0 + 7.0f, CUT_A2)) mask |= 1u << q;
             }
-            s_g[tid] = make_float4(i00, i01, c0, h2f(raw.w4 >> 16));
-            s_h[tid] = make_float4(i10, i11, c1, h2f(raw.w3));
-            s_c[tid] = make_float2(h2f(raw.w3 >> 16), h2f(raw.w4));
+            s_rec[tid] = make_float4(i00, i01, c0, h2f(raw.w4 >> 16));
+            s_rec[BLEND_SLOTS + tid] = make_float4(i10, i11, c1, h2f(raw.w3));
+            *reinterpret_cast<float2*>(&s_rec[2 * BLEND_SLOTS + tid]) = make_float2(h2f(raw.w3 >> 16), h2f(raw.w4));
         }
         s_m[tid] = mask;
         // the next batch's gathers (entry index -> Splat record, two dependent round trips) fly while this batch
@@ -419,42 +457,36 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
         raw = blend_fetch_raw(p, range, hi_next, tid);
         __syncthreads();
         if (__ballot(T >= T_MIN) != 0ull) {  // a wave whose 64 pixels are saturated only keeps staging
-            // wave-private compaction: slots whose kept ellipse reaches this quadrant, in near -> far order
+            // wave-private compaction: records whose kept ellipse reaches this quadrant, in near -> far order
             uint32_t n = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool t = (s_m[r * 64 + lane] & qbit) != 0u;
                 const unsigned long long bal = __ballot(t);
                 const uint32_t pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                if (t) my_list[pos] = (uint32_t)(r * 64 + lane);
+                if (t) my_list[pos] = (uint32_t)(r * 64 + lane) * 16u;
                 n += (uint32_t)__popcll(bal);
             }
             if (n > 0u) {
-                // two-deep pipeline: slot index of record i+2 and the record i+1 are in flight while i is composited
-                uint32_t k_next = my_list[n > 1u ? 1u : 0u];
-                uint32_t k_cur = my_list[0];
-                float4 g4 = s_g[k_cur], h4 = s_h[k_cur];
-                float2 c2 = s_c[k_cur];
-                for (uint32_t i = 0; i < n; ++i) {
-                    const uint32_t i2 = (i + 2u < n) ? i + 2u : n - 1u;
-                    const uint32_t k_nn = my_list[i2];
-                    const float4 gn = s_g[k_next], hn = s_h[k_next];
-                    const float2 cn = s_c[k_next];
-                    const float p0 = fmaf(g4.x, lx, fmaf(g4.y, ly, g4.z));
-                    const float p1 = fmaf(h4.x, lx, fmaf(h4.y, ly, h4.z));
-                    const float a = fmaf(p0, p0, p1 * p1);
-                    if (a <= CUT_A2) {
-                        const float b = fminf(0.99f, __builtin_amdgcn_exp2f(-a) * g4.w);
-                        const float wgt = b * T;
-                        cr = fmaf(wgt, h4.w, cr);
-                        cg = fmaf(wgt, c2.x, cg);
-                        cb = fmaf(wgt, c2.y, cb);
-                        T -= wgt;
-                    }
-                    k_next = k_nn;
-                    g4 = gn;
-                    h4 = hn;
-                    c2 = cn;
+                if (lane < 4 && ((n + (uint32_t)lane) >> 2) == (n >> 2) && (n & 3u)) my_list[n + lane] = 256u * 16u;  // pad to x4
+                const uint32_t n4 = (n + 3u) >> 2;
+                const uint4* lp = reinterpret_cast<const uint4*>(my_list);
+                // groups of four list entries; the next group's offsets and the next record are in flight while the
+                // current record is composited
+                uint4 o = lp[0];
+                uint4 on = lp[n4 > 1u ? 1u : 0u];
+                BlendRec cur = blend_load_rec(s_rec, o.x);
+                for (uint32_t g = 0; g < n4; ++g) {
+                    const BlendRec r1 = blend_load_rec(s_rec, o.y);
+                    blend_composite(cur, lx, ly, T, cr, cg, cb);
+                    const BlendRec r2 = blend_load_rec(s_rec, o.z);
+                    blend_composite(r1, lx, ly, T, cr, cg, cb);
+                    const BlendRec r3 = blend_load_rec(s_rec, o.w);
+                    blend_composite(r2, lx, ly, T, cr, cg, cb);
+                    cur = blend_load_rec(s_rec, on.x);  // (re-reads a valid record after the last group)
+                    blend_composite(r3, lx, ly, T, cr, cg, cb);
+                    o = on;
+                    on = lp[g + 2u < n4 ? g + 2u : n4 - 1u];
                 }
             }
         }
