@@ -1,0 +1,23 @@
+import os, sys, time
+sys.path[:0] = ["web-splat_amd", "tests", "."]
+import numpy as np, torch
+import websplat as ws, bench
+ctx = ws.Context(0)
+gpc, views, (w, h) = bench.build_workload(ws, "c2", 64)
+pc = ws.PointCloud(ctx, gpc)
+for ns in (1, 4, 8):
+    rs = [ws.GaussianRenderer(ctx, "rgba32float", 3, False) for _ in range(ns)]
+    tg = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(ns)]
+    st = [torch.cuda.current_stream().cuda_stream] + [torch.cuda.Stream().cuda_stream for _ in range(ns - 1)]
+    def frame(i):
+        k = i % ns
+        rs[k].prepare(pc, views[i % 64], stream=st[k]); rs[k].render(pc, target_ptr=tg[k].data_ptr(), stream=st[k])
+    for i in range(20): frame(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(300): frame(i)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"streams {ns}: enqueue {1e6*(t1-t0)/300:.1f} us/frame, total {1e6*(t2-t0)/300:.1f} us/frame")
+    for r in rs: r.close()

@@ -485,6 +485,9 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
                     blend_composite(r2, lx, ly, T, cr, cg, cb);
                     cur = blend_load_rec(s_rec, on.x);  // (re-reads a valid record after the last group)
                     blend_composite(r3, lx, ly, T, cr, cg, cb);
+                    // the quadrant is saturated: nothing behind can add more than T_MIN (one compare per four pairs;
+                    // on dense tiles this stops the walk well inside the 256-entry batch)
+                    if (__ballot(T >= T_MIN) == 0ull) break;
                     o = on;
                     on = lp[g + 2u < n4 ? g + 2u : n4 - 1u];
                 }
