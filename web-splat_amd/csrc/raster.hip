@@ -155,7 +155,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
                                                          uint32_t* __restrict__ entry_vals,
                                                          const FrameCounters* __restrict__ counters,
                                                          uint32_t tiles_x, uint32_t* __restrict__ tile_hist,
-                                                         uint32_t tile_hist_pitch) {
+                                                         uint32_t tile_hist_pitch, uint32_t tile_hist_mask) {
     constexpr int EPT = EMIT_EPT;
     __shared__ uint32_t s_off[EMIT_TILE + 2];
     __shared__ uint32_t s_own[EMIT_TILE + BIN_THREADS];
@@ -248,14 +248,14 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
         const uint32_t key = (y0 + q) * tiles_x + (x0 + rem);
         entry_keys[e] = key;
         entry_vals[e] = sorted_idx[pos];
-        atomicAdd(&s_hist[(key & (RADIX - 1)) * EMIT_COPIES + copy], 1u);
+        atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
     }
     if (tile_hist) {  // digit counts of sort tile blockIdx.x for the tile-id sort's first pass ([digit][tile])
         __syncthreads();
         uint32_t c = 0;
 #pragma unroll
         for (int r = 0; r < EMIT_COPIES; ++r) c += s_hist[tid * EMIT_COPIES + r];
-        tile_hist[(size_t)tid * tile_hist_pitch + slice] = c;
+        if ((uint32_t)tid <= tile_hist_mask) tile_hist[(size_t)tid * tile_hist_pitch + slice] = c;
     }
     __syncthreads();  // LDS is reused by the next slice
     }
@@ -746,7 +746,8 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     if (blocks == 0) return WS_OK;
     if (blocks > 2048u) blocks = 2048u;  // slices are strided over; surplus workgroups are not free
     hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx, b.rects_sorted, b.offsets,
-                       b.emit_start, b.entry_keys, b.entry_vals, b.counters, b.tiles_x, b.tile_hist, b.tile_hist_pitch);
+                       b.emit_start, b.entry_keys, b.entry_vals, b.counters, b.tiles_x, b.tile_hist, b.tile_hist_pitch,
+                       b.tile_hist_mask);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __re
 template <int KPT>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ d_count, uint32_t n,
-                                                                int shift, uint32_t* __restrict__ tile_sums,
+                                                                int shift, uint32_t mask, uint32_t* __restrict__ tile_sums,
                                                                 uint32_t tiles_cap) {
     constexpr int TILE_N = SORT_THREADS * KPT;
     __shared__ uint32_t sh[RADIX * HIST_COPIES];
@@ -146,13 +146,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t*
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
-            if (pos < count) atomicAdd(&sh[((k[j] >> shift) & (RADIX - 1)) * HIST_COPIES + copy], 1u);
+            if (pos < count) atomicAdd(&sh[((k[j] >> shift) & mask) * HIST_COPIES + copy], 1u);
         }
         __syncthreads();
         uint32_t c = 0;
 #pragma unroll
         for (int r = 0; r < HIST_COPIES; ++r) c += sh[threadIdx.x * HIST_COPIES + r];
-        tile_sums[(size_t)threadIdx.x * tiles_cap + t] = c;
+        if (threadIdx.x <= mask) tile_sums[(size_t)threadIdx.x * tiles_cap + t] = c;  // rows of the digits in use
         __syncthreads();
     }
 }
@@ -189,7 +189,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* 
 // a contiguous run of its LDS-ordered tile, so run boundaries are found there and merged across workgroups with
 // two atomicMax per (workgroup, key) pair on ranges[key] = (0xFFFFFFFF - begin, end), zero = empty.  This
 // replaces a separate pass over the sorted keys and the final 4-B-per-entry key write.
-template <bool LOOKBACK, int KPT, bool RANGES>
+// BITS: width of this sort's digits (8 for 32-bit keys; the tile-id sort splits its 12..16 key bits evenly over its
+// passes, e.g. 6 + 6 for 3750 tiles: fewer ballots per key, shorter scans, longer write runs).
+template <bool LOOKBACK, int KPT, bool RANGES, int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ d_count, uint32_t n, int shift, int iota,
@@ -200,6 +202,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     uint32_t tiles_cap, uint32_t epoch, uint32_t* __restrict__ error_word, uint2* __restrict__ ranges,
     uint32_t nranges) {
     constexpr int TILE_N = SORT_THREADS * KPT;
+    constexpr uint32_t DMASK = (1u << BITS) - 1u;
+    static_assert(!LOOKBACK || BITS == RADIX_BITS, "the one-sweep path uses 8-bit digits");
     __shared__ uint32_t s_wave_hist[WAVES][RADIX];
     __shared__ uint32_t s_local_excl[RADIX];
     __shared__ uint32_t s_global_base[RADIX];
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 
     const uint32_t count = device_count(d_count, n);
     // first output position of every digit: the same for all tiles of this pass
-    const uint32_t digit_base = block_exclusive_scan(hist[tid], s_tmp, nullptr);
+    const uint32_t digit_base = block_exclusive_scan((uint32_t)tid <= DMASK ? hist[tid] : 0u, s_tmp, nullptr);
     // Scan path: the grid is capped (sort_grid) and workgroups stride over the tiles.  One-sweep path: the grid is
     // sized for the host-side bound n, only ceil(count / TILE) workgroups have work; the surplus ones leave BEFORE
     // touching the ticket, so exactly the needed number of tickets 0..ntiles-1 is drawn, one tile per workgroup.
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         val[j] = iota ? pos : (pos < count ? vals_in[pos] : 0u);
     }
     uint32_t my_tile_off = 0u;  // issued early: needed only after the ranking
-    if (!LOOKBACK) my_tile_off = tile_off[(size_t)tid * tiles_cap + t];
+    if (!LOOKBACK && (uint32_t)tid <= DMASK) my_tile_off = tile_off[(size_t)tid * tiles_cap + t];
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) s_wave_hist[w][tid] = 0u;
     __syncthreads();
@@ -267,10 +271,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-        const uint32_t d = (key[j] >> shift) & (RADIX - 1);
+        const uint32_t d = (key[j] >> shift) & DMASK;
         uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
 #pragma unroll
-        for (int bit = 0; bit < RADIX_BITS; ++bit) {
+        for (int bit = 0; bit < BITS; ++bit) {
             const uint32_t B = (uint32_t)(-(int32_t)((d >> bit) & 1u));  // all ones if the bit is set
             const unsigned long long bal = __ballot(B != 0u);
             mlo &= ~((uint32_t)bal ^ B);
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     uint32_t prev[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-        const uint32_t d = (key[j] >> shift) & (RADIX - 1);
+        const uint32_t d = (key[j] >> shift) & DMASK;
         prev[j] = 0u;
         if (info[j] >> 16) prev[j] = atomicAdd(&s_wave_hist[wave][d], info[j] >> 16);
     }
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     // ---- reorder keys AND values through LDS (one barrier), write contiguous digit runs -------------------
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-        const uint32_t d = (key[j] >> shift) & (RADIX - 1);
+        const uint32_t d = (key[j] >> shift) & DMASK;
         const uint32_t lpos = s_local_excl[d] + s_wave_hist[wave][d] + rank[j];
         s_keys[lpos] = key[j];
         s_vals[lpos] = val[j];
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         const uint32_t lp = k * SORT_THREADS + tid;
         const uint32_t kk = s_keys[lp];
         const uint32_t vv = s_vals[lp];
-        const uint32_t d = (kk >> shift) & (RADIX - 1);
+        const uint32_t d = (kk >> shift) & DMASK;
         const uint32_t gpos = s_global_base[d] + lp;
         if (lp < valid) {
             vals_out[gpos] = vv;
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     }
 }
 
-template <int KPT>
+template <int KPT, int BITS>
 int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout,
                     const uint32_t* d_count, uint32_t n, int begin_bit, int npass, bool implicit_iota,
                     bool first_tile_hist_ready, uint32_t epoch, hipStream_t stream, uint32_t** fk, uint32_t** fv,
@@ -392,22 +396,22 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
     constexpr uint32_t TILE_N = SORT_THREADS * KPT;
     const uint32_t tiles = sort_grid((n + TILE_N - 1) / TILE_N);
     for (int p = 0; p < npass; ++p) {
-        const int shift = begin_bit + p * RADIX_BITS;
+        const int shift = begin_bit + p * BITS;
         const int iota = (implicit_iota && p == 0) ? 1 : 0;
         if (!(p == 0 && first_tile_hist_ready)) {
             hipLaunchKernelGGL(k_sort_tile_hist<KPT>, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift,
-                               sc.tile_sums, sc.tiles_cap);
+                               (1u << BITS) - 1u, sc.tile_sums, sc.tiles_cap);
             km_mark(km, names[0]);
         }
-        hipLaunchKernelGGL(k_sort_col_scan, dim3(RADIX), dim3(SORT_THREADS), 0, stream, d_count, n, TILE_N, sc.tile_sums,
-                           sc.tiles_cap, sc.hist + p * RADIX);
+        hipLaunchKernelGGL(k_sort_col_scan, dim3(1u << BITS), dim3(SORT_THREADS), 0, stream, d_count, n, TILE_N,
+                           sc.tile_sums, sc.tiles_cap, sc.hist + p * RADIX);
         km_mark(km, names[1]);
         if (ranges && p == npass - 1)
-            hipLaunchKernelGGL((k_sort_scatter<false, KPT, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
+            hipLaunchKernelGGL((k_sort_scatter<false, KPT, true, BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr,
                                (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr, ranges, nranges);
         else
-            hipLaunchKernelGGL((k_sort_scatter<false, KPT, false>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
+            hipLaunchKernelGGL((k_sort_scatter<false, KPT, false, BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr,
                                (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr,
                                (uint2*)nullptr, 0u);
@@ -440,7 +444,7 @@ uint32_t sort_tile_size(uint32_t n) { return n <= SORT_SMALL_MAX ? SORT_THREADS 
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
                       uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km,
-                      const char* tag, uint2* ranges, uint32_t nranges) {
+                      const char* tag, uint2* ranges, uint32_t nranges, int digit_bits) {
     // labels of the per-kernel timers: "<tag>k_sort_..." with tag = "depth:" / "tiles:"
     const bool depth = tag && tag[0] == 'd';
     static const char* const N_DEPTH[4] = {"depth:k_sort_tile_hist", "depth:k_sort_col_scan", "depth:k_sort_scatter",
@@ -452,10 +456,13 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
     if (out_vals) *out_vals = vals;
     if (n == 0) return WS_OK;
     if (n > sc.cap) return fail(WS_ERR_INVALID, "sort: n exceeds the scratch capacity");
-    if ((begin_bit % RADIX_BITS) || (end_bit % RADIX_BITS) || begin_bit < 0 || end_bit > 32 || begin_bit >= end_bit)
-        return fail(WS_ERR_INVALID, "sort: bit range must be non-empty multiples of 8 within [0,32]");
+    if (algo == 1) digit_bits = RADIX_BITS;
+    if (digit_bits < 6 || digit_bits > RADIX_BITS) return fail(WS_ERR_INVALID, "sort: digit width must be 6, 7 or 8 bits");
+    if (begin_bit < 0 || end_bit > 32 || begin_bit >= end_bit)
+        return fail(WS_ERR_INVALID, "sort: bit range must be non-empty and within [0,32]");
     if ((reinterpret_cast<uintptr_t>(keys) & 15u) != 0) return fail(WS_ERR_INVALID, "sort: keys must be 16-byte aligned");
-    const int npass = (end_bit - begin_bit) / RADIX_BITS;
+    const int npass = (end_bit - begin_bit + digit_bits - 1) / digit_bits;
+    if (npass > 4) return fail(WS_ERR_INVALID, "sort: more than four digit passes");
 
     uint32_t* kin = keys;
     uint32_t* vin = vals;
@@ -464,12 +471,18 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
 
     if (algo != 1) {
         int rc;
-        if (sort_tile_size(n) == SORT_TILE)
-            rc = run_passes_scan<SORT_KPT>(sc, kin, vin, kout, vout, d_count, n, begin_bit, npass, implicit_iota,
-                                           first_tile_hist_ready, epoch, stream, &kin, &vin, km, names, ranges, nranges);
-        else
-            rc = run_passes_scan<SORT_KPT_SMALL>(sc, kin, vin, kout, vout, d_count, n, begin_bit, npass, implicit_iota,
-                                                 first_tile_hist_ready, epoch, stream, &kin, &vin, km, names, ranges, nranges);
+        const bool big = sort_tile_size(n) == SORT_TILE;
+#define WS_RUN_SCAN(KPT_, BITS_)                                                                                       \
+    rc = run_passes_scan<KPT_, BITS_>(sc, kin, vin, kout, vout, d_count, n, begin_bit, npass, implicit_iota,          \
+                                      first_tile_hist_ready, epoch, stream, &kin, &vin, km, names, ranges, nranges)
+        if (digit_bits == 8) {
+            if (big) WS_RUN_SCAN(SORT_KPT, 8); else WS_RUN_SCAN(SORT_KPT_SMALL, 8);
+        } else if (digit_bits == 7) {
+            if (big) WS_RUN_SCAN(SORT_KPT, 7); else WS_RUN_SCAN(SORT_KPT_SMALL, 7);
+        } else {
+            if (big) WS_RUN_SCAN(SORT_KPT, 6); else WS_RUN_SCAN(SORT_KPT_SMALL, 6);
+        }
+#undef WS_RUN_SCAN
         if (rc) return rc;
     } else {
         const uint32_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
@@ -484,12 +497,12 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
             const int shift = begin_bit + p * RADIX_BITS;
             const int iota = (implicit_iota && p == 0) ? 1 : 0;
             if (ranges && p == npass - 1)
-                hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
+                hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, true, RADIX_BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
                                    vin, kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX,
                                    sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
                                    0u, epoch, sc.error, ranges, nranges);
             else
-                hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, false>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
+                hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, false, RADIX_BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
                                    vin, kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX,
                                    sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
                                    0u, epoch, sc.error, (uint2*)nullptr, 0u);

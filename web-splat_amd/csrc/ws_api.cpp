@@ -621,17 +621,27 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     const bool fused_hist = r->ctx->sort_algo != 1 && sort_tile_size(r->entry_cap) == (uint32_t)EMIT_TILE;
     bb.tile_hist = fused_hist ? r->sort_tiles.tile_sums : nullptr;
     bb.tile_hist_pitch = r->sort_tiles.tiles_cap;
+    // The tile-id sort is "segmented": only the bits a tile id can have take part, split evenly over the passes
+    // (3750 tiles -> 12 bits -> 6 + 6; 8160 tiles -> 13 bits -> 7 + 6(7); 32400 tiles -> 15 bits -> 8 + 7(8)).
+    const uint32_t ntiles = r->tiles_x * r->tiles_y;
+    int tile_bits = 1;
+    while ((1ull << tile_bits) < ntiles) ++tile_bits;
+    int tile_passes = (tile_bits + RADIX_BITS - 1) / RADIX_BITS;
+    int digit_bits = (tile_bits + tile_passes - 1) / tile_passes;
+    if (digit_bits < 6) digit_bits = 6;
+    if (r->ctx->sort_algo == 1) {  // one-sweep cross-check path: 8-bit digits
+        digit_bits = RADIX_BITS;
+        tile_bits = tile_passes * RADIX_BITS;
+    }
+    bb.tile_hist_mask = (1u << digit_bits) - 1u;
     if ((rc = launch_bin_prefix(bb, stream))) return rc;
     km_mark(km, "k_bin_prefix");
     if ((rc = launch_bin_emit(bb, stream))) return rc;
     km_mark(km, "k_bin_emit");
-    const uint32_t ntiles = r->tiles_x * r->tiles_y;
-    int tile_bits = 8;
-    while ((1ull << tile_bits) < ntiles) tile_bits += 8;
     uint32_t *ek = nullptr, *evv = nullptr;
     if ((rc = launch_sort_pairs(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap, 0,
                                 tile_bits, false, fused_hist, r->ctx->sort_algo, r->epoch, stream, &ek, &evv, km,
-                                "tiles:", r->tile_ranges, ntiles)))
+                                "tiles:", r->tile_ranges, ntiles, digit_bits)))
         return rc;
     r->entries_sorted = evv;  // the last pass wrote the per-tile ranges instead of the sorted tile ids
     if (r->timers) {

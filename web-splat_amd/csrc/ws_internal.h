@@ -115,7 +115,7 @@ struct SortScratch {
 
 // Launch an ascending stable LSD radix sort of (key, value) pairs on `stream`.
 //   d_count == nullptr -> sort n pairs; else the count is read on the device (clamped to n).
-//   begin_bit/end_bit: key bits that participate (multiples of 8).
+//   begin_bit/end_bit: key bits that participate; digit_bits (6..8): digit width, passes = ceil(bits / digit_bits).
 //   implicit_iota: values of the first pass are the element positions (vals in is not read).
 //   first_tile_hist_ready (algo 0): the producer of the keys already wrote the first pass's per-tile digit
 //     counts into sc.tile_sums (layout [digit][tiles_cap], tile = sort_tile_size(n) consecutive keys).
@@ -127,7 +127,8 @@ struct SortScratch {
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
                       uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals,
-                      KernelMarks* km = nullptr, const char* tag = "", uint2* ranges = nullptr, uint32_t nranges = 0);
+                      KernelMarks* km = nullptr, const char* tag = "", uint2* ranges = nullptr, uint32_t nranges = 0,
+                      int digit_bits = RADIX_BITS);
 
 // ---- preprocess ---------------------------------------------------------------------------------
 struct K1Buffers {
@@ -158,7 +159,8 @@ struct BinBuffers {
     uint32_t* entry_keys;        // [cap] tile ids
     uint32_t* entry_vals;        // [cap] store indices
     uint32_t* tile_hist;         // nullptr, or the tile sort's tile_sums: emit workgroup m also writes the digit
-    uint32_t tile_hist_pitch;    //   counts (low 8 bits of the tile id) of sort tile m -> no histogram pass 0
+    uint32_t tile_hist_pitch;    //   counts (first digit of the tile id) of sort tile m -> no histogram pass 0
+    uint32_t tile_hist_mask;     //   (1 << digit bits of the tile sort) - 1
     uint32_t entry_cap;
     uint2* tile_ranges;          // [tiles] (begin, end) into the sorted entry list
     FrameCounters* counters;
