@@ -97,7 +97,10 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_KPT = WS_SORT_KPT;                 // keys per thread
 constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;    // keys per work tile
 constexpr int SORT_KPT_SMALL = 4;                     // small inputs: 1024-key tiles -> 4x the workgroups
-constexpr uint32_t SORT_SMALL_MAX = 2u << 20;         // host-side bound n up to which the small tile is used
+#ifndef WS_SORT_SMALL_MAX
+#define WS_SORT_SMALL_MAX (2u << 20)
+#endif
+constexpr uint32_t SORT_SMALL_MAX = WS_SORT_SMALL_MAX;  // host-side bound n up to which the small tile is used
 uint32_t sort_tile_size(uint32_t n);                  // tile size the scan path (algo 0) uses for bound n
 
 struct SortScratch {
