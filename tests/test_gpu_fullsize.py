@@ -124,3 +124,45 @@ def test_c5_compressed_4k_vs_oracle(ws, ctx, oracle, tmp_path):
     finally:
         r.close()
         pc.close()
+
+
+def test_frames_in_flight_do_not_interfere(ws, ctx, oracle):
+    """bench.py keeps several frames in flight (one renderer + HIP stream each, shared scene): every image must
+    equal the one rendered alone."""
+    import ctypes as C
+    sc = scenes.c2(ws, oracle, n=400_000, viewport=(1200, 799))
+    cams = synth.orbit_cameras(64, 1200, 799, 1200.0, 1200.0)
+    views = []
+    for cj in cams[:6]:
+        cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, 1200, 799)
+        cam.fit_near_far(sc.gpc.aabb)
+        views.append(ws.SplattingArgs(camera=cam, viewport=(1200, 799), max_sh_deg=3))
+    pc = ws.PointCloud(ctx, sc.gpc)
+    hip = C.CDLL("libamdhip64.so")
+    n = 3
+    rs = [ws.GaussianRenderer(ctx, "rgba32float", 3, False) for _ in range(n)]
+    streams = []
+    for _ in range(n):
+        s = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0  # hipStreamNonBlocking
+        streams.append(s)
+    try:
+        alone = []
+        for v in views:
+            rs[0].prepare(pc, v)
+            rs[0].render(pc)
+            alone.append(rs[0].download_target())
+        for rep in range(3):
+            for base in (0, 3):
+                for k in range(n):          # enqueue three frames back to back on three streams, no sync in between
+                    rs[k].prepare(pc, views[base + k], stream=streams[k].value)
+                    rs[k].render(pc, stream=streams[k].value)
+                for k in range(n):
+                    ctx.sync(streams[k].value)
+                    assert np.array_equal(rs[k].download_target(), alone[base + k]), (rep, base, k)
+    finally:
+        for r in rs:
+            r.close()
+        for s in streams:
+            hip.hipStreamDestroy(s)
+        pc.close()
