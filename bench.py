@@ -19,6 +19,7 @@ Workloads (BASELINE.json configs):
   hd1m          the north-star headline: same distribution, 1 M Gaussians, 1920x1080
   c3            5 M Gaussians, 1920x1080 (sort stress)
   c1            10 k Gaussians, 800x600
+  c5            compressed c3dgs .npz (native loader), 1 M Gaussians, 3840x2160
 """
 import argparse
 import json
@@ -48,9 +49,23 @@ def build_workload(ws, name, n_views):
     elif name == "c1":
         rows, (w, h) = synth.scene_c1(n=10_000, seed=0), (800, 600)
         cams = [synth.camera_c1(w, h)] * n_views
+    elif name == "c5":
+        # BASELINE config 5: compressed c3dgs scene at 3840x2160, written as a real .npz and read back by the
+        # library's native loader (io/npz.rs path)
+        import tempfile
+        w, h = 3840, 2160
+        a = synth.c3dgs_arrays(n=1_000_000, n_geometry=4096, n_sh=4096, seed=3, sh_deg=3, extent=1.0)
+        a["scaling_factor_zero_point"] = np.array(390, dtype=np.int32)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "c5.npz")
+            synth.write_npz(path, a)
+            gpc = ws.read_npz(path)
+        cams = synth.orbit_cameras(n_views, w, h, 3000.0, 3000.0, radius=3.2, height_off=0.6)
+        rows = None
     else:
         raise SystemExit(f"unknown workload {name}")
-    gpc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
+    if rows is not None:
+        gpc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
     args = []
     for cj in cams:
         cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, cj.width, cj.height)
@@ -68,11 +83,23 @@ def cpu_baseline(gpc, arg, viewport, budget_s=20.0):
     w, h = viewport
     cu = oracle.camera_uniform(cam, w, h)
     rs = oracle.settings_uniform(oracle.make_aabb(gpc.aabb.min, gpc.aabb.max), gpc.center)
-    oracle.render_frame(gpc.gaussians, gpc.sh_coefs, cu, rs, w, h)  # warm-up (page-in, thread pool)
+    if gpc.compressed:
+        q = gpc.quantization
+        oq = oracle.make_quantization({n: (getattr(q, n).zero_point, getattr(q, n).scale)
+                                       for n in ("color_dc", "color_rest", "opacity", "scaling_factor")})
+
+        def one_frame():
+            splats, keys, _ = oracle.preprocess_compressed(gpc.gaussians, gpc.sh_coefs, gpc.covars, oq, gpc.sh_deg, cu, rs)
+            _, order = oracle.sort_pairs(keys, np.arange(len(keys), dtype=np.uint32))
+            oracle.render(splats, order, w, h, (0, 0, 0, 0), 0)
+    else:
+        def one_frame():
+            oracle.render_frame(gpc.gaussians, gpc.sh_coefs, cu, rs, w, h)
+    one_frame()  # warm-up (page-in, thread pool)
     t0 = time.perf_counter()
     frames = 0
     while True:
-        oracle.render_frame(gpc.gaussians, gpc.sh_coefs, cu, rs, w, h)
+        one_frame()
         frames += 1
         dt = time.perf_counter() - t0
         if dt > budget_s or frames >= 10:
@@ -119,7 +146,7 @@ def main():
     tdtype = {"rgba32float": torch.float32, "rgba16float": torch.float16, "rgba8unorm": torch.uint8}[a.format]
     # one renderer (private scratch), one output image and one HIP stream per frame in flight; the scene is shared
     nstreams = max(1, a.streams)
-    renderers = [ws.GaussianRenderer(ctx, a.format, 3, False) for _ in range(nstreams)]
+    renderers = [ws.GaussianRenderer(ctx, a.format, gpc.sh_deg, gpc.compressed) for _ in range(nstreams)]
     targets = [torch.empty((h, w, 4), dtype=tdtype, device="cuda") for _ in range(nstreams)]
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
     streams = [s_.cuda_stream for s_ in tstreams]
@@ -199,7 +226,9 @@ def main():
         # D (tile, splat) entries.  A radix pass over M pairs reads and writes 8 B per pair: 16*M; the histogram
         # kernels read 4*M; the last tile-id pass does not write the keys (12*D).
         alg = {
+            # K1c: 24 B record for all, 12 B covariance + 3*(deg+1)^2 B SH gathers and 28 B out for survivors
             "k_preprocess": n * 124 + V * 28,
+            "k_preprocess<compressed>": n * 24 + V * (12 + 3 * (gpc.sh_deg + 1) ** 2) + V * 28,
             "depth:k_sort_tile_hist": 4 * V, "depth:k_sort_col_scan": None, "depth:k_sort_scatter": 16 * V,
             "depth:k_sort_hist": 4 * V,
             "k_bin_prefix": V * (4 + 8) + V * (8 + 4),

@@ -177,3 +177,11 @@ def test_golden_sort_fixture(oracle):
     k, _ = oracle.sort_pairs(keys_in, np.arange(n, dtype=np.uint32))
     assert [int(x) for x in k[:8]] == g["first8_out_bits"]
     assert np.array_equal(k.view(np.float32), np.arange(n, dtype=np.float32))
+
+
+def test_snorm_times_127_is_a_clamp():
+    """preprocess_compressed.wgsl:147-171: unpack4x8snorm(x) * 127 = max(x / 127, -1) * 127 in f32 returns every int8
+    exactly (and -128 -> -127): the identity K1c relies on to drop the 48 divisions per Gaussian."""
+    x = np.arange(-128, 128).astype(np.float32)
+    y = (np.maximum(x / np.float32(127.0), np.float32(-1.0)) * np.float32(127.0)).astype(np.float32)
+    assert np.array_equal(y, np.maximum(x, np.float32(-127.0)))
