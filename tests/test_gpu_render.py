@@ -257,3 +257,23 @@ def test_ply_file_roundtrip(ws, ctx, oracle, tmp_path):
             _assert_close(img, ref)
         finally:
             pc.close()
+
+
+@pytest.mark.parametrize("env", [{"WS_SORT_ALGO": "1"}, {"WS_BLEND_VARIANT": "1"}, {"WS_SORT_ALGO": "1", "WS_BLEND_VARIANT": "1"}])
+def test_cross_check_paths(ws, oracle, env, monkeypatch):
+    """The alternative implementations kept as cross-checks (one-sweep look-back sort, wave-per-quadrant blend) must
+    give the same image as the default path: a context reads the selection from the environment when it is created."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = ws.Context(0)
+    try:
+        sc = scenes.c1(ws, oracle, n=20_000, viewport=(640, 480), seed=12)
+        pc, img, stats = _render(ws, c, sc)
+        try:
+            ref, _ = sc.oracle_image(pc)
+            _assert_close(img, ref)
+            assert stats["overflow"] == 0
+        finally:
+            pc.close()
+    finally:
+        c.close()
