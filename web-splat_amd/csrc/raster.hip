@@ -293,23 +293,40 @@ __device__ __forceinline__ bool ellipse_reaches_box(float A, float B2, float C, 
     return q <= cut * 1.0001f + 1e-4f;
 }
 
-// blockIdx -> tile.  4x4-tile blocks (64x64 px) are dealt round-robin to the 8 XCDs (workgroup b runs on XCD
+// blockIdx -> tiles.  4x4-tile blocks (64x64 px) are dealt round-robin to the 8 XCDs (workgroup b runs on XCD
 // b % 8 -- observed, used for locality only): a splat's tiles mostly share a block, so its 20-B record and the
 // neighbouring entry lists are served by ONE L2, while every XCD gets blocks from all over the image.
-__device__ __forceinline__ bool blend_tile_of_block(uint32_t b, uint32_t tiles_x, uint32_t tiles_y, uint32_t* tx,
-                                                    uint32_t* ty) {
+// A workgroup composites `tpw` = 2^tpw_log2 tiles of its block one after the other (the block's 16 tiles are split
+// over 16 / tpw workgroups, interleaved): with tens of thousands of tiles (4K) one workgroup per tile is bound by the
+// three dependent loads each workgroup starts with; here the next tile's loads are in flight while the current tile
+// is composited.
+struct BlendBlock {
+    uint32_t bx, by;   // 4x4-tile block coordinates
+    uint32_t w;        // this workgroup's lane inside the block: it owns tile slots w, w + wpb, w + 2 wpb, ...
+    bool valid;
+};
+__device__ __forceinline__ BlendBlock blend_block_of(uint32_t b, uint32_t tiles_x, uint32_t tiles_y, uint32_t tpw_log2) {
     const uint32_t nbx = (tiles_x + 3u) >> 2, nby = (tiles_y + 3u) >> 2;
+    const uint32_t wpb = 16u >> tpw_log2;
     const uint32_t xcd = b & 7u, j = b >> 3;
-    const uint32_t blk = (j >> 4) * 8u + xcd;
-    if (blk >= nbx * nby) return false;
-    const uint32_t bx = blk % nbx, by = blk / nbx;
-    *tx = bx * 4u + (j & 3u);
-    *ty = by * 4u + ((j >> 2) & 3u);
-    return *tx < tiles_x && *ty < tiles_y;
+    const uint32_t blk = (j / wpb) * 8u + xcd;
+    BlendBlock r;
+    r.w = j % wpb;
+    r.valid = blk < nbx * nby;
+    r.bx = r.valid ? blk % nbx : 0u;
+    r.by = r.valid ? blk / nbx : 0u;
+    return r;
 }
-__host__ __device__ inline uint32_t blend_grid_blocks(uint32_t tiles_x, uint32_t tiles_y) {
+__host__ __device__ inline uint32_t blend_grid_blocks(uint32_t tiles_x, uint32_t tiles_y, uint32_t tpw_log2) {
     const uint32_t nb = ((tiles_x + 3u) >> 2) * ((tiles_y + 3u) >> 2);
-    return ((nb + 7u) / 8u) * 8u * 16u;
+    return ((nb + 7u) / 8u) * 8u * (16u >> tpw_log2);
+}
+// Tiles per workgroup, measured on MI355X (WS_BLEND_TPW_LOG2 overrides): one tile per workgroup gives the lowest
+// frame latency up to 1080p (more tiles per workgroup serialise the per-tile barriers: 65 -> 76 us on c2 at two
+// tiles); at 4K-class tile counts (32 k tiles, mostly short lists) four tiles per workgroup are as fast alone and 4 %
+// faster with several frames in flight.
+inline uint32_t blend_tpw_log2(uint32_t tiles_x, uint32_t tiles_y) {
+    return (tiles_x * tiles_y > 16384u) ? 2u : 0u;
 }
 
 template <int FORMAT>
@@ -387,43 +404,73 @@ __device__ __forceinline__ void blend_composite(const BlendRec& r, float lx, flo
 }
 
 template <int FORMAT>
-__global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
+__global__ __launch_bounds__(256) void k_blend(const BlendParams p, const uint32_t tpw_log2) {
     __shared__ float4 s_rec[3 * BLEND_SLOTS];
     __shared__ uint32_t s_m[256];  // quadrant bits of the staged record (0 = slot unused)
     // per wave: byte offsets of the staged records that reach its quadrant, near -> far, padded with the null record
     __shared__ __attribute__((aligned(16))) uint32_t s_list[4][272];
+    __shared__ uint2 s_range[16];   // [begin, end) of this workgroup's tiles in the sorted entry list
+    __shared__ uint32_t s_txy[16];  // tx | ty << 16, or 0xFFFFFFFF for a slot outside the image
 
-    uint32_t tx, ty;
-    if (!blend_tile_of_block(blockIdx.x, p.tiles_x, p.tiles_y, &tx, &ty)) return;  // block-uniform
-    const uint32_t tile = ty * p.tiles_x + tx;
+    const BlendBlock blk = blend_block_of(blockIdx.x, p.tiles_x, p.tiles_y, tpw_log2);
+    if (!blk.valid) return;  // block-uniform
+    const uint32_t tpw = 1u << tpw_log2, wpb = 16u >> tpw_log2;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int qx = wave & 1, qy = wave >> 1;
     const float lx = (float)(qx * 8 + (lane & 7)) + 0.5f;  // tile-local pixel centre
     const float ly = (float)(qy * 8 + (lane >> 3)) + 0.5f;
-    const uint32_t px = tx * TILE + qx * 8 + (lane & 7);
-    const uint32_t py = ty * TILE + qy * 8 + (lane >> 3);
-    const bool inside = px < p.width && py < p.height;
     const uint32_t qbit = 1u << wave;
+    if ((uint32_t)tid < tpw) {  // the ranges of all my tiles up front: one round trip instead of one per tile
+        const uint32_t slot = blk.w + (uint32_t)tid * wpb;
+        const uint32_t tx = blk.bx * 4u + (slot & 3u), ty = blk.by * 4u + (slot >> 2);
+        uint2 range = make_uint2(0u, 0u);
+        uint32_t code = 0xFFFFFFFFu;
+        if (tx < p.tiles_x && ty < p.tiles_y) {
+            code = tx | (ty << 16);
+            range = p.tile_ranges[ty * p.tiles_x + tx];
+            range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
+        }
+        s_range[tid] = range;
+        s_txy[tid] = code;
+    }
     if (tid == 0) {  // the null record: a' = 1e18, never inside the cut-off (visible after the first barrier)
         s_rec[256] = make_float4(0.0f, 0.0f, 1.0e9f, 0.0f);
         s_rec[BLEND_SLOTS + 256] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         s_rec[2 * BLEND_SLOTS + 256] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+    __syncthreads();
+    const float W = (float)p.width, H = (float)p.height;
+    uint32_t* my_list = s_list[wave];
 
-    uint2 range = p.tile_ranges[tile];
-    range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
+    RawSplat raw = {0u, 0u, 0u, 0u, 0u};
+    {
+        const uint2 r0 = s_range[0];
+        if (r0.y > r0.x) raw = blend_fetch_raw(p, r0, r0.y, tid);  // (an empty tile must not touch the entry list)
+    }
+    for (uint32_t k = 0; k < tpw; ++k) {
+    const uint32_t code = s_txy[k];
+    const uint2 range = s_range[k];
+    // the first batch of the NEXT tile (entry index -> Splat record: two dependent round trips) flies while this
+    // tile is composited
+    RawSplat raw_next_tile = {0u, 0u, 0u, 0u, 0u};
+    if (k + 1u < tpw) {
+        const uint2 rn = s_range[k + 1u];
+        if (rn.y > rn.x) raw_next_tile = blend_fetch_raw(p, rn, rn.y, tid);
+    }
+    if (code != 0xFFFFFFFFu) {  // block-uniform
+    const uint32_t tx = code & 0xFFFFu, ty = code >> 16;
+    const uint32_t tile = ty * p.tiles_x + tx;
+    const uint32_t px = tx * TILE + qx * 8 + (lane & 7);
+    const uint32_t py = ty * TILE + qy * 8 + (lane >> 3);
+    const bool inside = px < p.width && py < p.height;
     // Pixels outside the image start with T = 0: they accumulate nothing and count as saturated.  There is no
     // per-pixel "done" flag in the inner loop: a pixel below T_MIN keeps accumulating (its contributions are
     // below T_MIN, the reference has no cut-off at all); T only decides when a wave / the tile may stop.
     float T = inside ? 1.0f : 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    const float W = (float)p.width, H = (float)p.height;
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
-    uint32_t* my_list = s_list[wave];
 
     uint32_t hi = range.y;
-    RawSplat raw = {0u, 0u, 0u, 0u, 0u};
-    if (hi > range.x) raw = blend_fetch_raw(p, range, hi, tid);  // (an empty tile must not touch the entry list)
     while (hi > range.x) {
         const uint32_t nb = (hi - range.x) < 256u ? (hi - range.x) : 256u;
         uint32_t mask = 0u;
@@ -451,10 +498,9 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
             *reinterpret_cast<float2*>(&s_rec[2 * BLEND_SLOTS + tid]) = make_float2(h2f(raw.w3 >> 16), h2f(raw.w4));
         }
         s_m[tid] = mask;
-        // the next batch's gathers (entry index -> Splat record, two dependent round trips) fly while this batch
-        // is composited; wasted only when the tile saturates first
+        // the next batch's gathers fly while this batch is composited; wasted only when the tile saturates first
         const uint32_t hi_next = hi - nb;
-        raw = blend_fetch_raw(p, range, hi_next, tid);
+        if (hi_next > range.x) raw = blend_fetch_raw(p, range, hi_next, tid);
         __syncthreads();
         if (__ballot(T >= T_MIN) != 0ull) {  // a wave whose 64 pixels are saturated only keeps staging
             // wave-private compaction: records whose kept ellipse reaches this quadrant, in near -> far order
@@ -503,6 +549,10 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p) {
         store_pixel<FORMAT>(p, px, py, cr + p.background[0] * T, cg + p.background[1] * T, cb + p.background[2] * T,
                             (1.0f - T) + p.background[3] * T);
     }
+    }  // tile inside the image
+    raw = raw_next_tile;
+    __syncthreads();  // the staging buffers are reused by the next tile
+    }  // tiles of this workgroup
 }
 
 // ---- k_blend_q: one WAVE per 8x8 quadrant, no LDS, no barriers -------------------------------------------
@@ -773,16 +823,17 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
         WS_HIP(hipGetLastError());
         return WS_OK;
     }
-    const uint32_t grid = blend_grid_blocks(p.tiles_x, p.tiles_y);
+    const uint32_t tpw_log2 = p.tpw_log2 >= 0 ? (uint32_t)p.tpw_log2 : blend_tpw_log2(p.tiles_x, p.tiles_y);
+    const uint32_t grid = blend_grid_blocks(p.tiles_x, p.tiles_y, tpw_log2);
     switch (p.format) {
         case WS_FORMAT_RGBA32_FLOAT:
-            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA32_FLOAT>, dim3(grid), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA32_FLOAT>, dim3(grid), dim3(256), 0, stream, p, tpw_log2);
             break;
         case WS_FORMAT_RGBA16_FLOAT:
-            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA16_FLOAT>, dim3(grid), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA16_FLOAT>, dim3(grid), dim3(256), 0, stream, p, tpw_log2);
             break;
         case WS_FORMAT_RGBA8_UNORM:
-            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA8_UNORM>, dim3(grid), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA8_UNORM>, dim3(grid), dim3(256), 0, stream, p, tpw_log2);
             break;
         default:
             return fail(WS_ERR_INVALID, "blend: unknown colour format");

@@ -278,6 +278,8 @@ int ws_context_create(int hip_device, ws_context** out) {
     WS_HIP(hipGetDeviceProperties(&ctx->props, hip_device));
     ctx->sort_algo = env_int("WS_SORT_ALGO", 0);
     ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
+    ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
+    if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
     *out = ctx;
     return WS_OK;
 }
@@ -676,6 +678,7 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.out = d_rgba_out;
     bp.pitch = row_pitch_bytes;
     bp.format = (int)r->format;
+    bp.tpw_log2 = r->ctx->blend_tpw_log2;
     bp.debug_consumed = r->capture ? r->debug_consumed : nullptr;
     if (bp.debug_consumed)
         WS_HIP(hipMemsetAsync(r->debug_consumed, 0, (size_t)r->tiles_x * r->tiles_y * sizeof(uint32_t), stream));

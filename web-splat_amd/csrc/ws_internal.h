@@ -184,6 +184,7 @@ struct BlendParams {
     void* out;
     size_t pitch;
     int format;
+    int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
     uint32_t* debug_consumed;   // nullptr, or [tiles]: entries of each tile's list the blend walked (capture mode)
 };
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
@@ -206,6 +207,7 @@ struct ws_context {
     hipDeviceProp_t props;
     int sort_algo = 0;    // 0 = tile histograms -> column scan -> scatter (default), 1 = one-sweep (look-back)
     int blend_variant = 0;
+    int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
 };
 
 struct ws_pointcloud {
