@@ -185,3 +185,56 @@ def test_snorm_times_127_is_a_clamp():
     x = np.arange(-128, 128).astype(np.float32)
     y = (np.maximum(x / np.float32(127.0), np.float32(-1.0)) * np.float32(127.0)).astype(np.float32)
     assert np.array_equal(y, np.maximum(x, np.float32(-127.0)))
+
+
+def test_sh_basis_is_the_real_spherical_harmonics(oracle):
+    """Pins the oracle's SH evaluation (preprocess.wgsl:4-23 constants, 124-154 polynomials) against an independent
+    source: scipy's spherical harmonics.  With a one-hot coefficient k = l^2 + l + m the colour minus 0.5 must be
+    (up to the fixed sign convention of 3D Gaussian splatting) the real harmonic Y_lm of the view direction."""
+    import scipy.special as sp
+
+    def sph_harm(m, l, az, pol):  # complex Y_l^m; scipy renamed the function (and swapped the argument order) in 1.15
+        if hasattr(sp, "sph_harm_y"):
+            return sp.sph_harm_y(l, m, pol, az)
+        return sp.sph_harm(m, l, az, pol)
+
+    def real_sh(l, m, d):
+        x, y, z = d
+        az, pol = np.arctan2(y, x), np.arccos(z / np.linalg.norm(d))
+        if m == 0:
+            return float(sph_harm(0, l, az, pol).real)
+        ylm = sph_harm(abs(m), l, az, pol)
+        return float(np.sqrt(2.0) * (-1.0) ** m * (ylm.real if m > 0 else ylm.imag))
+
+    amp = 0.25
+    rng = np.random.default_rng(5)
+    cam = oracle.make_camera([0.0, 0.0, -4.0], [1.0, 0.0, 0.0, 0.0], 0.9, 0.9, 0.1, 100.0, 1.0)
+    cu = oracle.camera_uniform(cam, 400, 400)
+    signs = {}
+    for trial in range(6):
+        pos = rng.uniform(-0.8, 0.8, size=3).astype(np.float32)
+        d = pos.astype(np.float64) - np.array([0.0, 0.0, -4.0])
+        d /= np.linalg.norm(d)
+        n = 16
+        g = np.zeros((n, 28), dtype=np.uint8)
+        sh = np.zeros((n, 48), dtype=np.float16)
+        for k in range(n):
+            g[k, 0:12] = pos.view(np.uint8)
+            g[k, 12:14] = np.array([1.0], dtype=np.float16).view(np.uint8)                 # opacity
+            g[k, 16:28] = np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], dtype=np.float16).view(np.uint8)  # small isotropic
+            sh[k, 3 * k] = amp                                                              # red channel of coefficient k
+        rs = oracle.settings_uniform(oracle.make_aabb([-1, -1, -1], [1, 1, 1]), [0.0, 0.0, 0.0], max_sh_deg=3)
+        splats, keys, src = oracle.preprocess(g, sh.view(np.uint8).reshape(n, 96), cu, rs)
+        assert len(keys) == n
+        red = splats.view(np.float16).reshape(n, 10)[:, 6].astype(np.float64)[np.argsort(src)]
+        for k in range(n):
+            l = int(np.sqrt(k))
+            m = k - l * l - l
+            got = (red[k] - 0.5) / amp
+            want = real_sh(l, m, d)
+            assert abs(abs(got) - abs(want)) < 1.2e-2, (k, l, m, got, want)   # f16 colour: 1e-3 / amp
+            if abs(want) > 0.1:
+                signs.setdefault(k, set()).add(int(np.sign(got * want)))
+    # the sign convention is a property of the basis, not of the direction; 3DGS carries the Condon-Shortley phase
+    assert all(len(v) == 1 for v in signs.values()), signs
+    assert signs[0] == {1} and signs[2] == {1} and signs[1] == {-1} and signs[3] == {-1}
