@@ -278,6 +278,7 @@ int ws_context_create(int hip_device, ws_context** out) {
     WS_HIP(hipGetDeviceProperties(&ctx->props, hip_device));
     ctx->sort_algo = env_int("WS_SORT_ALGO", 0);
     ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
+    ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
     if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
     *out = ctx;
@@ -593,6 +594,13 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     km_mark(km, pc->compressed ? "k_preprocess<compressed>" : "k_preprocess");
     if (r->timers) WS_HIP(hipEventRecord(r->ev[1], stream));
 
+    const int cut = r->ctx->debug_cut;
+    if (cut == 1) {  // analysis only (WS_DEBUG_CUT): the image is NOT produced
+        r->prepared = true;
+        r->prepared_pc = pc;
+        r->last_stream = stream;
+        return WS_OK;
+    }
     // depth sort: V (key, store index) pairs, 4 x 8 bit, values start as iota (preprocess.wgsl:274)
     uint32_t *sk = nullptr, *sv = nullptr;
     if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
@@ -600,6 +608,12 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         return rc;
     r->sorted_idx = sv;
     if (r->timers) WS_HIP(hipEventRecord(r->ev[2], stream));
+    if (cut == 2) {  // analysis only (WS_DEBUG_CUT): the image is NOT produced
+        r->prepared = true;
+        r->prepared_pc = pc;
+        r->last_stream = stream;
+        return WS_OK;
+    }
 
     // tile binning
     BinBuffers bb;
@@ -640,6 +654,12 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     km_mark(km, "k_bin_prefix");
     if ((rc = launch_bin_emit(bb, stream))) return rc;
     km_mark(km, "k_bin_emit");
+    if (cut == 3) {
+        r->prepared = true;
+        r->prepared_pc = pc;
+        r->last_stream = stream;
+        return WS_OK;
+    }
     uint32_t *ek = nullptr, *evv = nullptr;
     if ((rc = launch_sort_pairs(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap, 0,
                                 tile_bits, false, fused_hist, r->ctx->sort_algo, r->epoch, stream, &ek, &evv, km,
@@ -685,6 +705,7 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     KernelMarks* km = r->marks.active ? &r->marks : nullptr;
     if (km) km->begin(stream, false);
     if (r->timers) WS_HIP(hipEventRecord(r->ev[4], stream));
+    if (r->ctx->debug_cut >= 1 && r->ctx->debug_cut <= 4) return WS_OK;  // analysis only
     int rc = launch_blend(bp, r->ctx->blend_variant, stream);
     if (rc) return rc;
     km_mark(km, "k_blend");
