@@ -176,7 +176,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
                                                          uint32_t* __restrict__ entry_vals,
                                                          const FrameCounters* __restrict__ counters,
                                                          uint32_t tiles_x, uint32_t* __restrict__ tile_hist,
-                                                         uint32_t tile_hist_pitch, uint32_t tile_hist_mask) {
+                                                         uint32_t tile_hist_pitch, uint32_t tile_hist_mask, int key16) {
     constexpr int EPT = EMIT_EPT;
     __shared__ uint32_t s_off[EMIT_TILE + 2];
     __shared__ uint32_t s_own[EMIT_TILE + BIN_THREADS];
@@ -267,7 +267,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
         if (rem >= w) { q += 1u; rem -= w; }
         if (k >= (1u << 23)) { q = k / w; rem = k % w; }  // exactness of the float path ends at 2^23
         const uint32_t key = (y0 + q) * tiles_x + (x0 + rem);
-        entry_keys[e] = key;
+        if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
+        else entry_keys[e] = key;
         entry_vals[e] = sorted_idx[pos];
         atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
     }
@@ -821,7 +822,7 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     if (blocks > 2048u) blocks = 2048u;  // slices are strided over; surplus workgroups are not free
     hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx, b.rects_sorted, b.offsets,
                        b.emit_start, b.entry_keys, b.entry_vals, b.counters, b.tiles_x, b.tile_hist, b.tile_hist_pitch,
-                       b.tile_hist_mask);
+                       b.tile_hist_mask, b.key16);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }

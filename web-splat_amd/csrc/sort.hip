@@ -123,7 +123,7 @@ template <int KPT>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ d_count, uint32_t n,
                                                                 int shift, uint32_t mask, uint32_t* __restrict__ tile_sums,
-                                                                uint32_t tiles_cap) {
+                                                                uint32_t tiles_cap, int key16) {
     constexpr int TILE_N = SORT_THREADS * KPT;
     __shared__ uint32_t sh[RADIX * HIST_COPIES];
     const uint32_t count = device_count(d_count, n);
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t*
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
-            k[j] = keys[pos < count ? pos : count - 1u];
+            const uint32_t q = pos < count ? pos : count - 1u;
+            k[j] = key16 ? (uint32_t)reinterpret_cast<const uint16_t*>(keys)[q] : keys[q];
         }
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     uint32_t* __restrict__ ticket,         // tile dispenser, zero on entry                  (LOOKBACK)
     const uint32_t* __restrict__ tile_off, // [256][tiles_cap] exclusive offsets per digit   (!LOOKBACK)
     uint32_t tiles_cap, uint32_t epoch, uint32_t* __restrict__ error_word, uint2* __restrict__ ranges,
-    uint32_t nranges) {
+    uint32_t nranges, int key16) {  // key16: the key arrays hold uint16_t (tile ids below 65535): 2 B less per entry
     constexpr int TILE_N = SORT_THREADS * KPT;
     constexpr uint32_t DMASK = (1u << BITS) - 1u;
     static_assert(!LOOKBACK || BITS == RADIX_BITS, "the one-sweep path uses 8-bit digits");
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const uint32_t pos = wave_base + j * 64;
-        key[j] = pos < count ? keys_in[pos] : 0xFFFFFFFFu;
+        key[j] = pos < count ? (key16 ? (uint32_t)reinterpret_cast<const uint16_t*>(keys_in)[pos] : keys_in[pos])
+                             : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
@@ -374,7 +376,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         if (lp < valid) {
             vals_out[gpos] = vv;
             if (!RANGES) {
-                keys_out[gpos] = kk;
+                if (key16) reinterpret_cast<uint16_t*>(keys_out)[gpos] = (uint16_t)kk;
+                else keys_out[gpos] = kk;
             } else if (kk < nranges) {
                 const uint32_t prev_k = lp > 0u ? s_keys[lp - 1u] : ~kk;
                 const uint32_t next_k = lp + 1u < valid ? s_keys[lp + 1u] : ~kk;
@@ -392,7 +395,7 @@ template <int KPT, int BITS>
 int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout,
                     const uint32_t* d_count, uint32_t n, int begin_bit, int npass, bool implicit_iota,
                     bool first_tile_hist_ready, uint32_t epoch, hipStream_t stream, uint32_t** fk, uint32_t** fv,
-                    KernelMarks* km, const char* const* names, uint2* ranges, uint32_t nranges) {
+                    KernelMarks* km, const char* const* names, uint2* ranges, uint32_t nranges, bool key16) {
     constexpr uint32_t TILE_N = SORT_THREADS * KPT;
     const uint32_t tiles = sort_grid((n + TILE_N - 1) / TILE_N);
     for (int p = 0; p < npass; ++p) {
@@ -400,7 +403,7 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
         const int iota = (implicit_iota && p == 0) ? 1 : 0;
         if (!(p == 0 && first_tile_hist_ready)) {
             hipLaunchKernelGGL(k_sort_tile_hist<KPT>, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift,
-                               (1u << BITS) - 1u, sc.tile_sums, sc.tiles_cap);
+                               (1u << BITS) - 1u, sc.tile_sums, sc.tiles_cap, key16 ? 1 : 0);
             km_mark(km, names[0]);
         }
         hipLaunchKernelGGL(k_sort_col_scan, dim3(1u << BITS), dim3(SORT_THREADS), 0, stream, d_count, n, TILE_N,
@@ -409,12 +412,13 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
         if (ranges && p == npass - 1)
             hipLaunchKernelGGL((k_sort_scatter<false, KPT, true, BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr,
-                               (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr, ranges, nranges);
+                               (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr, ranges, nranges,
+                               key16 ? 1 : 0);
         else
             hipLaunchKernelGGL((k_sort_scatter<false, KPT, false, BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr,
                                (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr,
-                               (uint2*)nullptr, 0u);
+                               (uint2*)nullptr, 0u, key16 ? 1 : 0);
         km_mark(km, names[2]);
         WS_HIP(hipGetLastError());
         uint32_t* tk = kin;
@@ -444,7 +448,7 @@ uint32_t sort_tile_size(uint32_t n) { return n <= SORT_SMALL_MAX ? SORT_THREADS 
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
                       uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km,
-                      const char* tag, uint2* ranges, uint32_t nranges, int digit_bits) {
+                      const char* tag, uint2* ranges, uint32_t nranges, int digit_bits, bool key16) {
     // labels of the per-kernel timers: "<tag>k_sort_..." with tag = "depth:" / "tiles:"
     const bool depth = tag && tag[0] == 'd';
     static const char* const N_DEPTH[4] = {"depth:k_sort_tile_hist", "depth:k_sort_col_scan", "depth:k_sort_scatter",
@@ -457,6 +461,8 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
     if (n == 0) return WS_OK;
     if (n > sc.cap) return fail(WS_ERR_INVALID, "sort: n exceeds the scratch capacity");
     if (algo == 1) digit_bits = RADIX_BITS;
+    if (algo == 1 && key16) return fail(WS_ERR_INVALID, "sort: 16-bit keys are a feature of the scan path");
+    if (key16 && end_bit > 16) return fail(WS_ERR_INVALID, "sort: 16-bit keys with more than 16 key bits");
     if (digit_bits < 6 || digit_bits > RADIX_BITS) return fail(WS_ERR_INVALID, "sort: digit width must be 6, 7 or 8 bits");
     if (begin_bit < 0 || end_bit > 32 || begin_bit >= end_bit)
         return fail(WS_ERR_INVALID, "sort: bit range must be non-empty and within [0,32]");
@@ -474,7 +480,8 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
         const bool big = sort_tile_size(n) == SORT_TILE;
 #define WS_RUN_SCAN(KPT_, BITS_)                                                                                       \
     rc = run_passes_scan<KPT_, BITS_>(sc, kin, vin, kout, vout, d_count, n, begin_bit, npass, implicit_iota,          \
-                                      first_tile_hist_ready, epoch, stream, &kin, &vin, km, names, ranges, nranges)
+                                      first_tile_hist_ready, epoch, stream, &kin, &vin, km, names, ranges, nranges, \
+                                      key16)
         if (digit_bits == 8) {
             if (big) WS_RUN_SCAN(SORT_KPT, 8); else WS_RUN_SCAN(SORT_KPT_SMALL, 8);
         } else if (digit_bits == 7) {
@@ -500,12 +507,12 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                 hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, true, RADIX_BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
                                    vin, kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX,
                                    sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
-                                   0u, epoch, sc.error, ranges, nranges);
+                                   0u, epoch, sc.error, ranges, nranges, 0);
             else
                 hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, false, RADIX_BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
                                    vin, kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX,
                                    sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
-                                   0u, epoch, sc.error, (uint2*)nullptr, 0u);
+                                   0u, epoch, sc.error, (uint2*)nullptr, 0u, 0);
             km_mark(km, names[2]);
             WS_HIP(hipGetLastError());
             uint32_t* tk = kin;

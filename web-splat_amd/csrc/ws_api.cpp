@@ -650,6 +650,9 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         tile_bits = tile_passes * RADIX_BITS;
     }
     bb.tile_hist_mask = (1u << digit_bits) - 1u;
+    // tile ids fit 16 bits up to 65534 tiles (4096 x 4080 px): the key arrays of the tile sort then hold uint16_t
+    const bool key16 = r->ctx->sort_algo != 1 && ntiles < 65535u;
+    bb.key16 = key16 ? 1 : 0;
     if ((rc = launch_bin_prefix(bb, stream))) return rc;
     km_mark(km, "k_bin_prefix");
     if ((rc = launch_bin_emit(bb, stream))) return rc;
@@ -663,7 +666,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     uint32_t *ek = nullptr, *evv = nullptr;
     if ((rc = launch_sort_pairs(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap, 0,
                                 tile_bits, false, fused_hist, r->ctx->sort_algo, r->epoch, stream, &ek, &evv, km,
-                                "tiles:", r->tile_ranges, ntiles, digit_bits)))
+                                "tiles:", r->tile_ranges, ntiles, digit_bits, key16)))
         return rc;
     r->entries_sorted = evv;  // the last pass wrote the per-tile ranges instead of the sorted tile ids
     if (r->timers) {

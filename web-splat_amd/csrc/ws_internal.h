@@ -131,7 +131,7 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
                       uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals,
                       KernelMarks* km = nullptr, const char* tag = "", uint2* ranges = nullptr, uint32_t nranges = 0,
-                      int digit_bits = RADIX_BITS);
+                      int digit_bits = RADIX_BITS, bool key16 = false);
 
 // ---- preprocess ---------------------------------------------------------------------------------
 struct K1Buffers {
@@ -164,6 +164,7 @@ struct BinBuffers {
     uint32_t* tile_hist;         // nullptr, or the tile sort's tile_sums: emit workgroup m also writes the digit
     uint32_t tile_hist_pitch;    //   counts (first digit of the tile id) of sort tile m -> no histogram pass 0
     uint32_t tile_hist_mask;     //   (1 << digit bits of the tile sort) - 1
+    int key16;                   // entry_keys holds uint16_t tile ids (fewer than 65535 tiles): 2 B less per entry
     uint32_t entry_cap;
     uint2* tile_ranges;          // [tiles] (begin, end) into the sorted entry list
     FrameCounters* counters;
