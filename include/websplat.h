@@ -282,6 +282,11 @@ int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, 
  * how many of its entries the compositing pass walked before every pixel was saturated.  Syncs. */
 int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t* list_len, uint32_t* consumed,
                                     uint32_t* num_tiles);
+/* parity read-back of the binning result: tile t's depth-ordered (far -> near) splat list is
+ * entries[begin[t] .. end[t]) (store indices, as `sorted` of ws_renderer_download_frame). Any pointer may be NULL;
+ * *num_entries = D.  Syncs. */
+int ws_renderer_download_tile_lists(ws_renderer* r, uint32_t tile_capacity, uint32_t* begin, uint32_t* end,
+                                    uint32_t entry_capacity, uint32_t* entries, uint32_t* num_entries);
 
 /* ---- Scene: scene.rs:13-24, 113-194 (host only) ----------------------------------------------------- */
 #define WS_SPLIT_ALL (-1)

@@ -277,3 +277,80 @@ def test_cross_check_paths(ws, oracle, env, monkeypatch):
             pc.close()
     finally:
         c.close()
+
+
+def _coverage_tiles(splats_f16, viewport):
+    """For every splat: the set of 16x16 tiles holding at least one pixel centre with a <= 2*CUTOFF, evaluated as the
+    oracle does (oracle/ws_oracle.c setup_splat + wso_render), in float64 with a small slack towards 'covered'."""
+    w, h = viewport
+    tx_n = (w + 15) // 16
+    out = []
+    cut = 2 * 2.3539888583335364
+    for s in splats_f16.astype(np.float64):
+        m00, m10, m01, m11 = s[0] * w, -s[1] * h, s[2] * w, -s[3] * h
+        det = m00 * m11 - m01 * m10
+        tiles = set()
+        if det != 0 and np.isfinite(det):
+            cx, cy = (s[4] * 0.5 + 0.5) * w, (0.5 - s[5] * 0.5) * h
+            i00, i01, i10, i11 = m11 / det, -m01 / det, -m10 / det, m00 / det
+            ex = np.sqrt(cut) * np.hypot(m00, m01) + 1.0
+            ey = np.sqrt(cut) * np.hypot(m10, m11) + 1.0
+            x0, x1 = max(int(np.floor(cx - ex)), 0), min(int(np.ceil(cx + ex)), w - 1)
+            y0, y1 = max(int(np.floor(cy - ey)), 0), min(int(np.ceil(cy + ey)), h - 1)
+            if x0 <= x1 and y0 <= y1:
+                xs = np.arange(x0, x1 + 1) + 0.5 - cx
+                ys = np.arange(y0, y1 + 1) + 0.5 - cy
+                dx, dy = np.meshgrid(xs, ys)
+                a = (i00 * dx + i01 * dy) ** 2 + (i10 * dx + i11 * dy) ** 2
+                yy, xx = np.nonzero(a <= cut * (1 - 1e-6))
+                tiles = set(((yy + y0) // 16 * tx_n + (xx + x0) // 16).tolist())
+        out.append(tiles)
+    return out
+
+
+@pytest.mark.parametrize("kind", ["c1", "needles"])
+def test_binning_covers_every_touched_tile(ws, ctx, oracle, kind):
+    """Binning hands every tile of the kept ellipse's bounding rectangle to the blend.  It may list a tile the ellipse
+    misses (the blend's exact per-quadrant test drops it) but never drop one it touches: every tile holding a covered
+    pixel centre must list the splat, exactly once, and each tile's list must be in draw order."""
+    if kind == "c1":
+        rows = synth.scene_c1(n=6000, seed=21)
+    else:  # long thin splats at all orientations: the case a bounding rectangle is worst at
+        rng = np.random.default_rng(22)
+        rows = synth.scene_c1(n=3000, seed=22)
+        rows[:, -7:-4] = np.log(np.stack([rng.uniform(0.1, 0.4, 3000), rng.uniform(0.003, 0.01, 3000),
+                                          rng.uniform(0.003, 0.01, 3000)], 1)).astype(np.float32)
+    viewport = (640, 400)
+    gpc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
+    cj = synth.camera_c1(*viewport)
+    cj.fx = cj.fy = 600.0
+    cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, *viewport)
+    cam.fit_near_far(gpc.aabb)
+    args = ws.SplattingArgs(camera=cam, viewport=viewport, max_sh_deg=3)
+    pc = ws.PointCloud(ctx, gpc)
+    r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    try:
+        r.prepare(pc, args)
+        r.render(pc)
+        st = r.frame_stats()
+        assert st["overflow"] == 0
+        fr = r.download_frame()
+        begin, end, entries = r.tile_lists()
+        assert len(entries) == st["num_tile_entries"] == int((end - begin).sum())
+        rank = np.empty(st["num_visible"], dtype=np.int64)
+        rank[fr["sorted"]] = np.arange(st["num_visible"])
+        listed = [set() for _ in range(st["num_visible"])]
+        for t in range(len(begin)):
+            e = entries[begin[t]:end[t]]
+            assert len(np.unique(e)) == len(e)                        # a splat appears once per tile
+            assert np.all(np.diff(rank[e]) > 0)                        # far -> near inside the tile
+            for sidx in e.tolist():
+                listed[sidx].add(t)
+        cov = _coverage_tiles(fr["splats"].view(np.float16).reshape(-1, 10), viewport)
+        missing = [(i, sorted(c - listed[i])) for i, c in enumerate(cov) if not c <= listed[i]]
+        assert not missing, missing[:5]
+        n_cov, n_listed = sum(len(c) for c in cov), sum(len(l) for l in listed)
+        assert n_listed <= (1.6 if kind == "c1" else 6.0) * n_cov + 50, (n_listed, n_cov)  # bounding rectangles, not more
+    finally:
+        r.close()
+        pc.close()

@@ -100,11 +100,11 @@ struct ws_renderer {
     uint32_t vw = 0, vh = 0, tiles_x = 0, tiles_y = 0;
     uint64_t entry_cap_request = 0;
     uint32_t entry_cap = 0;
+    uint2* rects = nullptr;
+    uint2* rects_sorted = nullptr;
     uint8_t* splats = nullptr;      // Splat[N], 20 B each (pointcloud.rs:103-108 allocates it in PointCloud;
                                     // here it is per renderer so that renderers never share scratch)
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-    uint2* rects = nullptr;
-    uint2* rects_sorted = nullptr;
     uint32_t* src_index = nullptr;
     uint64_t* k1_status = nullptr;   // epoch-tagged look-back words (never re-zeroed)
     uint64_t* bin_status = nullptr;
@@ -789,6 +789,30 @@ int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t*
         for (uint32_t i = 0; i < nt; ++i) list_len[i] = rg[i].y ? rg[i].y - (0xFFFFFFFFu - rg[i].x) : 0u;
     }
     if (consumed) WS_HIP(hipMemcpy(consumed, r->debug_consumed, (size_t)nt * 4, hipMemcpyDeviceToHost));
+    return WS_OK;
+}
+
+int ws_renderer_download_tile_lists(ws_renderer* r, uint32_t tile_capacity, uint32_t* begin, uint32_t* end,
+                                    uint32_t entry_capacity, uint32_t* entries, uint32_t* num_entries) {
+    if (!r) return fail(WS_ERR_INVALID, "ws_renderer_download_tile_lists: null renderer");
+    ws_frame_stats st;
+    int rc = ws_renderer_frame_stats(r, &st);
+    if (rc) return rc;
+    const uint32_t nt = r->tiles_x * r->tiles_y;
+    if (num_entries) *num_entries = st.num_tile_entries;
+    if ((begin || end) && tile_capacity < nt) return fail(WS_ERR_INVALID, "ws_renderer_download_tile_lists: tile capacity too small");
+    if (entries && entry_capacity < st.num_tile_entries)
+        return fail(WS_ERR_INVALID, "ws_renderer_download_tile_lists: entry capacity too small");
+    if (begin || end) {
+        std::vector<uint2> rg(nt);
+        WS_HIP(hipMemcpy(rg.data(), r->tile_ranges, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < nt; ++i) {
+            if (begin) begin[i] = rg[i].y ? 0xFFFFFFFFu - rg[i].x : 0u;
+            if (end) end[i] = rg[i].y;
+        }
+    }
+    if (entries && st.num_tile_entries)
+        WS_HIP(hipMemcpy(entries, r->entries_sorted, (size_t)st.num_tile_entries * 4, hipMemcpyDeviceToHost));
     return WS_OK;
 }
 

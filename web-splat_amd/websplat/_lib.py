@@ -197,6 +197,7 @@ SIGNATURES = {
     "ws_renderer_stage_times": (C.c_int, [_P, C.POINTER(ws_stage_times)]),
     "ws_renderer_kernel_times": (C.c_int, [_P, C.c_uint32, C.POINTER(ws_kernel_time), _u32p]),
     "ws_renderer_download_tile_stats": (C.c_int, [_P, C.c_uint32, _P, _P, _u32p]),
+    "ws_renderer_download_tile_lists": (C.c_int, [_P, C.c_uint32, _P, _P, C.c_uint32, _P, _u32p]),
     "ws_renderer_enable_capture": (C.c_int, [_P, C.c_int]),
     "ws_renderer_set_tile_entry_capacity": (C.c_int, [_P, C.c_uint64]),
     "ws_renderer_download_frame": (C.c_int, [_P, C.c_uint32, _P, _P, _P, _P, _u32p]),

@@ -480,6 +480,20 @@ class GaussianRenderer:
         check(lib.ws_renderer_kernel_times(self.handle, 64, buf, C.byref(n)))
         return [(buf[i].name.decode(), buf[i].ms) for i in range(min(n.value, 64))]
 
+    def tile_lists(self):
+        """(begin[T], end[T], entries[D]): tile t's far -> near splat list is entries[begin[t]:end[t]] (store indices)."""
+        nt = C.c_uint32()
+        check(lib.ws_renderer_download_tile_stats(self.handle, 0, None, None, C.byref(nt)))
+        d = C.c_uint32()
+        check(lib.ws_renderer_download_tile_lists(self.handle, 0, None, None, 0, None, C.byref(d)))
+        begin = np.empty(nt.value, dtype=np.uint32)
+        end = np.empty(nt.value, dtype=np.uint32)
+        entries = np.empty(max(d.value, 1), dtype=np.uint32)
+        check(lib.ws_renderer_download_tile_lists(self.handle, nt.value, begin.ctypes.data_as(C.c_void_p),
+                                                  end.ctypes.data_as(C.c_void_p), entries.size,
+                                                  entries.ctypes.data_as(C.c_void_p), C.byref(d)))
+        return begin, end, entries[:d.value]
+
     def tile_stats(self, with_consumed=False):
         nt = C.c_uint32()
         check(lib.ws_renderer_download_tile_stats(self.handle, 0, None, None, C.byref(nt)))
