@@ -195,9 +195,12 @@ static void renderer_free_scratch(ws_renderer* r) {
 static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint32_t vh) {
     uint64_t want_cap = r->entry_cap_request;
     if (want_cap == 0) {
-        // automatic: 24 tile entries per Gaussian, at least 8 M -- 288 GB of HBM make this a non-issue
-        // (16 B per entry: 1.2 M Gaussians -> 0.46 GB, 5 M -> 1.9 GB)
-        want_cap = std::max<uint64_t>(8ull << 20, 24ull * n);
+        // automatic: 24 tile entries per Gaussian at ~1 Mpixel, growing with the pixel count (a splat's footprint in
+        // tiles scales with the resolution: the 24 M entries of 1 M Gaussians overflowed at 3840x2160), at least 8 M.
+        // 16 B per entry: 1.2 M Gaussians at 1200x799 -> 0.46 GB, 1 M at 4K -> 3.3 GB; 288 GB of HBM make this a
+        // non-issue, ws_renderer_set_tile_entry_capacity overrides it, and an overflow is always flagged.
+        const double mpix = (double)vw * (double)vh / (1200.0 * 800.0);
+        want_cap = std::max<uint64_t>(8ull << 20, (uint64_t)(24.0 * (double)n * std::max(1.0, mpix)));
     }
     // look-back words carry 30-bit counts (lookback.h): keep D below 2^30
     want_cap = std::min<uint64_t>(want_cap, (1ull << 30) - 2 * EMIT_TILE);
