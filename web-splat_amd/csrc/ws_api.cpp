@@ -144,7 +144,7 @@ static void free_sort_scratch(SortScratch& sc, bool own_alt) {
 }
 
 // status words are zeroed ONCE here; afterwards the epoch tag makes stale words invisible (lookback.h)
-static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt) {
+static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, bool one_sweep) {
     sc.cap = cap;
     sc.tiles = (cap + SORT_TILE - 1) / SORT_TILE;
     if (sc.tiles == 0) sc.tiles = 1;
@@ -153,7 +153,8 @@ static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt) {
         if ((rc = dmalloc(&sc.keys_alt, (size_t)cap + 4))) return rc;
         if ((rc = dmalloc(&sc.vals_alt, (size_t)cap + 4))) return rc;
     }
-    const size_t status_words = 4 * (size_t)sc.tiles * RADIX;
+    // look-back words of the one-sweep path (WS_SORT_ALGO=1): 8 KiB per 2048 pairs, only when that path is selected
+    const size_t status_words = one_sweep ? 4 * (size_t)sc.tiles * RADIX : 1;
     if ((rc = dmalloc(&sc.status, status_words))) return rc;
     WS_HIP(hipMemset(sc.status, 0, status_words * sizeof(uint64_t)));
     const uint32_t small_n = std::min<uint32_t>(cap, SORT_SMALL_MAX);
@@ -239,11 +240,11 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     WS_HIP(hipMemset(r->zero, 0, r->zero_bytes));
     r->counters = &r->zero->counters;
     r->tile_ranges = reinterpret_cast<uint2*>(reinterpret_cast<char*>(r->zero) + sizeof(FrameZero));
-    if ((rc = alloc_sort_scratch(r->sort_depth, n ? n : 1, false))) return rc;
+    if ((rc = alloc_sort_scratch(r->sort_depth, n ? n : 1, false, r->ctx->sort_algo == 1))) return rc;
     r->sort_depth.keys_alt = r->keys_b;
     r->sort_depth.vals_alt = r->vals_b;
     r->sort_depth.hist = r->zero->depth_hist;
-    if ((rc = alloc_sort_scratch(r->sort_tiles, r->entry_cap, false))) return rc;
+    if ((rc = alloc_sort_scratch(r->sort_tiles, r->entry_cap, false, r->ctx->sort_algo == 1))) return rc;
     r->sort_tiles.keys_alt = r->ekeys_b;
     r->sort_tiles.vals_alt = r->evals_b;
     r->sort_tiles.hist = r->zero->tile_hist;
@@ -582,8 +583,10 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     if (++r->epoch == 0) {
         WS_HIP(hipMemsetAsync(r->k1_status, 0, ((size_t)preprocess_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
         WS_HIP(hipMemsetAsync(r->bin_status, 0, ((size_t)bin_prefix_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
-        WS_HIP(hipMemsetAsync(r->sort_depth.status, 0, 4 * (size_t)r->sort_depth.tiles * RADIX * sizeof(uint64_t), stream));
-        WS_HIP(hipMemsetAsync(r->sort_tiles.status, 0, 4 * (size_t)r->sort_tiles.tiles * RADIX * sizeof(uint64_t), stream));
+        if (r->ctx->sort_algo == 1) {
+            WS_HIP(hipMemsetAsync(r->sort_depth.status, 0, 4 * (size_t)r->sort_depth.tiles * RADIX * sizeof(uint64_t), stream));
+            WS_HIP(hipMemsetAsync(r->sort_tiles.status, 0, 4 * (size_t)r->sort_tiles.tiles * RADIX * sizeof(uint64_t), stream));
+        }
         r->epoch = 1;
     }
     kp.epoch = r->epoch;
@@ -856,7 +859,7 @@ int ws_sorter_create(ws_context* ctx, uint32_t max_n, ws_sorter** out) {
     ws_sorter* s = new (std::nothrow) ws_sorter();
     if (!s) return fail(WS_ERR_OOM, "ws_sorter_create: host allocation failed");
     s->ctx = ctx;
-    int rc = alloc_sort_scratch(s->sc, max_n, true);
+    int rc = alloc_sort_scratch(s->sc, max_n, true, ctx->sort_algo == 1);
     if (rc == WS_OK) rc = dmalloc(&s->zero, 1);
     if (rc == WS_OK) {
         s->sc.tickets = s->zero->tickets;
@@ -884,7 +887,8 @@ int ws_sorter_sort(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, const ui
     if (!s || !d_keys || !d_payload) return fail(WS_ERR_INVALID, "ws_sorter_sort: null argument");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (++s->epoch == 0) {
-        WS_HIP(hipMemsetAsync(s->sc.status, 0, 4 * (size_t)s->sc.tiles * RADIX * sizeof(uint64_t), stream));
+        if (s->ctx->sort_algo == 1)
+            WS_HIP(hipMemsetAsync(s->sc.status, 0, 4 * (size_t)s->sc.tiles * RADIX * sizeof(uint64_t), stream));
         s->epoch = 1;
     }
     WS_HIP(hipMemsetAsync(s->zero, 0, sizeof(SorterZero), stream));
