@@ -73,28 +73,47 @@ struct Sh16 {
     float c[16][3];
 };
 
-// preprocess.wgsl:124-154 evaluate_sh, one channel
-__device__ __forceinline__ float eval_sh_channel(const Sh16& sh, int ch, float x, float y, float z, uint32_t deg) {
-    float result = SH_C0 * sh.c[0][ch];
-    if (deg > 0u) {
-        result += -SH_C1 * y * sh.c[1][ch] + SH_C1 * z * sh.c[2][ch] - SH_C1 * x * sh.c[3][ch];
-        if (deg > 1u) {
-            const float xx = x * x, yy = y * y, zz = z * z;
-            const float xy = x * y, yz = y * z, xz = x * z;
-            result += SH_C2_0 * xy * sh.c[4][ch] + SH_C2_1 * yz * sh.c[5][ch] +
-                      SH_C2_2 * (2.0f * zz - xx - yy) * sh.c[6][ch] + SH_C2_3 * xz * sh.c[7][ch] +
-                      SH_C2_4 * (xx - yy) * sh.c[8][ch];
-            if (deg > 2u) {
-                result += SH_C3_0 * y * (3.0f * xx - yy) * sh.c[9][ch] + SH_C3_1 * xy * z * sh.c[10][ch] +
-                          SH_C3_2 * y * (4.0f * zz - xx - yy) * sh.c[11][ch] +
-                          SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh.c[12][ch] +
-                          SH_C3_4 * x * (4.0f * zz - xx - yy) * sh.c[13][ch] + SH_C3_5 * z * (xx - yy) * sh.c[14][ch] +
-                          SH_C3_6 * x * (xx - 3.0f * yy) * sh.c[15][ch];
+// preprocess.wgsl:124-154 evaluate_sh, all three channels at once.  WGSL evaluates `C * p * sh` left to right, so the
+// channel-independent factor (C * p) of every term is computed once (bit-identical to the per-channel form); within a
+// channel the terms of a band are summed left to right and then added to the result, as the shader does.
+__device__ __forceinline__ void eval_sh3(const Sh16& sh, float x, float y, float z, uint32_t deg, float out[3]) {
+    float bas[16];
+    bas[0] = SH_C0;
+    bas[1] = -SH_C1 * y;
+    bas[2] = SH_C1 * z;
+    bas[3] = SH_C1 * x;  // subtracted
+    const float xx = x * x, yy = y * y, zz = z * z;
+    const float xy = x * y, yz = y * z, xz = x * z;
+    bas[4] = SH_C2_0 * xy;
+    bas[5] = SH_C2_1 * yz;
+    bas[6] = SH_C2_2 * (2.0f * zz - xx - yy);
+    bas[7] = SH_C2_3 * xz;
+    bas[8] = SH_C2_4 * (xx - yy);
+    bas[9] = SH_C3_0 * y * (3.0f * xx - yy);
+    bas[10] = SH_C3_1 * xy * z;
+    bas[11] = SH_C3_2 * y * (4.0f * zz - xx - yy);
+    bas[12] = SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+    bas[13] = SH_C3_4 * x * (4.0f * zz - xx - yy);
+    bas[14] = SH_C3_5 * z * (xx - yy);
+    bas[15] = SH_C3_6 * x * (xx - 3.0f * yy);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float result = bas[0] * sh.c[0][ch];
+        if (deg > 0u) {
+            result += bas[1] * sh.c[1][ch] + bas[2] * sh.c[2][ch] - bas[3] * sh.c[3][ch];
+            if (deg > 1u) {
+                result += bas[4] * sh.c[4][ch] + bas[5] * sh.c[5][ch] + bas[6] * sh.c[6][ch] + bas[7] * sh.c[7][ch] +
+                          bas[8] * sh.c[8][ch];
+                if (deg > 2u) {
+                    result += bas[9] * sh.c[9][ch] + bas[10] * sh.c[10][ch] + bas[11] * sh.c[11][ch] +
+                              bas[12] * sh.c[12][ch] + bas[13] * sh.c[13][ch] + bas[14] * sh.c[14][ch] +
+                              bas[15] * sh.c[15][ch];
+                }
             }
         }
+        result += 0.5f;
+        out[ch] = result;
     }
-    result += 0.5f;
-    return result;
 }
 
 struct SplatOut {
@@ -257,9 +276,9 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
     const float inv_dl = __builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz);
     const float dirx = dx * inv_dl, diry = dy * inv_dl, dirz = dz * inv_dl;
 #endif
-    const float cr = fmaxf(0.0f, eval_sh_channel(sh, 0, dirx, diry, dirz, p.rs.max_sh_deg));
-    const float cg = fmaxf(0.0f, eval_sh_channel(sh, 1, dirx, diry, dirz, p.rs.max_sh_deg));
-    const float cb = fmaxf(0.0f, eval_sh_channel(sh, 2, dirx, diry, dirz, p.rs.max_sh_deg));
+    float rgb[3];
+    eval_sh3(sh, dirx, diry, dirz, p.rs.max_sh_deg, rgb);
+    const float cr = fmaxf(0.0f, rgb[0]), cg = fmaxf(0.0f, rgb[1]), cb = fmaxf(0.0f, rgb[2]);
 
     const float vw = p.cam.viewport[0], vh = p.cam.viewport[1];
     const uint32_t h0 = f2h(qdiv(v1x, vw)), h1 = f2h(qdiv(v1y, vh)), h2 = f2h(qdiv(v2x, vw)), h3 = f2h(qdiv(v2y, vh));
