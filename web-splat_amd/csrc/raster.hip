@@ -11,10 +11,12 @@
 //   k_bin_prefix  : per depth-sorted splat: gather its tile rectangle, count tiles, exclusive prefix over the
 //                   draw order in ONE pass (ticketed wave-parallel decoupled look-back), total D
 //   k_bin_emit    : entry-parallel: every workgroup produces exactly EMIT_TILE (tile id, splat) entries, whatever
-//                   the footprint of the splats they come from (LDS binary search over the splat offsets)
-//   (radix sort of the entries by tile id: sort.hip, 2 passes, stable -> depth order kept inside a tile)
-//   (the last sort pass also records [begin,end) of every tile in the sorted entry list)
-//   k_blend       : 16x16 pixels per workgroup, splats staged through LDS 256 at a time, early-out on T
+//                   the footprint of the splats they come from (owners by an LDS max-scan over the splat offsets)
+//   (radix sort of the entries by tile id: sort.hip, ceil(log2 T / 8) passes, stable -> depth order kept inside a
+//    tile; its last pass records [begin,end) of every tile in the sorted entry list instead of writing the keys)
+//   k_blend       : 16x16 pixels per workgroup, splats staged through LDS 256 at a time, per-wave compaction to the
+//                   records that reach the wave's 8x8 quadrant, early-out on T
+//   k_display     : Display::render composite into an 8-bit surface
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 

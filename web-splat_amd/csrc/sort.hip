@@ -1,26 +1,28 @@
-// sort.hip -- stable ascending LSD radix sort of (u32 key, u32 value) pairs for gfx950.
+// sort.hip -- stable ascending LSD radix sort of (key, u32 value) pairs for gfx950.
 //
 // Replaces GPURSSorter (src/gpu_rs.rs:63-885) and src/shaders/radix_sort.wgsl:48-512 of the reference:
-// same contract (ascending, stable, 8-bit digits, key count read from device memory), new design.
+// same contract (ascending, stable, key count read from device memory), new design.
 //
-// Common to both paths (k_sort_scatter): one workgroup = one tile of 256 x KPT pairs; ranking inside a
-// wave uses wave64 ballots (8 per key) instead of the reference's O(subgroup) shared-memory match loop
-// (radix_sort.wgsl:279-302), with per-wave LDS digit counters updated by one leader lane per digit
-// (deterministic, no LDS atomics); keys and values are reordered through LDS so that global writes are
-// contiguous per digit run; the first pass can synthesise the iota payload.
+// Common to both paths (k_sort_scatter): one workgroup = one tile of 256 x KPT pairs; ranking inside a wave uses wave64
+// ballots (one per digit bit) instead of the reference's O(subgroup) shared-memory match loop
+// (radix_sort.wgsl:279-302); per-wave LDS digit counters are bumped by one leader lane per distinct digit, all keys'
+// LDS atomics issued back to back (in order per wave: deterministic, stable); keys and values are reordered through
+// LDS together so that global writes are contiguous per digit run; the first pass can synthesise the iota payload;
+// tiles are dealt to workgroups so that one XCD owns a contiguous tile range (partial cache lines of neighbouring
+// tiles' runs meet in one L2).  Digit width is a template parameter: 8 bits for 32-bit keys, 6..8 for the tile-id
+// sort, whose keys may also be stored as 16-bit values.
 //
 // Cross-tile prefix, two selectable paths (measured on MI355X, profiles/):
-//   algo 0  "tile histograms -> column scan -> scatter": per pass a histogram kernel writes the digit counts of
-//           every tile (transposed, [digit][tile]), 256 workgroups scan one digit row each, the scatter kernel
-//           reads its offsets.  No spinning, nothing to order; costs one extra read of the keys per pass.
-//           When the producer of the keys already knows the per-tile digit counts of the first pass (the tile
-//           binning kernel does) that histogram kernel is skipped.
+//   algo 0  "tile histograms -> column scan -> scatter" (default): per pass a histogram kernel writes the digit counts
+//           of every tile (transposed, [digit][tile]), one workgroup per digit scans its row, the scatter kernel reads
+//           its offsets.  No spinning, nothing to order; costs one extra read of the keys per pass.  When the producer
+//           of the keys already knows the per-tile digit counts of the first pass (the tile binning kernel does)
+//           that histogram kernel is skipped.
 //   algo 1  one-sweep: one histogram pass for all digits, then per pass a decoupled look-back over epoch-tagged
-//           64-bit {epoch,flag,count} words (lookback.h), windowed (4 predecessor tiles per round trip),
-//           tiles handed out by an atomic ticket.  Fewer launches, every pair read once per pass, but with
-//           ~1000 co-resident tiles starting together the look-back chain (~sqrt(2k) dependent L2 round trips
-//           for tile k, each ~1 us across 8 XCDs) costs more than re-reading the keys: ~2x slower per pass on
-//           6.6 M pairs.  Kept as a cross-check and for callers that prefer fewer launches.
+//           64-bit {epoch,flag,count} words (lookback.h), windowed (4 predecessor tiles per round trip), tiles handed
+//           out by an atomic ticket.  Fewer launches, every pair read once per pass, but with every tile co-resident
+//           and starting together the look-back chain (one ~1 us cross-XCD round trip per hop) costs more than
+//           re-reading the keys.  Kept as a cross-check (tests run both).
 #include <hip/hip_runtime.h>
 
 #include "lookback.h"
