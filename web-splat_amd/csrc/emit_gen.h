@@ -1,0 +1,131 @@
+// emit_gen.h -- generation of the (tile id, splat) entries of one EMIT_TILE-entry slice, in draw order.
+//
+// Used by k_bin_emit (raster.hip); kept separate from the kernel because a sort pass can generate its own input
+// with it (tried for the tile-id sort's first pass, not faster: see k_bin_emit).
+//
+// Every entry needs its owner: the draw position k with off[k] <= e < off[k] + cnt[k].  The owners of a whole slice
+// are found at once: every owning position drops its index on its first entry (atomicMax, so that zero-footprint
+// positions, which share an offset with their successor, lose), and an inclusive max-scan spreads it over the
+// entries.  (A per-entry binary search over the offsets was 12 dependent, bank-conflicting LDS reads per entry.)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ws_internal.h"
+
+namespace ws {
+namespace emit {
+
+constexpr int THREADS = 256;
+constexpr int EPT = EMIT_TILE / THREADS;  // entries per thread in the scan
+constexpr int OFF_WORDS = EMIT_TILE + 2;        // s_off
+constexpr int OWN_WORDS = EMIT_TILE + THREADS;  // s_own (bank-skewed)
+__device__ __forceinline__ uint32_t pad(uint32_t i) { return i + i / EPT; }  // per-thread blocks, bank-skewed
+
+struct Source {
+    const uint32_t* sorted_idx;   // [V] store indices in draw order
+    const uint2* rects_sorted;    // [V] tile rectangle by draw position
+    const uint32_t* offsets;      // [V] exclusive prefix of tiles touched, by draw position
+    const uint32_t* emit_start;   // draw position owning entry m * EMIT_TILE
+    const FrameCounters* counters;
+    uint32_t tiles_x;
+};
+
+struct Slice {
+    uint32_t e0, ne;        // first entry, number of entries
+    uint32_t s_lo, ns;      // draw positions [s_lo, s_lo + ns) own them
+    bool in_lds;            // the offsets fit the LDS window (block-uniform)
+    const uint32_t* goff;   // offsets + s_lo
+};
+
+// All THREADS threads of the workgroup call this (it contains barriers).  d = total entries, v = visible splats.
+__device__ __forceinline__ Slice slice_setup(const Source& src, uint32_t slice, uint32_t d, uint32_t v, uint32_t* s_off,
+                                             uint32_t* s_own, uint32_t* s_wmax) {
+    const int tid = threadIdx.x;
+    Slice sl;
+    sl.e0 = slice * EMIT_TILE;
+    const uint32_t e1 = (d - sl.e0) < (uint32_t)EMIT_TILE ? d : sl.e0 + EMIT_TILE;
+    sl.ne = e1 - sl.e0;
+    // draw positions [s_lo, s_hi] own the entries [e0, e1)
+    sl.s_lo = src.emit_start[slice];
+    const uint32_t s_hi = (e1 < d) ? src.emit_start[slice + 1] : (v - 1u);
+    // Positions that own entries of this slice number at most EMIT_TILE + 1, but visible splats with an EMPTY
+    // tile rectangle (centre inside the 1.2x cull bounds, footprint off screen) can sit in between in any
+    // number: normally the offsets fit the LDS window, otherwise the search runs on global memory (rare).
+    sl.ns = s_hi - sl.s_lo + 1u;
+    sl.in_lds = sl.ns <= (uint32_t)EMIT_TILE + 2u;
+    sl.goff = src.offsets + sl.s_lo;
+    if (sl.in_lds) {
+        for (uint32_t k = tid; k < sl.ns; k += THREADS) s_off[k] = sl.goff[k];
+        for (uint32_t i = tid; i < (uint32_t)OWN_WORDS; i += THREADS) s_own[i] = 0u;
+        __syncthreads();
+        for (uint32_t k = tid; k < sl.ns; k += THREADS) {
+            const uint32_t o = s_off[k];
+            const uint32_t f = o > sl.e0 ? o - sl.e0 : 0u;  // first entry of position k inside the slice
+            if (f < sl.ne) atomicMax(&s_own[pad(f)], k);
+        }
+        __syncthreads();
+        // inclusive max-scan over the slice, EPT consecutive entries per thread
+        uint32_t own[EPT];
+        uint32_t run = 0u;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            run = max(run, s_own[tid * (EPT + 1) + j]);
+            own[j] = run;
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl = max(incl, t);
+        }
+        if (lane == 63) s_wmax[wave] = incl;
+        uint32_t prefix = __shfl_up(incl, 1, 64);
+        if (lane == 0) prefix = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w)
+            if (w < wave) prefix = max(prefix, s_wmax[w]);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) s_own[tid * (EPT + 1) + j] = max(own[j], prefix);
+    }
+    __syncthreads();
+    return sl;
+}
+
+// Entry el (0 <= el < sl.ne) of the slice: tile id and splat (store index).
+__device__ __forceinline__ void entry(const Source& src, const Slice& sl, const uint32_t* s_off, const uint32_t* s_own,
+                                      uint32_t el, uint32_t* key, uint32_t* val) {
+    const uint32_t e = sl.e0 + el;
+    uint32_t lo;
+    if (sl.in_lds) {
+        lo = s_own[pad(el)];
+    } else {
+        // largest k in [0, ns) with off[k] <= e  (zero-footprint positions share their successor's offset and
+        // are skipped by taking the LAST such k)
+        uint32_t hi = sl.ns;
+        lo = 0;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sl.goff[mid] <= e) lo = mid; else hi = mid;
+        }
+    }
+    const uint32_t pos = sl.s_lo + lo;
+    const uint2 r = src.rects_sorted[pos];
+    const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu;
+    const uint32_t w = x1 - x0 + 1u;
+    const uint32_t k = e - (sl.in_lds ? s_off[lo] : sl.goff[lo]);
+    // k / w without the integer-division sequence: k < 2^24 always (a rectangle has at most 2^16 x 2^16 tiles
+    // but the entry capacity is below 2^30 and rows are at most 65535 wide; one correction step covers rounding)
+    uint32_t q = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
+    uint32_t rem = k - q * w;
+    if ((int32_t)rem < 0) { q -= 1u; rem += w; }
+    if (rem >= w) { q += 1u; rem -= w; }
+    if (k >= (1u << 23)) { q = k / w; rem = k % w; }  // exactness of the float path ends at 2^23
+    *key = (y0 + q) * src.tiles_x + (x0 + rem);
+    *val = src.sorted_idx[pos];
+}
+
+}  // namespace emit
+}  // namespace ws

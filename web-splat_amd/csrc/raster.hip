@@ -20,6 +20,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include "emit_gen.h"
 #include "lookback.h"
 #include "ws_internal.h"
 
@@ -161,127 +162,45 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
 }
 
 // ---- k_bin_emit: (tile id, splat) entries in draw order, EMIT_TILE entries per workgroup ---------------
-// Every entry needs its owner: the draw position k with off[k] <= e < off[k] + cnt[k].  Measured on MI355X
-// (profiles/): a per-entry binary search over the offsets in LDS is 12 dependent, bank-conflicting LDS reads per
-// entry and made this kernel the most VALU-expensive one after K1.  Here the owners are found for the whole slice
-// at once: every owning position drops its index on its first entry (atomicMax, so that zero-footprint positions,
-// which share an offset with their successor, lose), and an inclusive max-scan spreads it over the entries.
+// Entry generation lives in emit_gen.h.  Besides writing the entries this kernel counts the first sort digit of
+// every slice (the tile-id sort's per-tile histogram of pass 0).  (Generating the entries inside the sort's first
+// pass instead -- no entry list in memory before it is half sorted -- was measured: the 12 B per entry saved did
+// not pay for generating everything twice, once to count and once to scatter.)
 constexpr int EMIT_COPIES = 2;
-constexpr int EMIT_EPT = EMIT_TILE / BIN_THREADS;  // entries per thread in the scan
-__device__ __forceinline__ uint32_t emit_pad(uint32_t i) { return i + i / EMIT_EPT; }  // per-thread blocks, bank-skewed
 
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __restrict__ sorted_idx,
-                                                         const uint2* __restrict__ rects_sorted,
-                                                         const uint32_t* __restrict__ offsets,
-                                                         const uint32_t* __restrict__ emit_start,
-                                                         uint32_t* __restrict__ entry_keys,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src, uint32_t* __restrict__ entry_keys,
                                                          uint32_t* __restrict__ entry_vals,
-                                                         const FrameCounters* __restrict__ counters,
-                                                         uint32_t tiles_x, uint32_t* __restrict__ tile_hist,
-                                                         uint32_t tile_hist_pitch, uint32_t tile_hist_mask, int key16) {
-    constexpr int EPT = EMIT_EPT;
-    __shared__ uint32_t s_off[EMIT_TILE + 2];
-    __shared__ uint32_t s_own[EMIT_TILE + BIN_THREADS];
+                                                         uint32_t* __restrict__ tile_hist, uint32_t tile_hist_pitch,
+                                                         uint32_t tile_hist_mask, int key16) {
+    __shared__ uint32_t s_off[emit::OFF_WORDS];
+    __shared__ uint32_t s_own[emit::OWN_WORDS];
     __shared__ uint32_t s_hist[RADIX * EMIT_COPIES];
     __shared__ uint32_t s_wmax[BIN_THREADS / 64];
-    const uint32_t d = counters->num_entries;
-    const uint32_t v = counters->num_visible;
+    const uint32_t d = src.counters->num_entries;
+    const uint32_t v = src.counters->num_visible;
     const int tid = threadIdx.x;
-    // capped grid, workgroups stride over the 4096-entry slices (the host only knows the capacity, not D)
-    for (uint32_t slice = blockIdx.x; (uint64_t)slice * EMIT_TILE < d; slice += gridDim.x) {
-    const uint32_t e0 = slice * EMIT_TILE;
-    const uint32_t e1 = (d - e0) < (uint32_t)EMIT_TILE ? d : e0 + EMIT_TILE;
-    const uint32_t ne = e1 - e0;
-    // draw positions [s_lo, s_hi] own the entries [e0, e1)
-    const uint32_t s_lo = emit_start[slice];
-    const uint32_t s_hi = (e1 < d) ? emit_start[slice + 1] : (v - 1u);
-    // Positions that own entries of this slice number at most EMIT_TILE + 1, but visible splats with an EMPTY
-    // tile rectangle (centre inside the 1.2x cull bounds, footprint off screen) can sit in between in any
-    // number: normally the offsets fit the LDS window, otherwise the search runs on global memory (rare).
-    const uint32_t ns = s_hi - s_lo + 1u;
-    const bool in_lds = ns <= (uint32_t)EMIT_TILE + 2u;  // block-uniform
-    for (int k = tid; k < RADIX * EMIT_COPIES; k += BIN_THREADS) s_hist[k] = 0u;
     const uint32_t copy = (uint32_t)tid & (EMIT_COPIES - 1);
-    const uint32_t* goff = offsets + s_lo;
-    if (in_lds) {
-        for (uint32_t k = tid; k < ns; k += BIN_THREADS) s_off[k] = goff[k];
-        for (uint32_t i = tid; i < (uint32_t)(EMIT_TILE + BIN_THREADS); i += BIN_THREADS) s_own[i] = 0u;
-        __syncthreads();
-        for (uint32_t k = tid; k < ns; k += BIN_THREADS) {
-            const uint32_t o = s_off[k];
-            const uint32_t f = o > e0 ? o - e0 : 0u;  // first entry of position k inside the slice
-            if (f < ne) atomicMax(&s_own[emit_pad(f)], k);
+    // capped grid, workgroups stride over the slices (the host only knows the capacity, not D)
+    for (uint32_t slice = blockIdx.x; (uint64_t)slice * EMIT_TILE < d; slice += gridDim.x) {
+        for (int k = tid; k < RADIX * EMIT_COPIES; k += BIN_THREADS) s_hist[k] = 0u;
+        const emit::Slice sl = emit::slice_setup(src, slice, d, v, s_off, s_own, s_wmax);
+        for (uint32_t el = tid; el < sl.ne; el += BIN_THREADS) {
+            uint32_t key, val;
+            emit::entry(src, sl, s_off, s_own, el, &key, &val);
+            const uint32_t e = sl.e0 + el;
+            if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
+            else entry_keys[e] = key;
+            entry_vals[e] = val;
+            atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
         }
-        __syncthreads();
-        // inclusive max-scan over the slice, 16 consecutive entries per thread
-        uint32_t own[EPT];
-        uint32_t run = 0u;
+        if (tile_hist) {  // digit counts of sort tile `slice` for the tile-id sort's first pass ([digit][tile])
+            __syncthreads();
+            uint32_t c = 0;
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            run = max(run, s_own[tid * (EPT + 1) + j]);
-            own[j] = run;
+            for (int r = 0; r < EMIT_COPIES; ++r) c += s_hist[tid * EMIT_COPIES + r];
+            if ((uint32_t)tid <= tile_hist_mask) tile_hist[(size_t)tid * tile_hist_pitch + slice] = c;
         }
-        const int lane = tid & 63, wave = tid >> 6;
-        uint32_t incl = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl = max(incl, t);
-        }
-        if (lane == 63) s_wmax[wave] = incl;
-        uint32_t prefix = __shfl_up(incl, 1, 64);
-        if (lane == 0) prefix = 0u;
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < BIN_THREADS / 64; ++w)
-            if (w < wave) prefix = max(prefix, s_wmax[w]);
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) s_own[tid * (EPT + 1) + j] = max(own[j], prefix);
-        __syncthreads();
-    } else {
-        __syncthreads();
-    }
-    for (uint32_t el = tid; el < ne; el += BIN_THREADS) {
-        const uint32_t e = e0 + el;
-        uint32_t lo;
-        if (in_lds) {
-            lo = s_own[emit_pad(el)];
-        } else {
-            // largest k in [0, ns) with off[k] <= e  (zero-footprint positions share their successor's offset and
-            // are skipped by taking the LAST such k)
-            uint32_t hi = ns;
-            lo = 0;
-            while (hi - lo > 1u) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (goff[mid] <= e) lo = mid; else hi = mid;
-            }
-        }
-        const uint32_t pos = s_lo + lo;
-        const uint2 r = rects_sorted[pos];
-        const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu;
-        const uint32_t w = x1 - x0 + 1u;
-        const uint32_t k = e - (in_lds ? s_off[lo] : goff[lo]);
-        // k / w without the integer-division sequence: k < 2^24 always (a rectangle has at most 2^16 x 2^16 tiles
-        // but the entry capacity is below 2^30 and rows are at most 65535 wide; one correction step covers rounding)
-        uint32_t q = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
-        uint32_t rem = k - q * w;
-        if ((int32_t)rem < 0) { q -= 1u; rem += w; }
-        if (rem >= w) { q += 1u; rem -= w; }
-        if (k >= (1u << 23)) { q = k / w; rem = k % w; }  // exactness of the float path ends at 2^23
-        const uint32_t key = (y0 + q) * tiles_x + (x0 + rem);
-        if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
-        else entry_keys[e] = key;
-        entry_vals[e] = sorted_idx[pos];
-        atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
-    }
-    if (tile_hist) {  // digit counts of sort tile blockIdx.x for the tile-id sort's first pass ([digit][tile])
-        __syncthreads();
-        uint32_t c = 0;
-#pragma unroll
-        for (int r = 0; r < EMIT_COPIES; ++r) c += s_hist[tid * EMIT_COPIES + r];
-        if ((uint32_t)tid <= tile_hist_mask) tile_hist[(size_t)tid * tile_hist_pitch + slice] = c;
-    }
-    __syncthreads();  // LDS is reused by the next slice
+        __syncthreads();  // LDS is reused by the next slice
     }
 }
 
@@ -822,9 +741,15 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     uint32_t blocks = (b.entry_cap + EMIT_TILE - 1) / EMIT_TILE;
     if (blocks == 0) return WS_OK;
     if (blocks > 2048u) blocks = 2048u;  // slices are strided over; surplus workgroups are not free
-    hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx, b.rects_sorted, b.offsets,
-                       b.emit_start, b.entry_keys, b.entry_vals, b.counters, b.tiles_x, b.tile_hist, b.tile_hist_pitch,
-                       b.tile_hist_mask, b.key16);
+    emit::Source src;
+    src.sorted_idx = b.sorted_idx;
+    src.rects_sorted = b.rects_sorted;
+    src.offsets = b.offsets;
+    src.emit_start = b.emit_start;
+    src.counters = b.counters;
+    src.tiles_x = b.tiles_x;
+    hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, src, b.entry_keys, b.entry_vals, b.tile_hist,
+                       b.tile_hist_pitch, b.tile_hist_mask, b.key16);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }
