@@ -331,6 +331,22 @@ int ws_render_views(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* sc
  * reference) gives every in-flight frame its own renderer scratch, target and HIP stream. */
 int ws_measure(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, uint32_t num_samples,
                uint32_t frames_in_flight, float* fps);
+/* ---- view batches (BASELINE configs 4 / 5: many independent views of one resident scene) ----------------
+ * The reference renders one view at a time on one queue (lib.rs:422-431, bin/measure.rs:98-146).  A view batch keeps
+ * `frames_in_flight` frames going at once: frame i of the batch's life runs on renderer + HIP stream i mod
+ * frames_in_flight (private scratch each; the point cloud is shared).  ws_view_batch_render only ENQUEUES; the caller
+ * observes completion with ws_view_batch_sync.  d_targets[i] receives view i (device memory, format of the batch);
+ * targets may repeat with period frames_in_flight (a ring), since a slot's frames are ordered on its stream. */
+typedef struct ws_view_batch ws_view_batch;
+int ws_view_batch_create(ws_context* ctx, ws_color_format format, uint32_t sh_deg, int compressed,
+                         uint32_t frames_in_flight, ws_view_batch** out);
+void ws_view_batch_destroy(ws_view_batch* b);
+uint32_t ws_view_batch_frames_in_flight(const ws_view_batch* b);
+int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_splatting_args* views, uint32_t num_views,
+                         void* const* d_targets, size_t row_pitch_bytes, const float background[4]);
+int ws_view_batch_sync(ws_view_batch* b);
+ws_renderer* ws_view_batch_renderer(ws_view_batch* b, uint32_t slot); /* the renderer of a slot (stats, timers) */
+
 /* Display::render (renderer.rs:548-582) + display.wgsl:37-55: the splat image (premultiplied RGBA, renderer
  * format) composited with PREMULTIPLIED_ALPHA_BLENDING over a surface cleared to `background`, written as 8-bit
  * unorm in the surface's channel order (lib.rs:184-243 picks the surface format and strips the sRGB suffix). */

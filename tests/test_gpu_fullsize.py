@@ -166,3 +166,49 @@ def test_frames_in_flight_do_not_interfere(ws, ctx, oracle):
         for s in streams:
             hip.hipStreamDestroy(s)
         pc.close()
+
+
+def test_view_batch_matches_single_renders(ws, ctx, oracle):
+    """ws_view_batch_*: a batch with frames in flight (target ring of period frames_in_flight) gives, view by view, the
+    image the plain renderer gives."""
+    sc = scenes.c2(ws, oracle, n=300_000, viewport=(800, 600))
+    cams = synth.orbit_cameras(16, 800, 600, 800.0, 800.0)
+    views = []
+    for cj in cams[:7]:
+        cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, 800, 600)
+        cam.fit_near_far(sc.gpc.aabb)
+        views.append(ws.SplattingArgs(camera=cam, viewport=(800, 600), max_sh_deg=3))
+    pc = ws.PointCloud(ctx, sc.gpc)
+    r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    batch = ws.ViewBatch(ctx, "rgba32float", 3, False, frames_in_flight=3)
+    nbytes = 800 * 600 * 16
+    bufs = [ctx.malloc(nbytes) for _ in range(7)]
+    try:
+        assert batch.frames_in_flight == 3
+        alone = []
+        for v in views:
+            r.prepare(pc, v)
+            r.render(pc)
+            alone.append(r.download_target())
+        for rep in range(2):
+            batch.render(pc, views, bufs, 800 * 16)      # seven frames over three slots, distinct targets
+            batch.sync()
+            for i in range(7):
+                assert np.array_equal(ctx.download(bufs[i], (600, 800, 4), np.float32), alone[i]), (rep, i)
+        ring = [bufs[i % 3] for i in range(6)]             # a ring of period frames_in_flight: last writer wins
+        batch2 = ws.ViewBatch(ctx, "rgba32float", 3, False, frames_in_flight=3)
+        batch2.render(pc, views[:6], ring, 800 * 16)
+        batch2.sync()
+        for k in range(3):
+            assert np.array_equal(ctx.download(bufs[k], (600, 800, 4), np.float32), alone[3 + k])
+        st = batch2.renderer(0).frame_stats()
+        assert st["overflow"] == 0 and st["num_visible"] > 0
+        batch2.close()
+        with pytest.raises(ws.WebSplatError):
+            ws.ViewBatch(ctx, "rgba32float", 3, False, frames_in_flight=0)
+    finally:
+        for b in bufs:
+            ctx.free(b)
+        batch.close()
+        r.close()
+        pc.close()

@@ -173,6 +173,12 @@ SIGNATURES = {
     "ws_png_write_rgba8": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _P, C.c_size_t]),
     "ws_render_views": (C.c_int, [_P, _P, _P, C.c_int, C.c_char_p, _u32p]),
     "ws_measure": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _f32p]),
+    "ws_view_batch_create": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_int, C.c_uint32, _PP]),
+    "ws_view_batch_destroy": (None, [_P]),
+    "ws_view_batch_frames_in_flight": (C.c_uint32, [_P]),
+    "ws_view_batch_render": (C.c_int, [_P, _P, C.POINTER(ws_splatting_args), C.c_uint32, _PP, C.c_size_t, _f32p]),
+    "ws_view_batch_sync": (C.c_int, [_P]),
+    "ws_view_batch_renderer": (C.c_void_p, [_P, C.c_uint32]),
     "ws_display_composite": (C.c_int, [_P, _P, C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, _f32p, C.c_int, _P,
                                        C.c_size_t, _P]),
     "ws_pointcloud_create": (C.c_int, [_P, C.POINTER(ws_pointcloud_desc), _PP]),

@@ -590,6 +590,56 @@ class GaussianRenderer:
         return {"num_visible": nv.value, "splats": splats, "keys": keys, "sorted": sorted_idx, "src_index": src}
 
 
+class ViewBatch:
+    """Several frames in flight over one resident scene (ws_view_batch_*): the unit a rank renders its shard of views with."""
+
+    def __init__(self, ctx: Context, color_format: str = "rgba32float", sh_deg: int = 3, compressed: bool = False,
+                 frames_in_flight: int = 4):
+        self.ctx = ctx
+        self.color_format_name = color_format
+        fmt, self.np_dtype, self.texel_bytes = FORMATS[color_format]
+        h = C.c_void_p()
+        check(lib.ws_view_batch_create(ctx.handle, fmt, int(sh_deg), int(compressed), int(frames_in_flight), C.byref(h)))
+        self.handle = h
+        self.frames_in_flight = lib.ws_view_batch_frames_in_flight(h)
+
+    def close(self):
+        if self.handle:
+            lib.ws_view_batch_destroy(self.handle)
+            self.handle = None
+
+    @staticmethod
+    def pack_views(views):
+        """SplattingArgs list -> contiguous ws_splatting_args array (convert once, render many times)."""
+        arr = (L.ws_splatting_args * len(views))()
+        for i, v in enumerate(views):
+            arr[i] = v.to_c()
+        return arr
+
+    def render(self, pc: "PointCloud", views, target_ptrs, row_pitch: int, background=(0.0, 0.0, 0.0, 0.0)):
+        """Enqueue len(views) frames (views: list of SplattingArgs or a pack_views() array); returns immediately."""
+        arr = views if isinstance(views, C.Array) else ViewBatch.pack_views(views)
+        n = len(arr)
+        tp = target_ptrs if isinstance(target_ptrs, C.Array) else (C.c_void_p * n)(*[int(p) for p in target_ptrs])
+        bg = (C.c_float * 4)(*[float(x) for x in background])
+        check(lib.ws_view_batch_render(self.handle, pc.handle, arr, n, tp, int(row_pitch), bg))
+
+    def sync(self):
+        check(lib.ws_view_batch_sync(self.handle))
+
+    def renderer(self, slot: int) -> "GaussianRenderer":
+        """A non-owning view of slot's renderer (frame_stats, timers)."""
+        r = GaussianRenderer.__new__(GaussianRenderer)
+        r.ctx = self.ctx
+        r.color_format_name = self.color_format_name
+        _, r.np_dtype, r.texel_bytes = FORMATS[self.color_format_name]
+        r.handle = C.c_void_p(lib.ws_view_batch_renderer(self.handle, int(slot)))
+        r._own_target = None
+        r._own_target_shape = None
+        r.close = lambda: None
+        return r
+
+
 class GPURSSorter:
     """gpu_rs.rs: GPURSSorter::new + create_sort_stuff(max_n); sort() = record_sort / record_sort_indirect."""
 
