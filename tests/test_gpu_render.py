@@ -53,9 +53,10 @@ def test_image_c1(ws, ctx, oracle):
         pc.close()
 
 
-@pytest.mark.parametrize("viewport", [(801, 599), (16, 16), (17, 33), (250, 7)])
+@pytest.mark.parametrize("viewport", [(801, 599), (16, 16), (17, 33), (250, 7), (4096, 4096)])
 def test_image_odd_viewports(ws, ctx, oracle, viewport):
-    """Viewports that are not multiples of the 16-px tile, down to a single tile."""
+    """Viewports that are not multiples of the 16-px tile, down to a single tile (one 6-bit sort pass, ranges written by
+    that pass), up to 65536 tiles (two 8-bit passes, 32-bit tile keys instead of 16-bit ones)."""
     sc = scenes.c1(ws, oracle, n=3000, viewport=viewport, seed=9)
     pc, img, _ = _render(ws, ctx, sc)
     try:
