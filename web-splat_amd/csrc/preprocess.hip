@@ -29,6 +29,12 @@ namespace {
 
 constexpr int K1_THREADS = 256;
 constexpr int K1_ITEMS = 4;  // Gaussians per thread
+#ifndef WS_K1_BACK_GROUP
+#define WS_K1_BACK_GROUP 2
+#endif
+constexpr int K1_BACK_GROUP = WS_K1_BACK_GROUP;  // survivors whose covariance + SH planes are in flight together
+// (1 instead of 2: 117 instead of 143 VGPRs, four waves per SIMD instead of three -- and the same 53 us: the kernel
+//  runs its ~36 us of HBM traffic and ~20 us of VALU work one after the other, whatever the occupancy)
 
 __device__ __forceinline__ float h2f(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)(h & 0xFFFFu))); }
 __device__ __forceinline__ uint32_t f2h(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
@@ -572,16 +578,16 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
     if (!COMPRESSED) {
         const uint32_t safe_idx = block_base < n ? block_base : 0u;  // culled lanes re-read this (cached) record
 #pragma unroll
-        for (int pair = 0; pair < K1_ITEMS; pair += 2) {
-            RawBack rb[2];
+        for (int grp = 0; grp < K1_ITEMS; grp += K1_BACK_GROUP) {
+            RawBack rb[K1_BACK_GROUP];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int it = pair + u;
+            for (int u = 0; u < K1_BACK_GROUP; ++u) {
+                const int it = grp + u;
                 k1_back_load(p, b, vis[it] ? block_base + it * K1_THREADS + tid : safe_idx, &rb[u]);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int it = pair + u;
+            for (int u = 0; u < K1_BACK_GROUP; ++u) {
+                const int it = grp + u;
                 if (vis[it]) k1_back_math(p, fr[it], rb[u], &so[it]);
             }
         }
@@ -593,6 +599,8 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
 
     // ---- ordered compaction, part 2: look-back (wave 0) and scatter ----------------------------------------
     if (wave == 0) {
+        // (measured: replacing the ordered look-back by one unordered atomicAdd per block does not change this kernel's
+        // time -- determinism is free here)
         const uint32_t excl = lb::wave_lookback(b.block_status, bid, p.epoch, lane, &b.counters->overflow, 2u);
         if (lane == 0) {
             s_base = excl;
