@@ -162,7 +162,7 @@ typedef struct ws_kernel_time {
 /* device-side statistics of the last prepared frame (forces a sync) */
 typedef struct ws_frame_stats {
     uint32_t num_visible;      /* V: renderer.rs:170-189 num_visible_points */
-    uint32_t num_tile_entries; /* D: sum over visible splats of 16x16 tiles touched */
+    uint32_t num_tile_entries; /* D: sum over visible splats of tiles touched */
     uint32_t tile_entries_capacity;
     uint32_t overflow;         /* 1 if D exceeded the capacity (entries dropped) */
 } ws_frame_stats;
@@ -278,7 +278,16 @@ int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries);
  * (far -> near).  Any pointer may be NULL.  capacity = number of elements each array can hold. Syncs. */
 int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, uint32_t* keys,
                                uint32_t* src_index, uint32_t* sorted, uint32_t* num_visible);
-/* tuning / analysis read-back: per 16x16 tile, the length of its depth-ordered splat list and (capture mode)
+/* The binning tile in pixels: 16x16 (the north star's tile; one workgroup of 2x2 wave quadrants), or 32x16 / 32x32
+ * when two / four such tiles share one binned list (WS_TILE_SHAPE=2x2|4x2|4x4 at context creation; tuning). */
+int ws_context_tile_size(const ws_context* ctx, uint32_t* width, uint32_t* height);
+/* test hook, host only (no device work): the compositing pass's staging step for ONE (tile, splat) entry --
+ * splat = the five 32-bit words of a 20-B Splat record (pointcloud.rs:352-358), tile origin in pixels ->
+ * rec[10] = {i00, i01, c0, i10, i11, c1, alpha, r, g, b} (tile-local affine form of gaussian.wgsl:59-61 in the
+ * exp2 domain) and the mask of 8x8-pixel quadrants (bit qy * (tile_w / 8) + qx) the kept ellipse may reach. */
+int ws_debug_stage_splat(const uint32_t splat[5], float viewport_w, float viewport_h, float tile_x0, float tile_y0,
+                         uint32_t tile_w, uint32_t tile_h, float rec[10], uint32_t* quadrant_mask);
+/* tuning / analysis read-back: per tile, the length of its depth-ordered splat list and (capture mode)
  * how many of its entries the compositing pass walked before every pixel was saturated.  Syncs. */
 int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t* list_len, uint32_t* consumed,
                                     uint32_t* num_tiles);

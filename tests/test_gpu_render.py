@@ -260,10 +260,16 @@ def test_ply_file_roundtrip(ws, ctx, oracle, tmp_path):
             pc.close()
 
 
-@pytest.mark.parametrize("env", [{"WS_SORT_ALGO": "1"}, {"WS_BLEND_VARIANT": "1"}, {"WS_SORT_ALGO": "1", "WS_BLEND_VARIANT": "1"}])
+@pytest.mark.parametrize("env", [{"WS_SORT_ALGO": "1"}, {"WS_BLEND_VARIANT": "1"}, {"WS_SORT_ALGO": "1", "WS_BLEND_VARIANT": "1"},
+                                 {"WS_TILE_SHAPE": "2x2"}, {"WS_TILE_SHAPE": "4x2"}, {"WS_TILE_SHAPE": "4x4"},
+                                 {"WS_TILE_SHAPE": "4x2", "WS_BLEND_VARIANT": "1"},
+                                 {"WS_TILE_SHAPE": "4x4", "WS_BLEND_VARIANT": "1", "WS_SORT_ALGO": "1"},
+                                 {"WS_TILE_SHAPE": "4x4", "WS_BLEND_TPW_LOG2": "1"},
+                                 {"WS_TILE_SHAPE": "4x2", "WS_BLEND_TPW_LOG2": "2"}])
 def test_cross_check_paths(ws, oracle, env, monkeypatch):
-    """The alternative implementations kept as cross-checks (one-sweep look-back sort, wave-per-quadrant blend) must
-    give the same image as the default path: a context reads the selection from the environment when it is created."""
+    """The alternative implementations kept as cross-checks (one-sweep look-back sort, wave-per-quadrant blend) and
+    every tile shape (16x16, 32x16, 32x32 binning tiles) must give the same image as the oracle: a context reads the
+    selection from the environment when it is created."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     c = ws.Context(0)
@@ -280,11 +286,32 @@ def test_cross_check_paths(ws, oracle, env, monkeypatch):
         c.close()
 
 
-def _coverage_tiles(splats_f16, viewport):
-    """For every splat: the set of 16x16 tiles holding at least one pixel centre with a <= 2*CUTOFF, evaluated as the
+@pytest.mark.parametrize("shape", ["2x2", "4x2", "4x4"])
+@pytest.mark.parametrize("viewport", [(801, 599), (17, 33), (250, 7), (1283, 721)])
+def test_tile_shapes_odd_viewports(ws, oracle, shape, viewport, monkeypatch):
+    """Every binning-tile shape on viewports that are not multiples of the tile (partial quadrants, partial 64-px
+    blocks, a single tile)."""
+    monkeypatch.setenv("WS_TILE_SHAPE", shape)
+    c = ws.Context(0)
+    try:
+        sc = scenes.c1(ws, oracle, n=4000, viewport=viewport, seed=13)
+        pc, img, stats = _render(ws, c, sc)
+        try:
+            ref, _ = sc.oracle_image(pc)
+            _assert_close(img, ref)
+            assert stats["overflow"] == 0
+        finally:
+            pc.close()
+    finally:
+        c.close()
+
+
+def _coverage_tiles(splats_f16, viewport, tile=(16, 16)):
+    """For every splat: the set of tiles holding at least one pixel centre with a <= 2*CUTOFF, evaluated as the
     oracle does (oracle/ws_oracle.c setup_splat + wso_render), in float64 with a small slack towards 'covered'."""
     w, h = viewport
-    tx_n = (w + 15) // 16
+    tw, th = tile
+    tx_n = (w + tw - 1) // tw
     out = []
     cut = 2 * 2.3539888583335364
     for s in splats_f16.astype(np.float64):
@@ -304,16 +331,23 @@ def _coverage_tiles(splats_f16, viewport):
                 dx, dy = np.meshgrid(xs, ys)
                 a = (i00 * dx + i01 * dy) ** 2 + (i10 * dx + i11 * dy) ** 2
                 yy, xx = np.nonzero(a <= cut * (1 - 1e-6))
-                tiles = set(((yy + y0) // 16 * tx_n + (xx + x0) // 16).tolist())
+                tiles = set(((yy + y0) // th * tx_n + (xx + x0) // tw).tolist())
         out.append(tiles)
     return out
 
 
+@pytest.mark.parametrize("shape", [None, "2x2", "4x2", "4x4"])
 @pytest.mark.parametrize("kind", ["c1", "needles"])
-def test_binning_covers_every_touched_tile(ws, ctx, oracle, kind):
+def test_binning_covers_every_touched_tile(ws, oracle, kind, shape, monkeypatch):
     """Binning hands every tile of the kept ellipse's bounding rectangle to the blend.  It may list a tile the ellipse
     misses (the blend's exact per-quadrant test drops it) but never drop one it touches: every tile holding a covered
     pixel centre must list the splat, exactly once, and each tile's list must be in draw order."""
+    if shape:
+        monkeypatch.setenv("WS_TILE_SHAPE", shape)
+    ctx = ws.Context(0)
+    tile = ctx.tile_size()
+    if shape:
+        assert tile == (8 * int(shape[0]), 8 * int(shape[2]))
     if kind == "c1":
         rows = synth.scene_c1(n=6000, seed=21)
     else:  # long thin splats at all orientations: the case a bounding rectangle is worst at
@@ -347,7 +381,8 @@ def test_binning_covers_every_touched_tile(ws, ctx, oracle, kind):
             assert np.all(np.diff(rank[e]) > 0)                        # far -> near inside the tile
             for sidx in e.tolist():
                 listed[sidx].add(t)
-        cov = _coverage_tiles(fr["splats"].view(np.float16).reshape(-1, 10), viewport)
+        assert len(begin) == -(-viewport[0] // tile[0]) * -(-viewport[1] // tile[1])
+        cov = _coverage_tiles(fr["splats"].view(np.float16).reshape(-1, 10), viewport, tile)
         missing = [(i, sorted(c - listed[i])) for i, c in enumerate(cov) if not c <= listed[i]]
         assert not missing, missing[:5]
         n_cov, n_listed = sum(len(c) for c in cov), sum(len(l) for l in listed)
@@ -355,3 +390,4 @@ def test_binning_covers_every_touched_tile(ws, ctx, oracle, kind):
     finally:
         r.close()
         pc.close()
+        ctx.close()

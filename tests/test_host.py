@@ -125,3 +125,61 @@ def test_write_ply_layout(tmp_path):
     head, body = raw.split(b"end_header\n", 1)
     assert head.startswith(b"ply\nformat binary_little_endian 1.0\n")
     assert head.count(b"property float") == 62 and len(body) == 10 * 248
+
+
+# ---- the compositing pass's staging step (blend_stage.h), host twin through the ABI -----------------------------
+def _random_splat_words(rng, viewport, tile_origin, tile):
+    """A 20-B Splat record (pointcloud.rs:352-358) whose ellipse lies somewhere around the tile: sizes from
+    sub-pixel to thousands of pixels, anisotropy up to ~1e4."""
+    W, H = viewport
+    s1 = np.exp(rng.uniform(np.log(0.3), np.log(3000.0)))
+    s2 = s1 * np.exp(rng.uniform(-1, 1)) if rng.random() < 0.4 else np.exp(rng.uniform(np.log(0.3), np.log(3000.0)))
+    th = rng.uniform(0, 2 * np.pi)
+    reach = 2.3 * max(s1, s2) + max(tile)
+    cx = tile_origin[0] + tile[0] / 2 + rng.uniform(-1, 1) * reach
+    cy = tile_origin[1] + tile[1] / 2 + rng.uniform(-1, 1) * reach
+    if rng.random() < 0.25:
+        cx = tile_origin[0] + rng.uniform(0, tile[0])
+        cy = tile_origin[1] + rng.uniform(0, tile[1])
+    c, s = np.cos(th), np.sin(th)
+    # M = [[m00, m01], [m10, m11]] in pixels; v1 = (m00 / W, -m10 / H), v2 = (m01 / W, -m11 / H)
+    m00, m01, m10, m11 = c * s1, -s * s2, s * s1, c * s2
+    halves = np.array([m00 / W, -m10 / H, m01 / W, -m11 / H, cx / W * 2 - 1, 1 - cy / H * 2,
+                       rng.random(), rng.random(), rng.random(), rng.random()], dtype=np.float32).astype(np.float16)
+    return halves.view(np.uint32)
+
+
+@pytest.mark.parametrize("tile", [(16, 16), (32, 16), (32, 32)])
+def test_quadrant_mask_never_drops_a_covered_pixel(ws, tile):
+    """The staged record's quadrant mask only prunes work: every pixel centre the per-pixel test keeps
+    (a' <= 2*CUTOFF*log2 e, evaluated in f32 exactly as the kernel does) must lie in a quadrant whose bit is set;
+    and the mask must stay tight (few quadrants flagged that hold no kept pixel)."""
+    rng = np.random.default_rng(7)
+    viewport = (1920.0, 1080.0)
+    cut = np.float32(2 * 2.3539888583335364 * 1.4426950408889634)
+    qw = tile[0] // 8
+    ys, xs = np.mgrid[0:tile[1], 0:tile[0]]
+    lx = (xs + 0.5).astype(np.float32)
+    ly = (ys + 0.5).astype(np.float32)
+    quad = (ys // 8) * qw + (xs // 8)
+    needed = flagged = 0
+    for trial in range(6000):
+        origin = (float(tile[0] * rng.integers(0, 40)), float(tile[1] * rng.integers(0, 30)))
+        words = _random_splat_words(rng, viewport, origin, tile)
+        rec, mask = ws.stage_splat(words, viewport, origin, tile)
+        if not np.all(np.isfinite(rec[:6])):
+            continue
+        # a' per pixel centre: same operation order as blend_composite (fma chains), in f64-free f32
+        p0 = rec[0] * lx + (rec[1] * ly + rec[2])
+        p1 = rec[3] * lx + (rec[4] * ly + rec[5])
+        a = p0 * p0 + p1 * p1
+        # allow for fma-vs-separate rounding: treat anything within a relative 1e-5 of the cut-off as kept
+        kept = a <= cut * np.float32(1.00001)
+        truth = 0
+        for q in np.unique(quad[kept]):
+            truth |= 1 << int(q)
+        assert truth & ~mask == 0, (trial, hex(truth), hex(mask), words)
+        needed += bin(truth).count("1")
+        flagged += bin(mask).count("1")
+    assert needed > 2000
+    assert flagged <= needed * 1.02 + 10

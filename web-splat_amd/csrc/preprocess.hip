@@ -297,7 +297,7 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
 
     out->key = k1_depth_key<COMPRESSED>(p, pos2d[2]);
 
-    // 16x16-tile rectangle of the kept ellipse a <= 2*CUTOFF (gaussian.wgsl:40-64), derived from the
+    // tile rectangle of the kept ellipse a <= 2*CUTOFF (gaussian.wgsl:40-64), derived from the
     // f16-ROUNDED splat so that binning and blending agree on coverage.
     {
         const float q1x = h2f(h0), q1y = h2f(h1), q2x = h2f(h2), q2y = h2f(h3);
@@ -321,8 +321,8 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
             x_hi = fminf(x_hi, vw - 1.0f);
             y_hi = fminf(y_hi, vh - 1.0f);
             if (x_lo <= x_hi && y_lo <= y_hi) {
-                const uint32_t tx0 = (uint32_t)x_lo / TILE, tx1 = (uint32_t)x_hi / TILE;
-                const uint32_t ty0 = (uint32_t)y_lo / TILE, ty1 = (uint32_t)y_hi / TILE;
+                const uint32_t tx0 = (uint32_t)x_lo >> p.tile_w_log2, tx1 = (uint32_t)x_hi >> p.tile_w_log2;
+                const uint32_t ty0 = (uint32_t)y_lo >> p.tile_h_log2, ty1 = (uint32_t)y_hi >> p.tile_h_log2;
                 rect = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
             }
         }

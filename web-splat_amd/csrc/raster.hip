@@ -20,6 +20,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include "blend_stage.h"
 #include "emit_gen.h"
 #include "lookback.h"
 #include "ws_internal.h"
@@ -205,52 +206,49 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
 }
 
 // ---- k_blend ---------------------------------------------------------------------------------------
-// One workgroup = one 16x16 tile, one pixel per thread; wave w owns the 8x8 quadrant (w&1, w>>1).
-// Splats are staged through LDS 256 at a time in NEAR -> FAR order.  A staged record is the affine map
+// One workgroup = one tile of QW x QH quadrants (8x8 pixels each, one wave per quadrant, one pixel per lane):
+// 2x2 = the 16x16 tile of the north star, 4x2 / 4x4 = two / four such tiles sharing one binned list (fewer,
+// longer lists: every (tile, splat) entry costs sort and gather traffic, and a 24-px splat touches 8.3 16x16
+// tiles but only 4.4 32x16 ones).  Splats are staged through LDS STAGE at a time in NEAR -> FAR order.  A staged
+// record is the affine map
 //   screen_pos * sqrt(log2 e) = I' * pixel_local + c      (I' = sqrt(log2 e) * M^-1, c = -I' * centre_local)
 // in TILE-LOCAL pixel coordinates, so a' = |.|^2 = log2(e) * dot(screen_pos, screen_pos) of gaussian.wgsl:60 costs
 // four FMAs + a multiply-add per pixel and exp(-a) is a bare v_exp_f32 (2^-a').  Measured on MI355X (profiles/):
-// walking all 256 staged records with one dependent LDS read + branch each made the kernel latency-bound
-// (~30 us per batch); here every wave first compacts the staged records to those whose kept ELLIPSE (exact
-// ellipse-vs-square test, not the bounding box) reaches its quadrant -- 4 LDS reads + 4 ballots per batch -- and
-// then walks only those, with the next record's LDS reads in flight while the current one is composited.
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float SQRT_LOG2E = 1.2011224087864498f;
+// walking all staged records with one dependent LDS read + branch each made the kernel latency-bound
+// (~30 us per batch); here the staging thread also computes which quadrants the kept ELLIPSE reaches (exact
+// band-by-band x-range, blend_stage.h -- not the bounding box), every wave compacts the staged records to those
+// that reach its quadrant -- one LDS read + one ballot per 64 records -- and then walks only those, with the next
+// record's LDS reads in flight while the current one is composited.
+constexpr float LOG2E = stage::LOG2E_F;
 constexpr float CUT_A2 = CUT_A * LOG2E;  // gaussian.wgsl:61 cut-off, in the exp2 domain
 
-// min over y in [y0, y1] of the quadratic form A X^2 + B2 X y + C y^2 (C > 0), X fixed
-__device__ __forceinline__ float qform_min_on_edge(float A, float B2, float C, float rcpC, float X, float y0, float y1) {
-    const float ys = fminf(fmaxf(-0.5f * B2 * X * rcpC, y0), y1);
-    return (A * X + B2 * ys) * X + C * ys * ys;
-}
-
-// Does the kept ellipse {d : |N d|^2 <= cut} (centre at the origin) reach the square [x0,x1] x [y0,y1]?
-// Conservative by a relative 1e-4 margin (the per-pixel test is exact; this only prunes work).
-__device__ __forceinline__ bool ellipse_reaches_box(float A, float B2, float C, float rcpA, float rcpC, float x0,
-                                                    float x1, float y0, float y1, float cut) {
-    if (x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f) return true;
-    float q = qform_min_on_edge(A, B2, C, rcpC, x0, y0, y1);
-    q = fminf(q, qform_min_on_edge(A, B2, C, rcpC, x1, y0, y1));
-    q = fminf(q, qform_min_on_edge(C, B2, A, rcpA, y0, x0, x1));
-    q = fminf(q, qform_min_on_edge(C, B2, A, rcpA, y1, x0, x1));
-    return q <= cut * 1.0001f + 1e-4f;
-}
-
-// blockIdx -> tiles.  4x4-tile blocks (64x64 px) are dealt round-robin to the 8 XCDs (workgroup b runs on XCD
-// b % 8 -- observed, used for locality only): a splat's tiles mostly share a block, so its 20-B record and the
-// neighbouring entry lists are served by ONE L2, while every XCD gets blocks from all over the image.
-// A workgroup composites `tpw` = 2^tpw_log2 tiles of its block one after the other (the block's 16 tiles are split
-// over 16 / tpw workgroups, interleaved): with tens of thousands of tiles (4K) one workgroup per tile is bound by the
+// blockIdx -> tiles.  64x64-pixel blocks (16 / 8 / 4 tiles) are dealt round-robin to the 8 XCDs (workgroup b runs
+// on XCD b % 8 -- observed, used for locality only): a splat's tiles mostly share a block, so its 20-B record and
+// the neighbouring entry lists are served by ONE L2, while every XCD gets blocks from all over the image.
+// A workgroup composites `tpw` = 2^tpw_log2 tiles of its block one after the other (the block's tiles are split
+// over tpb / tpw workgroups, interleaved): with tens of thousands of tiles (4K) one workgroup per tile is bound by the
 // three dependent loads each workgroup starts with; here the next tile's loads are in flight while the current tile
 // is composited.
 struct BlendBlock {
-    uint32_t bx, by;   // 4x4-tile block coordinates
+    uint32_t bx, by;   // 64x64-px block coordinates
     uint32_t w;        // this workgroup's lane inside the block: it owns tile slots w, w + wpb, w + 2 wpb, ...
     bool valid;
 };
-__device__ __forceinline__ BlendBlock blend_block_of(uint32_t b, uint32_t tiles_x, uint32_t tiles_y, uint32_t tpw_log2) {
-    const uint32_t nbx = (tiles_x + 3u) >> 2, nby = (tiles_y + 3u) >> 2;
-    const uint32_t wpb = 16u >> tpw_log2;
+struct BlendShape {
+    uint32_t tbx_log2, tby_log2;  // tiles per block along x / y = 8 / QW, 8 / QH
+    __host__ __device__ uint32_t tpb() const { return 1u << (tbx_log2 + tby_log2); }
+};
+__host__ __device__ inline BlendShape blend_shape(uint32_t qw, uint32_t qh) {
+    BlendShape s;
+    s.tbx_log2 = qw == 2u ? 2u : (qw == 4u ? 1u : 0u);
+    s.tby_log2 = qh == 2u ? 2u : (qh == 4u ? 1u : 0u);
+    return s;
+}
+__device__ __forceinline__ BlendBlock blend_block_of(uint32_t b, uint32_t tiles_x, uint32_t tiles_y, BlendShape sh,
+                                                     uint32_t tpw_log2) {
+    const uint32_t nbx = (tiles_x + (1u << sh.tbx_log2) - 1u) >> sh.tbx_log2;
+    const uint32_t nby = (tiles_y + (1u << sh.tby_log2) - 1u) >> sh.tby_log2;
+    const uint32_t wpb = sh.tpb() >> tpw_log2;
     const uint32_t xcd = b & 7u, j = b >> 3;
     const uint32_t blk = (j / wpb) * 8u + xcd;
     BlendBlock r;
@@ -260,16 +258,20 @@ __device__ __forceinline__ BlendBlock blend_block_of(uint32_t b, uint32_t tiles_
     r.by = r.valid ? blk / nbx : 0u;
     return r;
 }
-__host__ __device__ inline uint32_t blend_grid_blocks(uint32_t tiles_x, uint32_t tiles_y, uint32_t tpw_log2) {
-    const uint32_t nb = ((tiles_x + 3u) >> 2) * ((tiles_y + 3u) >> 2);
-    return ((nb + 7u) / 8u) * 8u * (16u >> tpw_log2);
+inline uint32_t blend_grid_blocks(uint32_t tiles_x, uint32_t tiles_y, BlendShape sh, uint32_t tpw_log2) {
+    const uint32_t nbx = (tiles_x + (1u << sh.tbx_log2) - 1u) >> sh.tbx_log2;
+    const uint32_t nby = (tiles_y + (1u << sh.tby_log2) - 1u) >> sh.tby_log2;
+    const uint32_t nb = nbx * nby;
+    return ((nb + 7u) / 8u) * 8u * (sh.tpb() >> tpw_log2);
 }
 // Tiles per workgroup, measured on MI355X (WS_BLEND_TPW_LOG2 overrides): one tile per workgroup gives the lowest
 // frame latency up to 1080p (more tiles per workgroup serialise the per-tile barriers: 65 -> 76 us on c2 at two
-// tiles); at 4K-class tile counts (32 k tiles, mostly short lists) four tiles per workgroup are as fast alone and 4 %
-// faster with several frames in flight.
-inline uint32_t blend_tpw_log2(uint32_t tiles_x, uint32_t tiles_y) {
-    return (tiles_x * tiles_y > 16384u) ? 2u : 0u;
+// 16x16 tiles); at 4K-class tile counts (32 k tiles, mostly short lists) four tiles per workgroup are as fast alone
+// and 4 % faster with several frames in flight.
+inline uint32_t blend_tpw_log2(uint32_t tiles_x, uint32_t tiles_y, BlendShape sh) {
+    const uint32_t want = (tiles_x * tiles_y > 16384u) ? 2u : 0u;
+    const uint32_t most = sh.tbx_log2 + sh.tby_log2;
+    return want < most ? want : most;
 }
 
 template <int FORMAT>
@@ -297,9 +299,10 @@ struct RawSplat {
 };
 // Unconditional gather of this thread's entry of the batch that ends at `hi` (slot 0 = nearest).  The address
 // is clamped into the tile's range, so the loads never depend on a branch and can be issued a whole batch ahead.
+template <int STAGE>
 __device__ __forceinline__ RawSplat blend_fetch_raw(const BlendParams& p, uint2 range, uint32_t hi, int tid) {
     const uint32_t h = hi > range.x ? hi : range.x + 1u;
-    const uint32_t nb = (h - range.x) < 256u ? (h - range.x) : 256u;
+    const uint32_t nb = (h - range.x) < (uint32_t)STAGE ? (h - range.x) : (uint32_t)STAGE;
     const uint32_t off = (uint32_t)tid < nb ? (uint32_t)tid : nb - 1u;
     const uint32_t idx = p.entry_vals[h - 1u - off];
     const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx * 20);
@@ -312,61 +315,81 @@ __device__ __forceinline__ RawSplat blend_fetch_raw(const BlendParams& p, uint2 
     return r;
 }
 
-// LDS layout of a staged batch: three planes of 16-B records with the SAME slot stride, so one byte offset
-// (slot * 16, what the per-wave lists store) addresses all three with immediate offsets.  Slot 256 is a null
-// record (a' far beyond the cut-off) that pads the lists to multiples of four.
-constexpr int BLEND_SLOTS = 257;
+// LDS layout of a staged batch: two planes of 16-B records with the SAME slot stride, so one byte offset
+// (slot * 16, what the per-wave lists store) addresses both with immediate offsets: two ds_read_b128 per record
+// (4 LDS cycles each; the LDS array serves the CU's four SIMDs, and at ~16 VALU instructions per (record, wave)
+// a third read made the LDS the co-limiter).  The colour and opacity stay the f16 pairs of the Splat record
+// (words 3 and 4, copied verbatim): v_fma_mix_f32 takes f16 operands, so keeping them packed costs no conversion
+// and no precision.  Slot STAGE is a null record (a' far beyond the cut-off) that pads the lists to multiples of four.
 struct BlendRec {
-    float4 g;  // i00', i01', c0, alpha
-    float4 h;  // i10', i11', c1, r
-    float2 c;  // g, b
+    float4 g;  // i00', i01', c0, i10'
+    float4 h;  // i11', c1, (r | g << 16) f16x2, (b | alpha << 16) f16x2
 };
+template <int SLOTS>
 __device__ __forceinline__ BlendRec blend_load_rec(const float4* s_rec, uint32_t byte_off) {
     const char* base = reinterpret_cast<const char*>(s_rec) + byte_off;
     BlendRec r;
     r.g = *reinterpret_cast<const float4*>(base);
-    r.h = *reinterpret_cast<const float4*>(base + BLEND_SLOTS * 16);
-    r.c = *reinterpret_cast<const float2*>(base + 2 * BLEND_SLOTS * 16);
+    r.h = *reinterpret_cast<const float4*>(base + SLOTS * 16);
     return r;
 }
 // One (pixel, splat) pair: gaussian.wgsl:59-66 in the exp2 domain, front-to-back "over".
 __device__ __forceinline__ void blend_composite(const BlendRec& r, float lx, float ly, float& T, float& cr, float& cg,
                                                 float& cb) {
     const float p0 = fmaf(r.g.x, lx, fmaf(r.g.y, ly, r.g.z));
-    const float p1 = fmaf(r.h.x, lx, fmaf(r.h.y, ly, r.h.z));
+    const float p1 = fmaf(r.g.w, lx, fmaf(r.h.x, ly, r.h.y));
     const float a = fmaf(p0, p0, p1 * p1);
     if (a <= CUT_A2) {
-        const float b = fminf(0.99f, __builtin_amdgcn_exp2f(-a) * r.g.w);
+        // b = min(0.99, 2^-a' * alpha), alpha = high half of h.w.  One asm block: gfx950 needs one wait state between
+        // a transcendental's result and a VALU instruction reading it, and the compiler does not look inside asm.
+        float b;
+        asm("v_exp_f32_e64 %0, -%1\n\ts_nop 0\n\t"
+            "v_fma_mix_f32 %0, %0, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n\t"
+            "v_min_f32_e32 %0, 0x3f7d70a4, %0"
+            : "=&v"(b)
+            : "v"(a), "v"(r.h.w));
         const float wgt = b * T;
-        // three plain v_fmac: the compiler's v_pk_fma_f32 pairing costs a v_pk_mov and issues at half rate on gfx950
-        asm("v_fmac_f32 %0, %1, %2" : "+v"(cr) : "v"(wgt), "v"(r.h.w));
-        asm("v_fmac_f32 %0, %1, %2" : "+v"(cg) : "v"(wgt), "v"(r.c.x));
-        asm("v_fmac_f32 %0, %1, %2" : "+v"(cb) : "v"(wgt), "v"(r.c.y));
+        // plain (mixed-precision) FMAs: the compiler's v_pk_fma_f32 pairing costs a v_pk_mov and issues at half rate
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(cr) : "v"(wgt), "v"(r.h.z));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(cg) : "v"(wgt), "v"(r.h.z));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(cb) : "v"(wgt), "v"(r.h.w));
         T -= wgt;
     }
 }
 
-template <int FORMAT>
-__global__ __launch_bounds__(256) void k_blend(const BlendParams p, const uint32_t tpw_log2) {
-    __shared__ float4 s_rec[3 * BLEND_SLOTS];
-    __shared__ uint32_t s_m[256];  // quadrant bits of the staged record (0 = slot unused)
+#ifndef WS_BLEND_MINWAVES
+#define WS_BLEND_MINWAVES 1
+#endif
+template <int FORMAT, int QW, int QH, bool MULTI>
+__global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const BlendParams p, const uint32_t tpw_log2_arg) {
+    const uint32_t tpw_log2 = MULTI ? tpw_log2_arg : 0u;  // MULTI = several tiles per workgroup (4K-class tile counts)
+    constexpr int NW = QW * QH;                  // waves = quadrants
+    constexpr int NT = 64 * NW;
+    constexpr int STAGE = NT < 512 ? NT : 512;   // entries staged per batch
+    constexpr int SLOTS = STAGE + 1;
+    constexpr int TW = 8 * QW, TH = 8 * QH;
+    __shared__ float4 s_rec[2 * SLOTS];
+    __shared__ uint32_t s_m[STAGE];  // quadrant bits of the staged record (0 = slot unused)
     // per wave: byte offsets of the staged records that reach its quadrant, near -> far, padded with the null record
-    __shared__ __attribute__((aligned(16))) uint32_t s_list[4][272];
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[NW][STAGE + 16];
     __shared__ uint2 s_range[16];   // [begin, end) of this workgroup's tiles in the sorted entry list
     __shared__ uint32_t s_txy[16];  // tx | ty << 16, or 0xFFFFFFFF for a slot outside the image
 
-    const BlendBlock blk = blend_block_of(blockIdx.x, p.tiles_x, p.tiles_y, tpw_log2);
+    const BlendShape shape = blend_shape(QW, QH);
+    const BlendBlock blk = blend_block_of(blockIdx.x, p.tiles_x, p.tiles_y, shape, tpw_log2);
     if (!blk.valid) return;  // block-uniform
-    const uint32_t tpw = 1u << tpw_log2, wpb = 16u >> tpw_log2;
+    const uint32_t tpw = 1u << tpw_log2, wpb = shape.tpb() >> tpw_log2;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int qx = wave & 1, qy = wave >> 1;
+    const int qx = wave % QW, qy = wave / QW;
     const float lx = (float)(qx * 8 + (lane & 7)) + 0.5f;  // tile-local pixel centre
     const float ly = (float)(qy * 8 + (lane >> 3)) + 0.5f;
     const uint32_t qbit = 1u << wave;
+    const bool stager = NT == STAGE || tid < STAGE;  // wave-uniform
     if ((uint32_t)tid < tpw) {  // the ranges of all my tiles up front: one round trip instead of one per tile
         const uint32_t slot = blk.w + (uint32_t)tid * wpb;
-        const uint32_t tx = blk.bx * 4u + (slot & 3u), ty = blk.by * 4u + (slot >> 2);
+        const uint32_t tx = (blk.bx << shape.tbx_log2) + (slot & ((1u << shape.tbx_log2) - 1u));
+        const uint32_t ty = (blk.by << shape.tby_log2) + (slot >> shape.tbx_log2);
         uint2 range = make_uint2(0u, 0u);
         uint32_t code = 0xFFFFFFFFu;
         if (tx < p.tiles_x && ty < p.tiles_y) {
@@ -378,18 +401,17 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p, const uint32
         s_txy[tid] = code;
     }
     if (tid == 0) {  // the null record: a' = 1e18, never inside the cut-off (visible after the first barrier)
-        s_rec[256] = make_float4(0.0f, 0.0f, 1.0e9f, 0.0f);
-        s_rec[BLEND_SLOTS + 256] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        s_rec[2 * BLEND_SLOTS + 256] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_rec[STAGE] = make_float4(0.0f, 0.0f, 1.0e9f, 0.0f);
+        s_rec[SLOTS + STAGE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     __syncthreads();
     const float W = (float)p.width, H = (float)p.height;
     uint32_t* my_list = s_list[wave];
 
     RawSplat raw = {0u, 0u, 0u, 0u, 0u};
-    {
+    if (stager) {
         const uint2 r0 = s_range[0];
-        if (r0.y > r0.x) raw = blend_fetch_raw(p, r0, r0.y, tid);  // (an empty tile must not touch the entry list)
+        if (r0.y > r0.x) raw = blend_fetch_raw<STAGE>(p, r0, r0.y, tid);  // (an empty tile must not touch the entry list)
     }
     for (uint32_t k = 0; k < tpw; ++k) {
     const uint32_t code = s_txy[k];
@@ -397,59 +419,45 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p, const uint32
     // the first batch of the NEXT tile (entry index -> Splat record: two dependent round trips) flies while this
     // tile is composited
     RawSplat raw_next_tile = {0u, 0u, 0u, 0u, 0u};
-    if (k + 1u < tpw) {
+    if (MULTI && stager && k + 1u < tpw) {
         const uint2 rn = s_range[k + 1u];
-        if (rn.y > rn.x) raw_next_tile = blend_fetch_raw(p, rn, rn.y, tid);
+        if (rn.y > rn.x) raw_next_tile = blend_fetch_raw<STAGE>(p, rn, rn.y, tid);
     }
     if (code != 0xFFFFFFFFu) {  // block-uniform
     const uint32_t tx = code & 0xFFFFu, ty = code >> 16;
     const uint32_t tile = ty * p.tiles_x + tx;
-    const uint32_t px = tx * TILE + qx * 8 + (lane & 7);
-    const uint32_t py = ty * TILE + qy * 8 + (lane >> 3);
+    const uint32_t px = tx * TW + qx * 8 + (lane & 7);
+    const uint32_t py = ty * TH + qy * 8 + (lane >> 3);
     const bool inside = px < p.width && py < p.height;
     // Pixels outside the image start with T = 0: they accumulate nothing and count as saturated.  There is no
     // per-pixel "done" flag in the inner loop: a pixel below T_MIN keeps accumulating (its contributions are
     // below T_MIN, the reference has no cut-off at all); T only decides when a wave / the tile may stop.
     float T = inside ? 1.0f : 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
+    const float tile_x0 = (float)(tx * TW), tile_y0 = (float)(ty * TH);
 
     uint32_t hi = range.y;
     while (hi > range.x) {
-        const uint32_t nb = (hi - range.x) < 256u ? (hi - range.x) : 256u;
-        uint32_t mask = 0u;
-        if ((uint32_t)tid < nb) {
-            const float v1x = h2f(raw.w0), v1y = h2f(raw.w0 >> 16), v2x = h2f(raw.w1), v2y = h2f(raw.w1 >> 16);
-            const float m00 = v1x * W, m01 = v2x * W;
-            const float m10 = -v1y * H, m11 = -v2y * H;
-            const float det = m00 * m11 - m01 * m10;
-            const float inv = SQRT_LOG2E / det;
-            const float cxl = (h2f(raw.w2) * 0.5f + 0.5f) * W - tile_x0;  // centre, tile-local pixels
-            const float cyl = (0.5f - h2f(raw.w2 >> 16) * 0.5f) * H - tile_y0;
-            const float i00 = m11 * inv, i01 = -m01 * inv, i10 = -m10 * inv, i11 = m00 * inv;
-            const float c0 = -(i00 * cxl + i01 * cyl), c1 = -(i10 * cxl + i11 * cyl);
-            // a'(d) = A dx^2 + B2 dx dy + C dy^2 around the centre
-            const float A = i00 * i00 + i10 * i10, C = i01 * i01 + i11 * i11, B2 = 2.0f * (i00 * i01 + i10 * i11);
-            const float rcpA = __builtin_amdgcn_rcpf(A), rcpC = __builtin_amdgcn_rcpf(C);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // pixel centres of quadrant q span [q*8 + 0.5, q*8 + 7.5] in tile-local coordinates
-                const float x0 = (float)((q & 1) * 8) + 0.5f - cxl, y0 = (float)((q >> 1) * 8) + 0.5f - cyl;
-                if (ellipse_reaches_box(A, B2, C, rcpA, rcpC, x0, x0 + 7.0f, y0, y0 + 7.0f, CUT_A2)) mask |= 1u << q;
-            }
-            s_rec[tid] = make_float4(i00, i01, c0, h2f(raw.w4 >> 16));
-            s_rec[BLEND_SLOTS + tid] = make_float4(i10, i11, c1, h2f(raw.w3));
-            *reinterpret_cast<float2*>(&s_rec[2 * BLEND_SLOTS + tid]) = make_float2(h2f(raw.w3 >> 16), h2f(raw.w4));
-        }
-        s_m[tid] = mask;
-        // the next batch's gathers fly while this batch is composited; wasted only when the tile saturates first
+        const uint32_t nb = (hi - range.x) < (uint32_t)STAGE ? (hi - range.x) : (uint32_t)STAGE;
         const uint32_t hi_next = hi - nb;
-        if (hi_next > range.x) raw = blend_fetch_raw(p, range, hi_next, tid);
+        if (stager) {
+            uint32_t mask = 0u;
+            if ((uint32_t)tid < nb) {
+                const stage::Staged s = stage::decode<QW, QH>(raw.w0, raw.w1, raw.w2, raw.w3, raw.w4, W, H, tile_x0,
+                                                              tile_y0, CUT_A2);
+                mask = s.mask;
+                s_rec[tid] = make_float4(s.i00, s.i01, s.c0, s.i10);
+                s_rec[SLOTS + tid] = make_float4(s.i11, s.c1, __uint_as_float(raw.w3), __uint_as_float(raw.w4));
+            }
+            s_m[tid] = mask;
+            // the next batch's gathers fly while this batch is composited; wasted only when the tile saturates first
+            if (hi_next > range.x) raw = blend_fetch_raw<STAGE>(p, range, hi_next, tid);
+        }
         __syncthreads();
         if (__ballot(T >= T_MIN) != 0ull) {  // a wave whose 64 pixels are saturated only keeps staging
             // wave-private compaction: records whose kept ellipse reaches this quadrant, in near -> far order
             uint32_t n = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            const uint32_t rounds = (nb + 63u) >> 6;
+            for (uint32_t r = 0; r < rounds; ++r) {
                 const bool t = (s_m[r * 64 + lane] & qbit) != 0u;
                 const unsigned long long bal = __ballot(t);
                 const uint32_t pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
@@ -457,25 +465,25 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p, const uint32
                 n += (uint32_t)__popcll(bal);
             }
             if (n > 0u) {
-                if (lane < 4 && ((n + (uint32_t)lane) >> 2) == (n >> 2) && (n & 3u)) my_list[n + lane] = 256u * 16u;  // pad to x4
+                if (lane < 4 && ((n + (uint32_t)lane) >> 2) == (n >> 2) && (n & 3u)) my_list[n + lane] = (uint32_t)STAGE * 16u;  // pad to x4
                 const uint32_t n4 = (n + 3u) >> 2;
                 const uint4* lp = reinterpret_cast<const uint4*>(my_list);
                 // groups of four list entries; the next group's offsets and the next record are in flight while the
                 // current record is composited
                 uint4 o = lp[0];
                 uint4 on = lp[n4 > 1u ? 1u : 0u];
-                BlendRec cur = blend_load_rec(s_rec, o.x);
+                BlendRec cur = blend_load_rec<SLOTS>(s_rec, o.x);
                 for (uint32_t g = 0; g < n4; ++g) {
-                    const BlendRec r1 = blend_load_rec(s_rec, o.y);
+                    const BlendRec r1 = blend_load_rec<SLOTS>(s_rec, o.y);
                     blend_composite(cur, lx, ly, T, cr, cg, cb);
-                    const BlendRec r2 = blend_load_rec(s_rec, o.z);
+                    const BlendRec r2 = blend_load_rec<SLOTS>(s_rec, o.z);
                     blend_composite(r1, lx, ly, T, cr, cg, cb);
-                    const BlendRec r3 = blend_load_rec(s_rec, o.w);
+                    const BlendRec r3 = blend_load_rec<SLOTS>(s_rec, o.w);
                     blend_composite(r2, lx, ly, T, cr, cg, cb);
-                    cur = blend_load_rec(s_rec, on.x);  // (re-reads a valid record after the last group)
+                    cur = blend_load_rec<SLOTS>(s_rec, on.x);  // (re-reads a valid record after the last group)
                     blend_composite(r3, lx, ly, T, cr, cg, cb);
                     // the quadrant is saturated: nothing behind can add more than T_MIN (one compare per four pairs;
-                    // on dense tiles this stops the walk well inside the 256-entry batch)
+                    // on dense tiles this stops the walk well inside the staged batch)
                     if (__ballot(T >= T_MIN) == 0ull) break;
                     o = on;
                     on = lp[g + 2u < n4 ? g + 2u : n4 - 1u];
@@ -493,6 +501,7 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams p, const uint32
                             (1.0f - T) + p.background[3] * T);
     }
     }  // tile inside the image
+    if (!MULTI) break;
     raw = raw_next_tile;
     __syncthreads();  // the staging buffers are reused by the next tile
     }  // tiles of this workgroup
@@ -548,18 +557,20 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
     // blockIdx -> (tile, quadrant): workgroup b runs on XCD b % 8 (observed; used for locality only)
     const uint32_t b = blockIdx.x;
     const uint32_t xcd = b & 7u, j = b >> 3;
-    const uint32_t q = j & 3u;
-    const uint32_t tile = (j >> 2) * 8u + xcd;
+    const uint32_t nq = p.qw * p.qh;
+    const uint32_t q = j % nq;
+    const uint32_t tile = (j / nq) * 8u + xcd;
     const uint32_t ntiles = p.tiles_x * p.tiles_y;
     if (tile >= ntiles) return;
     const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int lane = threadIdx.x;
-    const uint32_t px = tx * TILE + (q & 1u) * 8u + (lane & 7);
-    const uint32_t py = ty * TILE + (q >> 1) * 8u + (lane >> 3);
+    const uint32_t qx0 = tx * p.qw * 8u + (q % p.qw) * 8u, qy0 = ty * p.qh * 8u + (q / p.qw) * 8u;
+    const uint32_t px = qx0 + (lane & 7);
+    const uint32_t py = qy0 + (lane >> 3);
     const bool inside = px < p.width && py < p.height;
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-    const float qx_lo = (float)(tx * TILE + (q & 1u) * 8u) + 0.5f;
-    const float qy_lo = (float)(ty * TILE + (q >> 1) * 8u) + 0.5f;
+    const float qx_lo = (float)qx0 + 0.5f;
+    const float qy_lo = (float)qy0 + 0.5f;
     const float W = (float)p.width, H = (float)p.height;
 
     uint2 range = p.tile_ranges[tile];
@@ -754,11 +765,41 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     return WS_OK;
 }
 
+template <int QW, int QH>
+static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
+    const BlendShape sh = blend_shape(QW, QH);
+    uint32_t tpw_log2 = p.tpw_log2 >= 0 ? (uint32_t)p.tpw_log2 : blend_tpw_log2(p.tiles_x, p.tiles_y, sh);
+    if (tpw_log2 > sh.tbx_log2 + sh.tby_log2) tpw_log2 = sh.tbx_log2 + sh.tby_log2;
+    const uint32_t grid = blend_grid_blocks(p.tiles_x, p.tiles_y, sh, tpw_log2);
+    constexpr int NT = 64 * QW * QH;
+#define WS_LAUNCH_BLEND(FMT)                                                                                         \
+    if (tpw_log2 > 0u)                                                                                               \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true>), dim3(grid), dim3(NT), 0, stream, p, tpw_log2);              \
+    else                                                                                                             \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, false>), dim3(grid), dim3(NT), 0, stream, p, tpw_log2)
+    switch (p.format) {
+        case WS_FORMAT_RGBA32_FLOAT:
+            WS_LAUNCH_BLEND(WS_FORMAT_RGBA32_FLOAT);
+            break;
+        case WS_FORMAT_RGBA16_FLOAT:
+            WS_LAUNCH_BLEND(WS_FORMAT_RGBA16_FLOAT);
+            break;
+        case WS_FORMAT_RGBA8_UNORM:
+            WS_LAUNCH_BLEND(WS_FORMAT_RGBA8_UNORM);
+            break;
+        default:
+            return fail(WS_ERR_INVALID, "blend: unknown colour format");
+    }
+#undef WS_LAUNCH_BLEND
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
     const uint32_t ntiles = p.tiles_x * p.tiles_y;
     if (ntiles == 0) return WS_OK;
-    if (variant == 1) {  // one wave per 8x8 quadrant (default)
-        const uint32_t groups = ((ntiles + 7u) / 8u) * 8u * 4u;
+    if (variant == 1) {  // one wave per 8x8 quadrant, no LDS (cross-check)
+        const uint32_t groups = ((ntiles + 7u) / 8u) * 8u * p.qw * p.qh;
         switch (p.format) {
             case WS_FORMAT_RGBA32_FLOAT:
                 hipLaunchKernelGGL(k_blend_q<WS_FORMAT_RGBA32_FLOAT>, dim3(groups), dim3(64), 0, stream, p);
@@ -775,22 +816,23 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
         WS_HIP(hipGetLastError());
         return WS_OK;
     }
-    const uint32_t tpw_log2 = p.tpw_log2 >= 0 ? (uint32_t)p.tpw_log2 : blend_tpw_log2(p.tiles_x, p.tiles_y);
-    const uint32_t grid = blend_grid_blocks(p.tiles_x, p.tiles_y, tpw_log2);
-    switch (p.format) {
-        case WS_FORMAT_RGBA32_FLOAT:
-            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA32_FLOAT>, dim3(grid), dim3(256), 0, stream, p, tpw_log2);
-            break;
-        case WS_FORMAT_RGBA16_FLOAT:
-            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA16_FLOAT>, dim3(grid), dim3(256), 0, stream, p, tpw_log2);
-            break;
-        case WS_FORMAT_RGBA8_UNORM:
-            hipLaunchKernelGGL(k_blend<WS_FORMAT_RGBA8_UNORM>, dim3(grid), dim3(256), 0, stream, p, tpw_log2);
-            break;
-        default:
-            return fail(WS_ERR_INVALID, "blend: unknown colour format");
-    }
-    WS_HIP(hipGetLastError());
+    if (p.qw == 2u && p.qh == 2u) return launch_blend_shape<2, 2>(p, stream);
+    if (p.qw == 4u && p.qh == 2u) return launch_blend_shape<4, 2>(p, stream);
+    if (p.qw == 4u && p.qh == 4u) return launch_blend_shape<4, 4>(p, stream);
+    return fail(WS_ERR_INVALID, "blend: unsupported tile shape");
+}
+
+// host-side twin of the staging step (CPU unit test of the quadrant mask; not on any render path)
+int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, float tile_y0, uint32_t qw, uint32_t qh,
+                      float rec[10], uint32_t* mask) {
+    stage::Staged s;
+    if (qw == 2u && qh == 2u) s = stage::decode<2, 2>(w[0], w[1], w[2], w[3], w[4], W, H, tile_x0, tile_y0, CUT_A * stage::LOG2E_F);
+    else if (qw == 4u && qh == 2u) s = stage::decode<4, 2>(w[0], w[1], w[2], w[3], w[4], W, H, tile_x0, tile_y0, CUT_A * stage::LOG2E_F);
+    else if (qw == 4u && qh == 4u) s = stage::decode<4, 4>(w[0], w[1], w[2], w[3], w[4], W, H, tile_x0, tile_y0, CUT_A * stage::LOG2E_F);
+    else return fail(WS_ERR_INVALID, "unsupported tile shape");
+    const float v[10] = {s.i00, s.i01, s.c0, s.i10, s.i11, s.c1, s.alpha, s.r, s.g, s.b};
+    for (int i = 0; i < 10; ++i) rec[i] = v[i];
+    *mask = s.mask;
     return WS_OK;
 }
 

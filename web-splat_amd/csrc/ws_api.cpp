@@ -231,8 +231,9 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     if ((rc = dmalloc(&r->evals_a, ne))) return rc;
     if ((rc = dmalloc(&r->evals_b, ne))) return rc;
     if ((rc = dmalloc(&r->emit_start, (size_t)r->entry_cap / EMIT_TILE + 4))) return rc;
-    r->tiles_x = (vw + TILE - 1) / TILE;
-    r->tiles_y = (vh + TILE - 1) / TILE;
+    const uint32_t tile_w = QUAD * r->ctx->tile_qw, tile_h = QUAD * r->ctx->tile_qh;
+    r->tiles_x = (vw + tile_w - 1) / tile_w;
+    r->tiles_y = (vh + tile_h - 1) / tile_h;
     if ((rc = dmalloc(&r->debug_consumed, (size_t)r->tiles_x * r->tiles_y))) return rc;
     // the per-frame zero arena: counters | depth histograms | tile histograms | tile ranges
     r->zero_bytes = sizeof(FrameZero) + (size_t)r->tiles_x * r->tiles_y * sizeof(uint2);
@@ -285,11 +286,32 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
     if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
+    if (const char* shape = std::getenv("WS_TILE_SHAPE")) {  // tuning / A-B: quadrants per tile
+        const std::string v(shape);
+        if (v == "2x2") { ctx->tile_qw = 2; ctx->tile_qh = 2; }
+        else if (v == "4x2") { ctx->tile_qw = 4; ctx->tile_qh = 2; }
+        else if (v == "4x4") { ctx->tile_qw = 4; ctx->tile_qh = 4; }
+        else { delete ctx; return fail(WS_ERR_INVALID, "WS_TILE_SHAPE must be 2x2, 4x2 or 4x4"); }
+    }
     *out = ctx;
     return WS_OK;
 }
 
 void ws_context_destroy(ws_context* ctx) { delete ctx; }
+
+int ws_context_tile_size(const ws_context* ctx, uint32_t* width, uint32_t* height) {
+    if (!ctx || !width || !height) return fail(WS_ERR_INVALID, "ws_context_tile_size: null argument");
+    *width = QUAD * ctx->tile_qw;
+    *height = QUAD * ctx->tile_qh;
+    return WS_OK;
+}
+
+int ws_debug_stage_splat(const uint32_t splat[5], float viewport_w, float viewport_h, float tile_x0, float tile_y0,
+                         uint32_t tile_w, uint32_t tile_h, float rec[10], uint32_t* quadrant_mask) {
+    if (!splat || !rec || !quadrant_mask) return fail(WS_ERR_INVALID, "ws_debug_stage_splat: null argument");
+    return debug_stage_splat(splat, viewport_w, viewport_h, tile_x0, tile_y0, tile_w / QUAD, tile_h / QUAD, rec,
+                             quadrant_mask);
+}
 
 int ws_sync(ws_context* ctx, void* stream) {
     if (!ctx) return fail(WS_ERR_INVALID, "ws_sync: null context");
@@ -536,8 +558,8 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     if (!r || !pc || !args) return fail(WS_ERR_INVALID, "ws_renderer_prepare: null argument");
     if (pc->compressed != r->compressed)
         return fail(WS_ERR_INVALID, "ws_renderer_prepare: renderer and point cloud disagree on `compressed`");
-    if (args->viewport[0] == 0 || args->viewport[1] == 0 || args->viewport[0] > 65535u * TILE ||
-        args->viewport[1] > 65535u * TILE)
+    if (args->viewport[0] == 0 || args->viewport[1] == 0 || args->viewport[0] > 65535u * QUAD * r->ctx->tile_qw ||
+        args->viewport[1] > 65535u * QUAD * r->ctx->tile_qh)
         return fail(WS_ERR_INVALID, "ws_renderer_prepare: bad viewport");
     if (args->max_sh_deg > 3) return fail(WS_ERR_UNSUPPORTED, "ws_renderer_prepare: max_sh_deg > 3");
     if (!pc->compressed && args->max_sh_deg > pc->sh_deg) {
@@ -559,6 +581,8 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     kp.sh_deg_layout = (r->sh_deg + 1) * (r->sh_deg + 1);
     kp.tiles_x = r->tiles_x;
     kp.tiles_y = r->tiles_y;
+    kp.tile_w_log2 = r->ctx->tile_qw == 4 ? 5u : 4u;
+    kp.tile_h_log2 = r->ctx->tile_qh == 4 ? 5u : 4u;
     kp.znear = -kp.cam.proj[3 * 4 + 2] / kp.cam.proj[2 * 4 + 2];
     kp.zfar = -kp.cam.proj[3 * 4 + 2] / (kp.cam.proj[2 * 4 + 2] - 1.0f);
     // fade-in (preprocess.wgsl:196-203): dd = 5 |centre - xyz| / extend <= 10 because the centroid lies inside the
@@ -703,6 +727,8 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.height = r->vh;
     bp.tiles_x = r->tiles_x;
     bp.tiles_y = r->tiles_y;
+    bp.qw = r->ctx->tile_qw;
+    bp.qh = r->ctx->tile_qh;
     for (int i = 0; i < 4; ++i) bp.background[i] = background ? background[i] : 0.0f;
     bp.out = d_rgba_out;
     bp.pitch = row_pitch_bytes;

@@ -22,7 +22,9 @@ int hip_fail(hipError_t e, const char* what);
     } while (0)
 
 // ---- geometry of the rasteriser ----------------------------------------------------------------
-constexpr int TILE = 16;                      // 16x16-pixel tiles (north star)
+// Tiles are QW x QH quadrants of 8x8 pixels (one wave each): 2x2 = the north star's 16x16 tile; 4x2 / 4x4 bin two /
+// four such tiles into one list (ws_context::tile_qw/qh, WS_TILE_SHAPE).
+constexpr int QUAD = 8;
 constexpr float CUTOFF = 2.3539888583335364f; // gaussian.wgsl:2  sqrt(ln 255)
 constexpr float CUT_A = 2.0f * CUTOFF;        // gaussian.wgsl:61 discard if a > 2*CUTOFF
 constexpr float T_MIN = 1.0f / 16384.0f;      // front-to-back early-out (6.1e-5; DESIGN.md section Blend)
@@ -59,6 +61,7 @@ struct K1Params {
     uint32_t num_points;
     uint32_t sh_deg_layout;  // compressed: number of coefficients per packed SH record, (sh_deg+1)^2
     uint32_t tiles_x, tiles_y;
+    uint32_t tile_w_log2, tile_h_log2;  // tile size in pixels (8 * QW, 8 * QH)
     uint32_t epoch;          // look-back epoch of this frame (lookback.h)
     float znear, zfar;       // -proj[3][2]/proj[2][2], -proj[3][2]/(proj[2][2]-1)  (preprocess.wgsl:270-271)
     uint32_t fade_done;      // walltime is past every Gaussian's fade-in: scale_mod == 1 exactly
@@ -181,6 +184,7 @@ struct BlendParams {
     const uint32_t* entry_vals; // sorted by tile, far -> near inside a tile
     const uint2* tile_ranges;   // (0xFFFFFFFF - begin, end) per tile, (0, 0) = empty  (written by the tile-id sort)
     uint32_t width, height, tiles_x, tiles_y;
+    uint32_t qw, qh;            // quadrants (8x8 px, one wave each) per tile
     float background[4];
     void* out;
     size_t pitch;
@@ -189,6 +193,8 @@ struct BlendParams {
     uint32_t* debug_consumed;   // nullptr, or [tiles]: entries of each tile's list the blend walked (capture mode)
 };
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
+int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, float tile_y0, uint32_t qw, uint32_t qh,
+                      float rec[10], uint32_t* mask);
 
 // ---- host math (host_math.cpp) ------------------------------------------------------------------
 void build_camera_uniform(const ws_camera& cam, const uint32_t viewport[2], ws_camera_uniform* out);
@@ -210,6 +216,7 @@ struct ws_context {
     int blend_variant = 0;
     int debug_cut = 0;        // WS_DEBUG_CUT (analysis): 0 = whole frame
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
+    uint32_t tile_qw = 2, tile_qh = 2;  // WS_TILE_SHAPE = 2x2 | 4x2 | 4x4
 };
 
 struct ws_pointcloud {

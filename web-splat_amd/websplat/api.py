@@ -137,6 +137,16 @@ class SplattingArgs:
         return a
 
 
+def stage_splat(words, viewport, tile_origin, tile_size=(16, 16)):
+    """Host-side twin of the compositing pass's staging step (test hook): (rec[10], quadrant mask)."""
+    w = (C.c_uint32 * 5)(*[int(x) for x in words])
+    rec = (C.c_float * 10)()
+    mask = C.c_uint32()
+    check(lib.ws_debug_stage_splat(w, float(viewport[0]), float(viewport[1]), float(tile_origin[0]),
+                                   float(tile_origin[1]), int(tile_size[0]), int(tile_size[1]), rec, C.byref(mask)))
+    return np.array(rec[:], dtype=np.float32), mask.value
+
+
 class Context:
     def __init__(self, device: int = 0):
         h = C.c_void_p()
@@ -151,6 +161,12 @@ class Context:
 
     def sync(self, stream=None):
         check(lib.ws_sync(self.handle, C.c_void_p(stream or 0)))
+
+    def tile_size(self):
+        """(width, height) of the binning tile in pixels (16x16 unless WS_TILE_SHAPE says otherwise)."""
+        w, h = C.c_uint32(), C.c_uint32()
+        check(lib.ws_context_tile_size(self.handle, C.byref(w), C.byref(h)))
+        return w.value, h.value
 
     def device_info(self):
         name = C.create_string_buffer(128)
