@@ -251,8 +251,9 @@ def main():
         r.enable_timers(0)
         n = gpc.num_points
         V, D = stat_acc["num_visible"], stat_acc["num_tile_entries"]
+        tile_w, tile_h = ctx.tile_size()
         tile_bits = 8
-        while (1 << tile_bits) < ((w + 15) // 16) * ((h + 15) // 16):
+        while (1 << tile_bits) < -(-w // tile_w) * -(-h // tile_h):
             tile_bits += 8
         tile_passes = tile_bits // 8
         # ALGORITHMIC bytes per launch (DESIGN.md "Roofline accounting"): N Gaussians, V visible,
@@ -305,6 +306,7 @@ def main():
             "config": {"workload": f"{a.workload}: {n} Gaussians (sh_deg 3), {w}x{h}, {a.format} target, "
                                    f"{len(views)} orbit views sharded view i -> rank i mod N, {inflight} frame(s) in flight per GPU",
                        "gaussians": n, "width": w, "height": h, "views": len(views), "frames_in_flight": inflight,
+                       "binning_tile": f"{tile_w}x{tile_h}",
                        "avg_visible": V, "avg_tile_entries": D, "overflow": overflow,
                        "single_stream_fps": single_stream_fps},
             "roofline": roofline,

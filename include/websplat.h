@@ -278,8 +278,9 @@ int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries);
  * (far -> near).  Any pointer may be NULL.  capacity = number of elements each array can hold. Syncs. */
 int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, uint32_t* keys,
                                uint32_t* src_index, uint32_t* sorted, uint32_t* num_visible);
-/* The binning tile in pixels: 16x16 (the north star's tile; one workgroup of 2x2 wave quadrants), or 32x16 / 32x32
- * when two / four such tiles share one binned list (WS_TILE_SHAPE=2x2|4x2|4x4 at context creation; tuning). */
+/* The binning tile in pixels: 32x32 by default (four 16x16 tiles -- 4x4 wave quadrants of 8x8 pixels -- sharing one
+ * binned list), 32x16 or 16x16 with WS_TILE_SHAPE=4x2|2x2 at context creation (tuning; 2x2 is the literal
+ * one-workgroup-per-16x16-tile form). */
 int ws_context_tile_size(const ws_context* ctx, uint32_t* width, uint32_t* height);
 /* test hook, host only (no device work): the compositing pass's staging step for ONE (tile, splat) entry --
  * splat = the five 32-bit words of a 20-B Splat record (pointcloud.rs:352-358), tile origin in pixels ->

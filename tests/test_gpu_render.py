@@ -55,8 +55,8 @@ def test_image_c1(ws, ctx, oracle):
 
 @pytest.mark.parametrize("viewport", [(801, 599), (16, 16), (17, 33), (250, 7), (4096, 4096)])
 def test_image_odd_viewports(ws, ctx, oracle, viewport):
-    """Viewports that are not multiples of the 16-px tile, down to a single tile (one 6-bit sort pass, ranges written by
-    that pass), up to 65536 tiles (two 8-bit passes, 32-bit tile keys instead of 16-bit ones)."""
+    """Viewports that are not multiples of the tile, down to a single tile (one sort pass, ranges written by that pass),
+    up to 16384 tiles of 32x32 px (two 7-bit passes); test_many_tiles_32bit_keys covers the 65536-tile case."""
     sc = scenes.c1(ws, oracle, n=3000, viewport=viewport, seed=9)
     pc, img, _ = _render(ws, ctx, sc)
     try:
@@ -275,6 +275,24 @@ def test_cross_check_paths(ws, oracle, env, monkeypatch):
     c = ws.Context(0)
     try:
         sc = scenes.c1(ws, oracle, n=20_000, viewport=(640, 480), seed=12)
+        pc, img, stats = _render(ws, c, sc)
+        try:
+            ref, _ = sc.oracle_image(pc)
+            _assert_close(img, ref)
+            assert stats["overflow"] == 0
+        finally:
+            pc.close()
+    finally:
+        c.close()
+
+
+def test_many_tiles_32bit_keys(ws, oracle, monkeypatch):
+    """65536 tiles (4096x4096 at 16x16): the tile sort switches from 16-bit to 32-bit tile ids, two 8-bit passes."""
+    monkeypatch.setenv("WS_TILE_SHAPE", "2x2")
+    c = ws.Context(0)
+    try:
+        assert c.tile_size() == (16, 16)
+        sc = scenes.c1(ws, oracle, n=3000, viewport=(4096, 4096), seed=9)
         pc, img, stats = _render(ws, c, sc)
         try:
             ref, _ = sc.oracle_image(pc)

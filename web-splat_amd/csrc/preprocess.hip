@@ -12,7 +12,7 @@
 //     needed because the word is its own payload.  The reference's atomicAdd(keys_size) order is
 //     nondeterministic (preprocess.wgsl:262); ordered compaction makes equal-depth ties, and hence the
 //     image, reproducible across runs and ranks.
-//   * Besides the reference's outputs (Splat 20 B, depth key) the kernel emits the splat's 16x16-tile
+//   * Besides the reference's outputs (Splat 20 B, depth key) the kernel emits the splat's binning-tile
 //     rectangle (8 B) for the binning stage that replaces the hardware rasteriser.
 //
 // This file is compiled with -ffp-contract=off: f32 operations happen in source order, which is the

@@ -4,7 +4,7 @@
 //   src/shaders/gaussian.wgsl:30-67 (vs_main / fs_main), src/renderer.rs:63-67 (PREMULTIPLIED_ALPHA_BLENDING),
 //   src/renderer.rs:250-260 (draw_indirect over the depth-sorted instances).
 // The reference lets the ROPs read-modify-write the render target once per covered pixel per splat, back to
-// front.  Here every 16x16 tile gets the list of splats that touch it (in the SAME depth order, produced by a
+// front.  Here every binning tile (32x32 px by default: 2x2 tiles of 16x16) gets the list of splats that touch it (in the SAME depth order, produced by a
 // stable counting sort on the tile id of depth-ordered (tile, splat) entries) and one workgroup composites the
 // list front-to-back out of LDS, keeping colour and transmittance in registers and writing each pixel once.
 //
@@ -14,8 +14,9 @@
 //                   the footprint of the splats they come from (owners by an LDS max-scan over the splat offsets)
 //   (radix sort of the entries by tile id: sort.hip, ceil(log2 T / 8) passes, stable -> depth order kept inside a
 //    tile; its last pass records [begin,end) of every tile in the sorted entry list instead of writing the keys)
-//   k_blend       : 16x16 pixels per workgroup, splats staged through LDS 256 at a time, per-wave compaction to the
-//                   records that reach the wave's 8x8 quadrant, early-out on T
+//   k_blend       : one workgroup per binning tile, one wave per 8x8-pixel quadrant (four waves = one 16x16 tile);
+//                   splats staged through LDS 256 / 512 at a time, per-wave compaction to the records that reach
+//                   the wave's quadrant, early-out on T
 //   k_display     : Display::render composite into an 8-bit surface
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>

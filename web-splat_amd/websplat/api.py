@@ -163,7 +163,7 @@ class Context:
         check(lib.ws_sync(self.handle, C.c_void_p(stream or 0)))
 
     def tile_size(self):
-        """(width, height) of the binning tile in pixels (16x16 unless WS_TILE_SHAPE says otherwise)."""
+        """(width, height) of the binning tile in pixels (32x32 unless WS_TILE_SHAPE says otherwise)."""
         w, h = C.c_uint32(), C.c_uint32()
         check(lib.ws_context_tile_size(self.handle, C.byref(w), C.byref(h)))
         return w.value, h.value
