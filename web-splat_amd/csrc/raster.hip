@@ -735,6 +735,17 @@ int launch_display(const void* src, int src_format, size_t src_pitch, uint32_t w
     return WS_OK;
 }
 
+// An empty launch: with per-kernel timers on, its event interval is the dispatch latency every dependent launch
+// of the frame carries (the kernel times rocprofv3 reports do not include it).
+namespace {
+__global__ void k_empty() {}
+}  // namespace
+int launch_empty(hipStream_t stream) {
+    hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, stream);
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
 uint32_t bin_prefix_blocks(uint32_t max_points) {
     const uint32_t items = BIN_THREADS * BIN_IPT;
     return (max_points + items - 1) / items;

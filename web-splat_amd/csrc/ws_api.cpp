@@ -618,7 +618,11 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     // memset clears the counters, every ticket, both sorts' digit histograms and the tile ranges
     WS_HIP(hipMemsetAsync(r->zero, 0, r->zero_bytes, stream));
     KernelMarks* km = r->marks.active ? &r->marks : nullptr;
-    if (km) km->begin(stream, true);
+    if (km) {
+        km->begin(stream, true);
+        if ((rc = launch_empty(stream))) return rc;  // calibration interval: dispatch latency of a dependent launch
+        km_mark(km, "_empty_launch");
+    }
     if (r->timers) WS_HIP(hipEventRecord(r->ev[0], stream));
     if ((rc = launch_preprocess(kp, kb, pc->compressed, stream))) return rc;
     km_mark(km, pc->compressed ? "k_preprocess<compressed>" : "k_preprocess");

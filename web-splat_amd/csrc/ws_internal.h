@@ -195,6 +195,7 @@ struct BlendParams {
     uint32_t* debug_consumed;   // nullptr, or [tiles]: entries of each tile's list the blend walked (capture mode)
 };
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
+int launch_empty(hipStream_t stream);
 int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, float tile_y0, uint32_t qw, uint32_t qh,
                       float rec[10], uint32_t* mask);
 
