@@ -28,7 +28,11 @@ namespace ws {
 namespace {
 
 constexpr int K1_THREADS = 256;
-constexpr int K1_ITEMS = 4;  // Gaussians per thread
+#ifndef WS_K1_ITEMS
+#define WS_K1_ITEMS 4
+#endif
+constexpr int K1_ITEMS = WS_K1_ITEMS;  // Gaussians per thread (measured on c2: 2 -> 59 us, 4 -> 56, 8 -> 70; 1 -> 80: one
+                                       // ticket per 256 Gaussians makes the ~11 ns dispenser atomic the bottleneck)
 #ifndef WS_K1_BACK_GROUP
 #define WS_K1_BACK_GROUP 2
 #endif
