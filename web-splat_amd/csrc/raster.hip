@@ -86,7 +86,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
     const uint32_t v = counters->num_visible;
     if ((uint64_t)blockIdx.x * BIN_ITEMS >= v) return;  // surplus workgroups leave before drawing a ticket
     const int tid = threadIdx.x;
+    // Workgroup order of the look-back = blockIdx order (lookback.h: dispatch is in order per XCD; -DWS_TICKET_ORDER
+    // hands the ids out by an atomic ticket instead: start order, no assumption, ~11 ns per workgroup in series)
+#ifdef WS_TICKET_ORDER
     if (tid == 0) s_bid = atomicAdd(&counters->bin_ticket, 1u);
+#else
+    if (tid == 0) s_bid = blockIdx.x;
+#endif
     __syncthreads();
     const uint32_t bid = s_bid;
     const uint32_t nblocks = (v + BIN_ITEMS - 1) / BIN_ITEMS;
