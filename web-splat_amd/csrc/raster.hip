@@ -9,7 +9,7 @@
 // list front-to-back out of LDS, keeping colour and transmittance in registers and writing each pixel once.
 //
 //   k_bin_prefix  : per depth-sorted splat: gather its tile rectangle, count tiles, exclusive prefix over the
-//                   draw order in ONE pass (ticketed wave-parallel decoupled look-back), total D
+//                   draw order in ONE pass (wave-parallel decoupled look-back), total D
 //   k_bin_emit    : entry-parallel: every workgroup produces exactly EMIT_TILE (tile id, splat) entries, whatever
 //                   the footprint of the splats they come from (owners by an LDS max-scan over the splat offsets)
 //   (radix sort of the entries by tile id: sort.hip, ceil(log2 T / 8) passes, stable -> depth order kept inside a
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_base;
     const uint32_t v = counters->num_visible;
-    if ((uint64_t)blockIdx.x * BIN_ITEMS >= v) return;  // surplus workgroups leave before drawing a ticket
+    if ((uint64_t)blockIdx.x * BIN_ITEMS >= v) return;  // surplus workgroups leave first
     const int tid = threadIdx.x;
     // Workgroup order of the look-back = blockIdx order (lookback.h: dispatch is in order per XCD; -DWS_TICKET_ORDER
     // hands the ids out by an atomic ticket instead: start order, no assumption, ~11 ns per workgroup in series)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
 #pragma unroll
     for (int k = 0; k < BIN_IPT; ++k) {
         const uint32_t i = base + k * BIN_THREADS + tid;
-        r[k] = rects[sidx[k]];
+        r[k] = rects[sidx[k]];  // (the random 8-B gather: 7 of this kernel's 26 us on c2, 73 of 117 us on c3)
         if (i >= v) r[k] = make_uint2(1u, 0u);
         cnt[k] = rect_count(r[k]);
         s_cnt[pad(k * BIN_THREADS + tid)] = cnt[k];
