@@ -292,19 +292,26 @@ def main():
         tpath = os.path.join(ROOT, "profiles", f"traffic_{a.workload}.json")
         if os.path.exists(tpath):  # PMC pass of the same command (scripts/pmc_traffic.sh), bytes per launch
             traffic = json.load(open(tpath)).get(dom)
+        valu = None
+        vpath = os.path.join(ROOT, "profiles", f"valu_{a.workload}.json")
+        if os.path.exists(vpath):  # PMC pass of the same command (scripts/pmc_valu.py): VALU issue accounting per launch
+            valu = json.load(open(vpath)).get(dom)
         bound = "hbm"
         roofline = {"kernel": dom, "bound": bound, "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (dk["GBps"] / HBM_PEAK_GBS) if dk["GBps"] else None, "traffic": traffic,
                     "alg_bytes_per_launch": dk["alg_bytes_per_launch"], "avg_launch_ms": dk["avg_launch_ms"],
                     "launches_per_frame": dk["launches_per_frame"],
                     "event_interval_ms": dk["event_interval_ms"], "empty_launch_interval_ms": empty_ms,
-                    "limited_by": "valu" if dom == "k_blend" else "hbm",
+                    "limited_by": ("latency" if (valu and valu.get("issue_util", 1.0) < 0.5) else "valu") if dom == "k_blend" else "hbm",
+                    "valu": valu,
                     "note": "dominant = most GPU time per frame summed over its launches; HIP events around every "
                             "launch on the launch stream, one frame in flight; avg_launch_ms = event interval minus "
                             "the interval of an empty launch recorded the same way in every frame (dispatch latency "
                             "of a dependent launch, which rocprofv3 kernel durations do not contain).  No stage is a dense contraction, so "
-                            "MFMA is unused and every kernel is priced against HBM; k_blend is bound by VALU issue "
-                            "(DESIGN.md 3.3) and early-out makes its real traffic a fraction of the algorithmic bytes"}
+                            "MFMA is unused and every kernel is priced against HBM; k_blend moves few bytes per "
+                            "(pixel, splat) pair: what limits it is VALU issue and, on scenes whose tiles saturate after "
+                            "one or two staged batches, the per-tile start-up latency (valu.issue_util, DESIGN.md 3.3); "
+                            "early-out makes its real traffic a fraction of the algorithmic bytes"}
         stages = {k: {"ms": v} for k, v in stage_acc.items()}
         fps = world * a.steps / elapsed
         out = {

@@ -294,6 +294,10 @@ int ws_debug_stage_splat(const uint32_t splat[5], float viewport_w, float viewpo
  * how many of its entries the compositing pass walked before every pixel was saturated.  Syncs. */
 int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t* list_len, uint32_t* consumed,
                                     uint32_t* num_tiles);
+/* analysis read-back (capture mode): walked[t * 17 + w] = staged records wave w of tile t composited (w < waves
+ * per tile, 16 at the default tile), walked[t * 17 + 16] = sum over the tile's batches of the most any of its waves
+ * composited in that batch -- the lock-step cost of the per-batch barriers.  Syncs. */
+int ws_renderer_download_wave_stats(ws_renderer* r, uint32_t tile_capacity, uint32_t* walked);
 /* parity read-back of the binning result: tile t's depth-ordered (far -> near) splat list is
  * entries[begin[t] .. end[t]) (store indices, as `sorted` of ws_renderer_download_frame). Any pointer may be NULL;
  * *num_entries = D.  Syncs. */

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One scripted GPU batch (run through gpurun): tests -> smoke -> PMC traffic -> bench -> rocprofv3 stats.
+# One scripted GPU batch (run through gpurun): tests -> smoke -> PMC traffic -> PMC VALU -> bench -> rocprofv3 stats.
 # Everything lands in gpurun_out/; copy what should be judged into profiles/.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 STEPS=${STEPS:-400}
 WORKLOAD=${WORKLOAD:-c2}
-WHAT=${WHAT:-tests,smoke,traffic,bench,prof}
+WHAT=${WHAT:-tests,smoke,traffic,valu,bench,prof}
 rm -f $OUT/summary.txt
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9|Compute Unit" | head -6 > $OUT/device.txt
 nproc >> $OUT/device.txt
@@ -22,6 +22,12 @@ fi
 if [[ $WHAT == *traffic* ]]; then
   bash scripts/pmc_traffic.sh $WORKLOAD > $OUT/traffic.log 2>&1; echo "traffic exit=$?" >> $OUT/summary.txt
   mkdir -p profiles; cp $OUT/traffic_$WORKLOAD.json profiles/traffic_$WORKLOAD.json 2>/dev/null  # bench.py reads it
+fi
+if [[ $WHAT == *valu* ]]; then
+  rm -rf $OUT/pmc_valu
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_valu -o pmc -- python bench.py --steps 6 --warmup 2 --streams 1 --no-cpu-baseline --workload $WORKLOAD > $OUT/pmc_valu.log 2>&1
+  python scripts/pmc_valu.py $OUT/pmc_valu/pmc_counter_collection.csv $OUT/valu_$WORKLOAD.json > $OUT/valu.log 2>&1; echo "valu exit=$?" >> $OUT/summary.txt
+  cp $OUT/valu_$WORKLOAD.json profiles/valu_$WORKLOAD.json 2>/dev/null  # bench.py reads it
 fi
 if [[ $WHAT == *bench* ]]; then
   timeout 900 python bench.py --steps $STEPS --warmup 20 --workload $WORKLOAD > $OUT/bench_$WORKLOAD.json 2> $OUT/bench_$WORKLOAD.err; echo "bench exit=$?" >> $OUT/summary.txt

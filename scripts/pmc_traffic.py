@@ -42,11 +42,12 @@ def per_label(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-fetch = per_label(sys.argv[1], "FETCH_SIZE")
-write = per_label(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(fetch) | set(write)):
-    out[k] = 2.0 * fetch.get(k, 0.0) * 1024.0 + write.get(k, 0.0) * 1024.0
-detail = {k: {"FETCH_SIZE_KiB": fetch.get(k), "WRITE_SIZE_KiB": write.get(k)} for k in out}
-json.dump({**out, "_raw": detail, "_formula": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 bytes per launch"}, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out))
+if __name__ == "__main__":
+    fetch = per_label(sys.argv[1], "FETCH_SIZE")
+    write = per_label(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        out[k] = 2.0 * fetch.get(k, 0.0) * 1024.0 + write.get(k, 0.0) * 1024.0
+    detail = {k: {"FETCH_SIZE_KiB": fetch.get(k), "WRITE_SIZE_KiB": write.get(k)} for k in out}
+    json.dump({**out, "_raw": detail, "_formula": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 bytes per launch"}, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out))

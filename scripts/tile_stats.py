@@ -24,5 +24,12 @@ for vi in (0, 3):
     print("  list_len  pct50/90/99/max:", [int(np.percentile(ll, p)) for p in (50, 90, 99, 100)], "sum", int(ll.sum()))
     print("  consumed  pct50/90/99/max:", [int(np.percentile(co, p)) for p in (50, 90, 99, 100)], "sum", int(co.sum()))
     print("  tiles with consumed > 1024:", int((co > 1024).sum()), " > 2048:", int((co > 2048).sum()), " > 4096:", int((co > 4096).sum()))
+    ws_ = r.wave_stats().astype(np.int64)
+    tw, th = ctx.tile_size()
+    nw = (tw // 8) * (th // 8)
+    per_wave, lock = ws_[:, :nw], ws_[:, 16]
+    print(f"  records composited: sum over waves {int(per_wave.sum())}; per tile: mean-wave sum {per_wave.mean(1).sum():.0f}, "
+          f"max-wave sum {int(per_wave.max(1).sum())}, lock-step (sum over batches of the batch maximum) {int(lock.sum())}"
+          f"  -> lock-step / mean = {lock.sum() / max(per_wave.mean(1).sum(), 1):.2f}, max / mean = {per_wave.max(1).sum() / max(per_wave.mean(1).sum(), 1):.2f}")
     print("  kernel times (us):", " ".join(f"{n}={ms*1e3:.1f}" for n, ms in kt), " total=%.1f" % (sum(ms for _, ms in kt) * 1e3))
 r.close(); pc.close(); ctx.close()

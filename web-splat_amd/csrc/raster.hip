@@ -367,7 +367,7 @@ __device__ __forceinline__ void blend_composite(const BlendRec& r, float lx, flo
 #ifndef WS_BLEND_MINWAVES
 #define WS_BLEND_MINWAVES 1
 #endif
-template <int FORMAT, int QW, int QH, bool MULTI>
+template <int FORMAT, int QW, int QH, bool MULTI, bool CAPTURE>
 __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const BlendParams p, const uint32_t tpw_log2_arg) {
     const uint32_t tpw_log2 = MULTI ? tpw_log2_arg : 0u;  // MULTI = several tiles per workgroup (4K-class tile counts)
     constexpr int NW = QW * QH;                  // waves = quadrants
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     __shared__ __attribute__((aligned(16))) uint32_t s_list[NW][STAGE + 16];
     __shared__ uint2 s_range[16];   // [begin, end) of this workgroup's tiles in the sorted entry list
     __shared__ uint32_t s_txy[16];  // tx | ty << 16, or 0xFFFFFFFF for a slot outside the image
+    __shared__ uint32_t s_dbg_max;  // capture mode: most records any wave walked in the current batch
 
     const BlendShape shape = blend_shape(QW, QH);
     const BlendBlock blk = blend_block_of(blockIdx.x, p.tiles_x, p.tiles_y, shape, tpw_log2);
@@ -443,6 +444,13 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     const float tile_x0 = (float)(tx * TW), tile_y0 = (float)(ty * TH);
 
     uint32_t hi = range.y;
+    // capture build only (p.debug_walked): records this wave walked, and the sum over batches of the most any wave
+    // walked in the batch (the lock-step cost of the per-batch barriers)
+    uint32_t dbg_walked = 0u, dbg_lockstep = 0u;
+    if ((CAPTURE && p.debug_walked)) {
+        if (tid == 0) s_dbg_max = 0u;
+        __syncthreads();
+    }
     while (hi > range.x) {
         const uint32_t nb = (hi - range.x) < (uint32_t)STAGE ? (hi - range.x) : (uint32_t)STAGE;
         const uint32_t hi_next = hi - nb;
@@ -460,6 +468,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
             if (hi_next > range.x) raw = blend_fetch_raw<STAGE>(p, range, hi_next, tid);
         }
         __syncthreads();
+        const uint32_t dbg_before = dbg_walked;
         if (__ballot(T >= T_MIN) != 0ull) {  // a wave whose 64 pixels are saturated only keeps staging
             // wave-private compaction: records whose kept ellipse reaches this quadrant, in near -> far order
             uint32_t n = 0;
@@ -491,6 +500,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
                     blend_composite(r3, lx, ly, T, cr, cg, cb);
                     // the quadrant is saturated: nothing behind can add more than T_MIN (one compare per four pairs;
                     // on dense tiles this stops the walk well inside the staged batch)
+                    if ((CAPTURE && p.debug_walked)) dbg_walked += 4u;
                     if (__ballot(T >= T_MIN) == 0ull) break;
                     o = on;
                     on = lp[g + 2u < n4 ? g + 2u : n4 - 1u];
@@ -498,9 +508,21 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
             }
         }
         hi = hi_next;
-        if (__syncthreads_and(T < T_MIN ? 1 : 0)) break;
+        if ((CAPTURE && p.debug_walked) && lane == 0) atomicMax(&s_dbg_max, dbg_walked - dbg_before);
+        const bool all_done = __syncthreads_and(T < T_MIN ? 1 : 0);
+        if ((CAPTURE && p.debug_walked)) {
+            dbg_lockstep += s_dbg_max;
+            __syncthreads();
+            if (tid == 0) s_dbg_max = 0u;
+            __syncthreads();
+        }
+        if (all_done) break;
     }
-    if (p.debug_consumed && tid == 0) p.debug_consumed[tile] = range.y - hi;
+    if ((CAPTURE && p.debug_consumed) && tid == 0) p.debug_consumed[tile] = range.y - hi;
+    if ((CAPTURE && p.debug_walked) && lane == 0) {
+        p.debug_walked[(size_t)tile * 17u + wave] = dbg_walked;
+        if (wave == 0) p.debug_walked[(size_t)tile * 17u + 16u] = dbg_lockstep;
+    }
 
     if (inside) {
         // begin_render_pass(clear = background) then "over": dst = src + dst * (1 - src.a), all four channels
@@ -790,11 +812,14 @@ static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
     if (tpw_log2 > sh.tbx_log2 + sh.tby_log2) tpw_log2 = sh.tbx_log2 + sh.tby_log2;
     const uint32_t grid = blend_grid_blocks(p.tiles_x, p.tiles_y, sh, tpw_log2);
     constexpr int NT = 64 * QW * QH;
+    const bool capture = p.debug_consumed != nullptr || p.debug_walked != nullptr;  // analysis build of the kernel
 #define WS_LAUNCH_BLEND(FMT)                                                                                         \
-    if (tpw_log2 > 0u)                                                                                               \
-        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true>), dim3(grid), dim3(NT), 0, stream, p, tpw_log2);              \
+    if (capture)                                                                                                     \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, true>), dim3(grid), dim3(NT), 0, stream, p, tpw_log2);        \
+    else if (tpw_log2 > 0u)                                                                                          \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, false>), dim3(grid), dim3(NT), 0, stream, p, tpw_log2);       \
     else                                                                                                             \
-        hipLaunchKernelGGL((k_blend<FMT, QW, QH, false>), dim3(grid), dim3(NT), 0, stream, p, tpw_log2)
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, false, false>), dim3(grid), dim3(NT), 0, stream, p, tpw_log2)
     switch (p.format) {
         case WS_FORMAT_RGBA32_FLOAT:
             WS_LAUNCH_BLEND(WS_FORMAT_RGBA32_FLOAT);

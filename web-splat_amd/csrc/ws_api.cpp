@@ -127,6 +127,7 @@ struct ws_renderer {
 
     bool capture = false;
     uint32_t* debug_consumed = nullptr;  // [tiles], capture mode only
+    uint32_t* debug_walked = nullptr;    // [tiles][17], capture mode only
     bool timers = false;
     KernelMarks marks;               // per-kernel events, timers level 2
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -182,6 +183,7 @@ static void renderer_free_scratch(ws_renderer* r) {
     dfree(r->evals_a);
     dfree(r->evals_b);
     dfree(r->debug_consumed);
+    dfree(r->debug_walked);
     if (r->zero) (void)hipFree(r->zero);
     r->zero = nullptr;
     r->tile_ranges = nullptr;
@@ -235,6 +237,7 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     r->tiles_x = (vw + tile_w - 1) / tile_w;
     r->tiles_y = (vh + tile_h - 1) / tile_h;
     if ((rc = dmalloc(&r->debug_consumed, (size_t)r->tiles_x * r->tiles_y))) return rc;
+    if ((rc = dmalloc(&r->debug_walked, (size_t)r->tiles_x * r->tiles_y * 17))) return rc;
     // the per-frame zero arena: counters | depth histograms | tile histograms | tile ranges
     r->zero_bytes = sizeof(FrameZero) + (size_t)r->tiles_x * r->tiles_y * sizeof(uint2);
     WS_HIP(hipMalloc(reinterpret_cast<void**>(&r->zero), r->zero_bytes));
@@ -739,8 +742,11 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.format = (int)r->format;
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
     bp.debug_consumed = r->capture ? r->debug_consumed : nullptr;
-    if (bp.debug_consumed)
+    bp.debug_walked = r->capture ? r->debug_walked : nullptr;
+    if (bp.debug_consumed) {
         WS_HIP(hipMemsetAsync(r->debug_consumed, 0, (size_t)r->tiles_x * r->tiles_y * sizeof(uint32_t), stream));
+        WS_HIP(hipMemsetAsync(r->debug_walked, 0, (size_t)r->tiles_x * r->tiles_y * 17 * sizeof(uint32_t), stream));
+    }
     KernelMarks* km = r->marks.active ? &r->marks : nullptr;
     if (km) km->begin(stream, false);
     if (r->timers) WS_HIP(hipEventRecord(r->ev[4], stream));
@@ -825,6 +831,17 @@ int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t*
         for (uint32_t i = 0; i < nt; ++i) list_len[i] = rg[i].y ? rg[i].y - (0xFFFFFFFFu - rg[i].x) : 0u;
     }
     if (consumed) WS_HIP(hipMemcpy(consumed, r->debug_consumed, (size_t)nt * 4, hipMemcpyDeviceToHost));
+    return WS_OK;
+}
+
+int ws_renderer_download_wave_stats(ws_renderer* r, uint32_t tile_capacity, uint32_t* walked) {
+    if (!r || !walked) return fail(WS_ERR_INVALID, "ws_renderer_download_wave_stats: null argument");
+    if (!r->prepared || !r->capture)
+        return fail(WS_ERR_STATE, "ws_renderer_download_wave_stats: needs ws_renderer_enable_capture and a rendered frame");
+    const uint32_t nt = r->tiles_x * r->tiles_y;
+    if (tile_capacity < nt) return fail(WS_ERR_INVALID, "ws_renderer_download_wave_stats: capacity smaller than the tile count");
+    WS_HIP(hipStreamSynchronize(r->last_stream));
+    WS_HIP(hipMemcpy(walked, r->debug_walked, (size_t)nt * 17 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return WS_OK;
 }
 

@@ -193,6 +193,7 @@ struct BlendParams {
     int format;
     int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
     uint32_t* debug_consumed;   // nullptr, or [tiles]: entries of each tile's list the blend walked (capture mode)
+    uint32_t* debug_walked;     // nullptr, or [tiles][17]: records walked per wave, [16] = sum over batches of the per-batch maximum
 };
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
 int launch_empty(hipStream_t stream);

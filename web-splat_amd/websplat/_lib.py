@@ -142,6 +142,7 @@ SIGNATURES = {
     "ws_context_create": (C.c_int, [C.c_int, _PP]),
     "ws_context_destroy": (None, [_P]),
     "ws_context_tile_size": (C.c_int, [_P, _u32p, _u32p]),
+    "ws_renderer_download_wave_stats": (C.c_int, [_P, C.c_uint32, _u32p]),
     "ws_debug_stage_splat": (C.c_int, [_u32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                        _f32p, _u32p]),
     "ws_sync": (C.c_int, [_P, _P]),

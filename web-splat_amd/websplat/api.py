@@ -510,6 +510,14 @@ class GaussianRenderer:
                                                   entries.ctypes.data_as(C.c_void_p), C.byref(d)))
         return begin, end, entries[:d.value]
 
+    def wave_stats(self):
+        """[tiles, 17] uint32 (capture mode): records composited per wave; column 16 = lock-step cost (see websplat.h)."""
+        nt = C.c_uint32()
+        check(lib.ws_renderer_download_tile_stats(self.handle, 0, None, None, C.byref(nt)))
+        out = np.zeros((nt.value, 17), dtype=np.uint32)
+        check(lib.ws_renderer_download_wave_stats(self.handle, nt.value, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
     def tile_stats(self, with_consumed=False):
         nt = C.c_uint32()
         check(lib.ws_renderer_download_tile_stats(self.handle, 0, None, None, C.byref(nt)))
