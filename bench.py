@@ -271,19 +271,21 @@ def main():
             "tiles:k_sort_scatter": (16 * D * (tile_passes - 1) + 12 * D) / tile_passes,
             "k_blend": D * 24 + w * h * 16,
         }
-        # An event interval = dispatch latency of a dependent launch + the kernel; rocprofv3 reports the kernel alone.
-        # The library records one EMPTY launch per frame in the same way: its interval is subtracted.
+        # An event interval = event + dispatch overhead of a dependent launch + the kernel; rocprofv3 reports the kernel
+        # alone.  The library records one EMPTY launch per frame in the same way (after K1): its interval is subtracted.
+        # Launches shorter than twice that interval are below what events can resolve: no duration, no GB/s for them
+        # (their rocprofv3 durations are in profiles/).
         empty = per_kernel.pop("_empty_launch", None)
         empty_ms = (empty[0] / empty[1]) if empty else 0.0
         kernels = {}
         for label, (tot, cnt) in per_kernel.items():
             launches = cnt / reps
             interval_ms = tot / cnt
-            avg_ms = max(interval_ms - empty_ms, 1e-4)
+            avg_ms = (interval_ms - empty_ms) if interval_ms >= 2.0 * empty_ms else None
             ab = alg.get(label)
             kernels[label] = {"launches_per_frame": launches, "avg_launch_ms": avg_ms, "event_interval_ms": interval_ms,
-                              "ms_per_frame": avg_ms * launches, "alg_bytes_per_launch": ab,
-                              "GBps": (ab / (avg_ms * 1e-3) / 1e9) if ab else None}
+                              "ms_per_frame": max(interval_ms - empty_ms, 0.0) * launches, "alg_bytes_per_launch": ab,
+                              "GBps": (ab / (avg_ms * 1e-3) / 1e9) if (ab and avg_ms) else None}
         # dominant kernel = the launch label with the most GPU time per frame (the same kernel symbols rocprofv3
         # --stats lists: the depth sort and the tile-id sort instantiate k_sort_scatter with different tile sizes)
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_frame"])

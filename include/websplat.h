@@ -267,8 +267,8 @@ int ws_renderer_frame_stats(ws_renderer* r, ws_frame_stats* out); /* syncs */
 int ws_renderer_enable_timers(ws_renderer* r, int enable);
 int ws_renderer_stage_times(ws_renderer* r, ws_stage_times* out);
 /* per-launch GPU time of the last frame (prepare + render), launch order; *count = launches recorded. Syncs.
- * Each time is a HIP-event interval = dispatch latency of a dependent launch + the kernel; the first entry,
- * "_empty_launch", is an empty kernel recorded the same way (subtract it to compare with rocprofv3 durations). */
+ * Each time is a HIP-event interval = dispatch latency of a dependent launch + the kernel; the entry
+ * "_empty_launch" (after the preprocess kernel) is an empty kernel recorded the same way (subtract it to compare with rocprofv3 durations). */
 int ws_renderer_kernel_times(ws_renderer* r, uint32_t capacity, ws_kernel_time* out, uint32_t* count);
 /* parity tooling: also record the original Gaussian index of every store slot (costs 4 B per visible splat) */
 int ws_renderer_enable_capture(ws_renderer* r, int enable);

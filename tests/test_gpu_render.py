@@ -413,7 +413,7 @@ def test_binning_covers_every_touched_tile(ws, oracle, kind, shape, monkeypatch)
 
 def test_stopwatch_stage_and_kernel_times(ws, ctx, oracle):
     """GPUStopwatch (utils.rs:26-134) equivalents: the four stage labels (renderer.rs:221,230, lib.rs:448 + binning)
-    and, at level 2, one interval per kernel launch in launch order, preceded by the empty calibration launch."""
+    and, at level 2, one interval per kernel launch in launch order, plus the empty calibration launch after K1."""
     sc = scenes.c1(ws, oracle, n=5000, viewport=(320, 240), seed=4)
     pc = ws.PointCloud(ctx, sc.gpc)
     r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
@@ -426,7 +426,7 @@ def test_stopwatch_stage_and_kernel_times(ws, ctx, oracle):
         assert all(v > 0 for v in st.values())
         kt = r.kernel_times()
         names = [k for k, _ in kt]
-        assert names[0] == "_empty_launch" and names[1] == "k_preprocess" and names[-1] == "k_blend"
+        assert names[0] == "k_preprocess" and names[1] == "_empty_launch" and names[-1] == "k_blend"
         assert "k_bin_prefix" in names and "k_bin_emit" in names
         assert sum(n.startswith("depth:") for n in names) == 12          # 4 passes x (histogram, scan, scatter)
         assert all(0 < ms < 50 for _, ms in kt)

@@ -621,15 +621,15 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     // memset clears the counters, every ticket, both sorts' digit histograms and the tile ranges
     WS_HIP(hipMemsetAsync(r->zero, 0, r->zero_bytes, stream));
     KernelMarks* km = r->marks.active ? &r->marks : nullptr;
-    if (km) {
-        km->begin(stream, true);
-        if ((rc = launch_empty(stream))) return rc;  // calibration interval: dispatch latency of a dependent launch
-        km_mark(km, "_empty_launch");
-    }
+    if (km) km->begin(stream, true);
     if (r->timers) WS_HIP(hipEventRecord(r->ev[0], stream));
     if ((rc = launch_preprocess(kp, kb, pc->compressed, stream))) return rc;
     km_mark(km, pc->compressed ? "k_preprocess<compressed>" : "k_preprocess");
     if (r->timers) WS_HIP(hipEventRecord(r->ev[1], stream));
+    if (km) {  // calibration interval between two kernels: the dispatch latency of a dependent launch
+        if ((rc = launch_empty(stream))) return rc;
+        km_mark(km, "_empty_launch");
+    }
 
     const int cut = r->ctx->debug_cut;
     if (cut == 1) {  // analysis only (WS_DEBUG_CUT): the image is NOT produced
