@@ -45,6 +45,10 @@ def build_workload(ws, name, n_views):
     if name == "c2":
         rows, (w, h), f = synth.scene_c2(n=1_200_000, seed=1), (1200, 799), 1200.0
         cams = synth.orbit_cameras(n_views, w, h, f, f)
+    elif name == "c4":
+        # BASELINE config 4: the c2 scene at 1920x1080, 64-view batch (view i -> rank i mod N)
+        rows, (w, h), f = synth.scene_c2(n=1_200_000, seed=1), (1920, 1080), 1920.0
+        cams = synth.orbit_cameras(n_views, w, h, f, f)
     elif name == "hd1m":
         rows, (w, h), f = synth.scene_c2(n=1_000_000, seed=1), (1920, 1080), 1920.0
         cams = synth.orbit_cameras(n_views, w, h, f, f)

@@ -1,6 +1,7 @@
 """Frames/s over N Gaussians x resolution (bonsai-like synthetic distribution), 4 frames in flight and 1 in flight.
 Writes gpurun_out/sweep.json; copy to profiles/ to keep."""
 import json, os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # four frames in flight need four hardware queues (bench.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "web-splat_amd"), os.path.join(ROOT, "tests"), ROOT]
 import numpy as np, torch

@@ -7,7 +7,7 @@
 //   * The point cloud lives in HBM as eight planes of 16-B chunks (ws_internal.h), so every load
 //     instruction of a wave is one fully coalesced 1-KiB read, and a culled Gaussian costs 16 B
 //     instead of 124 B: SH / covariance planes are only touched by lanes that survive the cull.
-//   * Compaction is ORDERED (store order == Gaussian index order) through a wave-parallel
+//   * Compaction is ORDERED (store order == Gaussian index order) through a ticketed, wave-parallel
 //     decoupled look-back over 1024-Gaussian blocks: one 32-bit {flag,count} word per block, no fence
 //     needed because the word is its own payload.  The reference's atomicAdd(keys_size) order is
 //     nondeterministic (preprocess.wgsl:262); ordered compaction makes equal-depth ties, and hence the
@@ -31,8 +31,8 @@ constexpr int K1_THREADS = 256;
 #ifndef WS_K1_ITEMS
 #define WS_K1_ITEMS 4
 #endif
-constexpr int K1_ITEMS = WS_K1_ITEMS;  // Gaussians per thread (measured on c2, blockIdx order: 4 -> 53 us alone and the
-                                       // most frames/s in flight; 2 -> 49 us alone but -3 % in flight; 1 -> 57; 8 -> slower)
+constexpr int K1_ITEMS = WS_K1_ITEMS;  // Gaussians per thread (measured on c2: 2 -> 59 us, 4 -> 56, 8 -> 70; 1 -> 80:
+                                       // one ticket per 256 Gaussians makes the ~11 ns dispenser atomic the bottleneck)
 #ifndef WS_K1_BACK_GROUP
 #define WS_K1_BACK_GROUP 2
 #endif
@@ -515,9 +515,8 @@ __device__ __forceinline__ void k1_back_compressed(const K1Params& p, const K1Bu
     k1_math<true>(p, f.xyz, camspace, pos2d, opacity, cov6, sh, so);
 }
 
-// One workgroup = one link of the look-back chain = K1_ITEMS x 256 consecutive Gaussians (1024); with
-// -DWS_TICKET_ORDER a single device-wide atomic per 1024 Gaussians keeps the ticket dispenser (~11 ns per returning
-// atomic on one address) below the
+// One workgroup = one ticket = K1_ITEMS x 256 consecutive Gaussians (1024): a single device-wide atomic per
+// 1024 Gaussians keeps the ticket dispenser (~11 ns per returning atomic on one address) well below the
 // kernel's HBM time.  Store order inside the block is (item, thread) = Gaussian index order.
 #ifndef WS_K1_MINWAVES
 #define WS_K1_MINWAVES 1
@@ -531,12 +530,15 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    // Workgroup order of the look-back = blockIdx order (lookback.h: dispatch is in order per XCD; -DWS_TICKET_ORDER
-    // hands the ids out by an atomic ticket instead: start order, no assumption, ~11 ns per workgroup in series)
-#ifdef WS_TICKET_ORDER
-    if (tid == 0) s_bid = atomicAdd(&b.counters->k1_ticket, 1u);
-#else
+    // Workgroup ids are handed out by an atomic ticket = START order: a workgroup only ever waits for workgroups that
+    // already hold their slot.  (blockIdx order -- -DWS_BLOCKIDX_ORDER -- saves the ~11 ns the returning atomic costs
+    // per workgroup, in series, but is NOT safe with several look-back kernels in flight: measured on MI355X with four
+    // frames on four streams, spinners of one kernel held the slots the missing predecessor of another needed and
+    // vice versa -- 6 ms and 38 ms per frame instead of 0.18 and 0.35, lookback.h.)
+#ifdef WS_BLOCKIDX_ORDER
     if (tid == 0) s_bid = blockIdx.x;
+#else
+    if (tid == 0) s_bid = atomicAdd(&b.counters->k1_ticket, 1u);
 #endif
     __syncthreads();
     const uint32_t bid = s_bid;

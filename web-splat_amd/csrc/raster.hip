@@ -9,7 +9,7 @@
 // list front-to-back out of LDS, keeping colour and transmittance in registers and writing each pixel once.
 //
 //   k_bin_prefix  : per depth-sorted splat: gather its tile rectangle, count tiles, exclusive prefix over the
-//                   draw order in ONE pass (wave-parallel decoupled look-back), total D
+//                   draw order in ONE pass (ticketed wave-parallel decoupled look-back), total D
 //   k_bin_emit    : entry-parallel: every workgroup produces exactly EMIT_TILE (tile id, splat) entries, whatever
 //                   the footprint of the splats they come from (owners by an LDS max-scan over the splat offsets)
 //   (radix sort of the entries by tile id: sort.hip, ceil(log2 T / 8) passes, stable -> depth order kept inside a
@@ -84,14 +84,17 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_base;
     const uint32_t v = counters->num_visible;
-    if ((uint64_t)blockIdx.x * BIN_ITEMS >= v) return;  // surplus workgroups leave first
+    if ((uint64_t)blockIdx.x * BIN_ITEMS >= v) return;  // surplus workgroups leave before drawing a ticket
     const int tid = threadIdx.x;
-    // Workgroup order of the look-back = blockIdx order (lookback.h: dispatch is in order per XCD; -DWS_TICKET_ORDER
-    // hands the ids out by an atomic ticket instead: start order, no assumption, ~11 ns per workgroup in series)
-#ifdef WS_TICKET_ORDER
-    if (tid == 0) s_bid = atomicAdd(&counters->bin_ticket, 1u);
-#else
+    // Workgroup ids are handed out by an atomic ticket = START order: a workgroup only ever waits for workgroups that
+    // already hold their slot.  (blockIdx order -- -DWS_BLOCKIDX_ORDER -- saves the ~11 ns the returning atomic costs
+    // per workgroup, in series, but is NOT safe with several look-back kernels in flight: measured on MI355X with four
+    // frames on four streams, spinners of one kernel held the slots the missing predecessor of another needed and
+    // vice versa -- 6 ms and 38 ms per frame instead of 0.18 and 0.35, lookback.h.)
+#ifdef WS_BLOCKIDX_ORDER
     if (tid == 0) s_bid = blockIdx.x;
+#else
+    if (tid == 0) s_bid = atomicAdd(&counters->bin_ticket, 1u);
 #endif
     __syncthreads();
     const uint32_t bid = s_bid;
