@@ -436,3 +436,36 @@ def test_stopwatch_stage_and_kernel_times(ws, ctx, oracle):
     finally:
         r.close()
         pc.close()
+
+
+def test_wave_stats_capture(ws, ctx, oracle):
+    """Analysis read-back of the compositing pass: per wave the staged records it composited, per tile the lock-step
+    cost (sum over batches of the busiest wave).  Needs capture mode; the image is unchanged by it."""
+    sc = scenes.c1(ws, oracle, n=8000, viewport=(320, 200), seed=5)
+    pc = ws.PointCloud(ctx, sc.gpc)
+    r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    try:
+        r.prepare(pc, sc.args)
+        r.render(pc)
+        img_plain = r.download_target()
+        with pytest.raises(ws.WebSplatError):
+            r.wave_stats()
+        r.enable_capture(True)
+        r.prepare(pc, sc.args)
+        r.render(pc)
+        img_cap = r.download_target()
+        assert np.array_equal(img_plain, img_cap)
+        st = r.wave_stats().astype(np.int64)
+        ts = r.tile_stats(with_consumed=True)
+        tw, th = ctx.tile_size()
+        nw = (tw // 8) * (th // 8)
+        assert st.shape == (len(ts["list_len"]), 17)
+        per_wave, lock = st[:, :nw], st[:, 16]
+        assert np.all(st[:, nw:16] == 0)
+        assert np.all(lock >= per_wave.max(axis=1)) and np.all(lock <= per_wave.sum(axis=1))
+        assert np.all(per_wave.max(axis=1) <= ts["consumed"] + 3)            # lists are padded to multiples of four
+        assert np.all((ts["list_len"] == 0) <= (per_wave.sum(axis=1) == 0))
+        assert per_wave.sum() > 0
+    finally:
+        r.close()
+        pc.close()

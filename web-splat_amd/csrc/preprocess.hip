@@ -27,7 +27,10 @@ namespace ws {
 
 namespace {
 
-constexpr int K1_THREADS = 256;
+#ifndef WS_K1_THREADS
+#define WS_K1_THREADS 256
+#endif
+constexpr int K1_THREADS = WS_K1_THREADS;
 #ifndef WS_K1_ITEMS
 #define WS_K1_ITEMS 4
 #endif
