@@ -252,6 +252,11 @@ def _k1_float64(gaussians, sh, cu, rs, sh_deg):
     opacity = raw[:, 12:14].copy().view(np.float16).astype(np.float64)[:, 0]
     cov6 = raw[:, 16:28].copy().view(np.float16).astype(np.float64)            # xx xy xz yy yz zz
     coef = np.ascontiguousarray(sh).view(np.uint8).reshape(n, 96).copy().view(np.float16).astype(np.float64).reshape(n, 16, 3)
+    return _k1_core_float64(xyz, opacity, cov6, coef, cu, rs, sh_deg, compressed=False)
+
+
+def _k1_core_float64(xyz, opacity, cov6, coef, cu, rs, sh_deg, compressed):
+    n = xyz.shape[0]
     V = np.array(cu.view[:], dtype=np.float64).reshape(4, 4).T                 # column-major storage -> matrix
     P = np.array(cu.proj[:], dtype=np.float64).reshape(4, 4).T
     Vinv = np.array(cu.view_inv[:], dtype=np.float64).reshape(4, 4).T
@@ -264,7 +269,8 @@ def _k1_float64(gaussians, sh, cu, rs, sh_deg):
     bounds = 1.2 * w
     lo, hi = np.array(rs.clip_min[:3]), np.array(rs.clip_max[:3])
     vis = np.all(xyz >= lo, 1) & np.all(xyz <= hi, 1)
-    vis &= ~((z <= 0) | (z >= 1) | (clip[:, 0] < -bounds) | (clip[:, 0] > bounds) | (clip[:, 1] < -bounds) | (clip[:, 1] > bounds))
+    zcull = ((z < 0) | (z > 1)) if compressed else ((z <= 0) | (z >= 1))   # preprocess_compressed.wgsl:229 vs preprocess.wgsl:192
+    vis &= ~(zcull | (clip[:, 0] < -bounds) | (clip[:, 0] > bounds) | (clip[:, 1] < -bounds) | (clip[:, 1] > bounds))
     # fade-in
     dd = 5.0 * np.linalg.norm(np.array(rs.scene_center[:3]) - xyz, axis=1) / float(rs.scene_extend)
     t = np.clip(float(rs.walltime) - dd, 0.0, 1.0)
@@ -297,13 +303,17 @@ def _k1_float64(gaussians, sh, cu, rs, sh_deg):
     d1, d2 = a_ + ks, c_ + ks
     mid = 0.5 * (d1 + d2)
     rad = np.hypot((d1 - d2) / 2, b_)
-    l1, l2 = mid + rad, np.maximum(mid - rad, 0.1)
+    if compressed:   # preprocess_compressed.wgsl:296-297 clamps the radius, not the smaller eigenvalue
+        l1, l2 = mid + np.maximum(rad, 0.1), mid - np.maximum(rad, 0.1)
+    else:
+        l1, l2 = mid + rad, np.maximum(mid - rad, 0.1)
     ex, ey = b_, l1 - d1                                                         # eigenvector of the larger eigenvalue
     nrm = np.hypot(ex, ey)
     ok = nrm > 0
     ex, ey = np.where(ok, ex / np.where(ok, nrm, 1), 1.0), np.where(ok, ey / np.where(ok, nrm, 1), 0.0)
     v1 = np.sqrt(2 * l1)[:, None] * np.stack([ex, ey], 1)
-    v2 = np.sqrt(2 * l2)[:, None] * np.stack([ey, -ex], 1)
+    with np.errstate(invalid="ignore"):
+        v2 = np.sqrt(2 * l2)[:, None] * np.stack([ey, -ex], 1)
     centre = clip[:, :2] / w[:, None]
     campos = Vinv[:3, 3]
     d = xyz - campos
@@ -328,6 +338,9 @@ def _k1_float64(gaussians, sh, cu, rs, sh_deg):
     col = np.maximum(col + 0.5, 0.0)
     rec = np.concatenate([v1 / [vw, vh], v2 / [vw, vh], centre, col, op[:, None]], 1)
     zfar = -P[2, 3] / (P[2, 2] - 1.0)
+    if compressed:
+        znear = -P[2, 3] / P[2, 2]
+        return vis, rec, 16777215.0 - (clip[:, 2] - znear) / (zfar - znear) * 16777215.0
     return vis, rec, zfar - clip[:, 2]
 
 
@@ -416,3 +429,56 @@ def test_render_oracle_agrees_with_float64_derivation(oracle):
     diff = np.abs(img - out).max(-1)
     assert np.mean(diff) < 2e-6
     assert (diff > 5e-5).sum() <= 4 and diff.max() < 0.0135
+
+
+@pytest.mark.parametrize("sh_deg", [3, 1])
+def test_k1c_oracle_agrees_with_float64_derivation(oracle, sh_deg):
+    """preprocess_compressed.wgsl:137-332 (int8 de-quantisation, codebook covariance x exp(scale)^2, packed SH records,
+    24-bit depth key, the radius-clamped eigenvalues) derived independently in float64 against the C oracle."""
+    from websplat import synth
+    blobs = synth.compressed_blobs(n=6000, n_geometry=256, n_sh=199, seed=51, sh_deg=sh_deg)
+    gdt = np.dtype([("xyz", "<f4", 3), ("opacity", "i1"), ("scale_factor", "i1"), ("pad", "u1", 2),
+                    ("geometry_idx", "<u4"), ("sh_idx", "<u4")])             # GaussianCompressed, pointcloud.rs:14-22
+    g = np.ascontiguousarray(blobs["gaussians"]).view(np.uint8).reshape(-1, 24).copy().view(gdt).reshape(-1)
+    n = len(g)
+    q = blobs["quant"]
+    xyz = g["xyz"].astype(np.float64)
+    deq = lambda v, name: (v.astype(np.float64) - q[name][0]) * np.float64(np.float32(q[name][1]))
+    opacity = deq(g["opacity"], "opacity")
+    s2 = np.exp(deq(g["scale_factor"], "scaling_factor")) ** 2
+    cov6 = blobs["covars"].view(np.float16).reshape(-1, 6).astype(np.float64)[g["geometry_idx"]] * s2[:, None]
+    ncoef = (sh_deg + 1) ** 2
+    sh8 = np.ascontiguousarray(blobs["sh"]).view(np.int8).reshape(-1, 3 * ncoef)[g["sh_idx"]].astype(np.float64)
+    sh8 = np.maximum(sh8, -127.0)                                   # unpack4x8snorm clamps -128 to -1.0
+    coef = np.zeros((n, 16, 3))
+    coef[:, 0] = (sh8[:, 0:3] - q["color_dc"][0]) * np.float64(np.float32(q["color_dc"][1]))
+    coef[:, 1:ncoef] = ((sh8[:, 3:] - q["color_rest"][0]) * np.float64(np.float32(q["color_rest"][1]))).reshape(n, ncoef - 1, 3)
+    cj = synth.look_at_camera(0, [0.0, 0.0, -3.0], [0, 0, 0], 800, 600, 800.0, 800.0)
+    cam = oracle.scene_camera_to_perspective(cj.position, cj.rotation, cj.fx, cj.fy, 800, 600)
+    aabb = oracle.make_aabb(xyz.min(0), xyz.max(0))
+    oracle.fit_near_far(cam, aabb)
+    cu = oracle.camera_uniform(cam, 800, 600)
+    rs = oracle.settings_uniform(aabb, xyz.mean(0), max_sh_deg=sh_deg)
+    oq = oracle.make_quantization(q)
+    splats, keys, src = oracle.preprocess_compressed(blobs["gaussians"], blobs["sh"], blobs["covars"], oq, sh_deg, cu, rs)
+    vis, rec, key64 = _k1_core_float64(xyz, opacity, cov6, coef, cu, rs, sh_deg, compressed=True)
+    mine, theirs = set(np.nonzero(vis)[0].tolist()), set(src.tolist())
+    assert len(mine ^ theirs) <= 2, sorted(mine ^ theirs)[:10]
+    both = np.array(sorted(mine & theirs))
+    assert len(both) > 1000
+    row_of = {int(s_): i for i, s_ in enumerate(src.tolist())}
+    rows = [row_of[int(i)] for i in both]
+    got = splats[rows].view(np.float16).astype(np.float64).reshape(-1, 10)
+    want = rec[both]
+    fin = np.all(np.isfinite(want), 1) & np.all(np.isfinite(got), 1)      # lambda2 < 0 gives NaN axes on both sides
+    assert np.array_equal(np.all(np.isfinite(want), 1), np.all(np.isfinite(got), 1))
+    assert fin.sum() > 1000
+    got, want = got[fin], want[fin]
+    sig = lambda v: np.einsum("ni,nj->nij", v[:, 0:2], v[:, 0:2]) + np.einsum("ni,nj->nij", v[:, 2:4], v[:, 2:4])
+    scale = np.abs(sig(want)).max(axis=(1, 2))[:, None, None]
+    assert np.max(np.abs(sig(got) - sig(want)) / scale) < 6e-3
+    assert np.max(np.abs(got[:, 4:6] - want[:, 4:6])) < 1.5e-3
+    assert np.max(np.abs(got[:, 6:10] - want[:, 6:10]) / np.maximum(np.abs(want[:, 6:10]), 0.05)) < 3e-3
+    k_got = keys[rows].astype(np.float64)[fin]
+    # 24-bit integer keys: the f32 expression carries a few ulp (1-2 units at 1.6e7 each) into the truncation
+    assert np.max(np.abs(k_got - np.floor(key64[both][fin]))) <= 4
