@@ -277,8 +277,11 @@ def main():
         }
         # An event interval = event + dispatch overhead of a dependent launch + the kernel; rocprofv3 reports the kernel
         # alone.  The library records one EMPTY launch per frame in the same way (after K1): its interval is subtracted.
-        # Launches shorter than twice that interval are below what events can resolve: no duration, no GB/s for them
-        # (their rocprofv3 durations are in profiles/).
+        # What an interval carries on top of the kernel is mostly the write-back of the PREVIOUS kernel's dirty L2 lines,
+        # so it varies (6 us after a memset, 12 us after K1's 30 MB of stores -- about what precedes the blend, for
+        # which the calibrated time matches rocprofv3 to 1 %); GBps_interval (nothing subtracted) is the lower bound.
+        # Launches shorter than twice the empty interval are below what events can resolve: no calibrated duration
+        # for them (their rocprofv3 durations are in profiles/).
         empty = per_kernel.pop("_empty_launch", None)
         empty_ms = (empty[0] / empty[1]) if empty else 0.0
         kernels = {}
@@ -289,7 +292,9 @@ def main():
             ab = alg.get(label)
             kernels[label] = {"launches_per_frame": launches, "avg_launch_ms": avg_ms, "event_interval_ms": interval_ms,
                               "ms_per_frame": max(interval_ms - empty_ms, 0.0) * launches, "alg_bytes_per_launch": ab,
-                              "GBps": (ab / (avg_ms * 1e-3) / 1e9) if (ab and avg_ms) else None}
+                              "GBps": (ab / (avg_ms * 1e-3) / 1e9) if (ab and avg_ms) else None,
+                              # lower bound: the whole event interval charged to the kernel
+                              "GBps_interval": (ab / (interval_ms * 1e-3) / 1e9) if ab else None}
         # dominant kernel = the launch label with the most GPU time per frame (the same kernel symbols rocprofv3
         # --stats lists: the depth sort and the tile-id sort instantiate k_sort_scatter with different tile sizes)
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_frame"])
