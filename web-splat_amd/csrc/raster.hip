@@ -32,7 +32,7 @@ namespace {
 
 constexpr int BIN_THREADS = 256;
 #ifndef WS_BIN_IPT
-#define WS_BIN_IPT 8
+#define WS_BIN_IPT 16
 #endif
 constexpr int BIN_IPT = WS_BIN_IPT;                // sorted splats per thread
 
