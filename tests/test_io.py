@@ -169,3 +169,73 @@ def test_oracle_io_closed_forms():
     src = np.array([[[0.25, 0.0, 0.5, 0.5]]], dtype=np.float32)
     assert oio.display_composite(src, (1.0, 1.0, 0.0, 1.0)).tolist() == [[[191, 128, 128, 255]]]
     assert oio.display_composite(src, (1.0, 1.0, 0.0, 1.0), bgra=True).tolist() == [[[128, 128, 191, 255]]]
+
+
+# ---- robustness of the host parsers: arbitrary bytes must come back as an error code, never crash -------------------
+from hypothesis import given, settings, strategies as st, HealthCheck  # noqa: E402
+
+
+@settings(max_examples=300, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(st.text(alphabet=st.sampled_from(list("[]{}\",:0123456789.eE+-truefalsn \n\\u\"idpostnwhgfxyrm_")), max_size=200))
+def test_scene_json_fuzz_never_crashes(ws, text):
+    """RFC 8259 reader of cameras.json (scene.rs:113-135 via serde_json in the reference): any input either parses
+    into a Scene or returns WS_ERR_*; the error travels as an exception, the process survives."""
+    try:
+        sc = ws.Scene.from_json_text(text)
+    except ws.WebSplatError:
+        return
+    assert sc.num_cameras() >= 0
+    sc.close()
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(st.data())
+def test_scene_json_mutations_never_crash(ws, data):
+    base = _cams_json(7)
+    pos = data.draw(st.integers(0, len(base) - 1))
+    kind = data.draw(st.sampled_from(["truncate", "delete", "replace", "duplicate"]))
+    if kind == "truncate":
+        text = base[:pos]
+    elif kind == "delete":
+        text = base[:pos] + base[pos + data.draw(st.integers(1, 20)):]
+    elif kind == "replace":
+        text = base[:pos] + data.draw(st.sampled_from(list("[]{},:\"x9-e. "))) + base[pos + 1:]
+    else:
+        text = base[:pos] + base[pos:pos + 30] + base[pos:]
+    try:
+        sc = ws.Scene.from_json_text(text)
+    except ws.WebSplatError:
+        return
+    assert 0 <= sc.num_cameras() <= 8
+    sc.close()
+
+
+@settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(st.data())
+def test_npz_reader_mutations_never_crash(ws, tmp_path_factory, data):
+    """ZIP / ZIP64 / .npy / DEFLATE reader (io/npz.rs via the npyz + zip crates in the reference): a valid c3dgs file
+    with one region truncated, zeroed or overwritten with random bytes is either still readable or rejected."""
+    global _NPZ_BASE
+    try:
+        raw = _NPZ_BASE
+    except NameError:
+        a = synth.c3dgs_arrays(n=300, n_geometry=16, n_sh=16, seed=9, sh_deg=1)
+        p = str(tmp_path_factory.mktemp("fuzz") / "base.npz")
+        synth.write_npz(p, a)
+        raw = _NPZ_BASE = open(p, "rb").read()
+    kind = data.draw(st.sampled_from(["truncate", "zero", "random", "central_dir"]))
+    buf = bytearray(raw)
+    if kind == "truncate":
+        buf = buf[:data.draw(st.integers(0, len(raw) - 1))]
+    else:
+        lo = data.draw(st.integers(0, len(raw) - 1)) if kind != "central_dir" else data.draw(st.integers(max(0, len(raw) - 1200), len(raw) - 1))
+        n = data.draw(st.integers(1, 64))
+        fill = bytes(n) if kind == "zero" else data.draw(st.binary(min_size=n, max_size=n))
+        buf[lo:lo + n] = fill[:max(0, min(n, len(raw) - lo))]
+    path = str(tmp_path_factory.mktemp("fuzz") / "m.npz")
+    open(path, "wb").write(bytes(buf))
+    try:
+        got = ws.read_npz(path)
+    except ws.WebSplatError:
+        return
+    assert got.num_points >= 0
