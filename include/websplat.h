@@ -205,6 +205,29 @@ int ws_pointcloud_stats(const void* gaussians, uint32_t n, uint32_t stride, cons
                         float center[3], int32_t* has_up, float up[3]);
 /* io/mod.rs:45-61 GenericGaussianPointCloud::load for a binary PLY file, then PointCloud::new */
 int ws_pointcloud_load_ply(ws_context* ctx, const char* path, ws_pointcloud** out);
+/* io/ply.rs:28-196 PlyReader::read + GenericGaussianPointCloud::new (io/mod.rs:63-105) on the HOST: the INRIA 3DGS
+ * .ply decoded into the loader's byte blobs (Gaussian 28 B x N, SH 96 B x N; host memory owned by the returned
+ * object), bbox grown from Aabb::zeroed(), centroid, plane fit, header comments.  No GPU needed. */
+typedef struct ws_ply_cloud {
+    uint32_t num_points;
+    uint32_t sh_deg;
+    const void* gaussians;
+    size_t gaussians_bytes;
+    const void* sh_coefs;
+    size_t sh_coefs_bytes;
+    ws_aabb bbox;
+    float center[3];
+    int32_t has_up;
+    float up[3];
+    int32_t has_mip_splatting;
+    int32_t mip_splatting;
+    int32_t has_kernel_size;
+    float kernel_size;
+    int32_t has_background_color;
+    float background_color[3];
+} ws_ply_cloud;
+int ws_ply_read(const char* path, ws_ply_cloud** out);
+void ws_ply_free(ws_ply_cloud* pc);
 
 /* io/npz.rs:59-225 NpzReader::read: a c3dgs .npz decoded into the loader's byte blobs (HOST memory, owned by the
  * returned object): GaussianCompressed 24 B x N, packed int8 SH records 3*(sh_deg+1)^2 B, Covariance3D 12 B x M,

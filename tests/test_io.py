@@ -239,3 +239,89 @@ def test_npz_reader_mutations_never_crash(ws, tmp_path_factory, data):
     except ws.WebSplatError:
         return
     assert got.num_points >= 0
+
+
+# ---- INRIA .ply reader on the host (io/ply.rs:28-196, io/mod.rs:63-105) ------------------------------------------------
+@pytest.mark.parametrize("sh_deg,big", [(3, False), (3, True), (2, False), (1, True), (0, False)])
+def test_ply_reader_matches_oracle(ws, oracle, tmp_path, sh_deg, big):
+    rows = synth.scene_c1(n=3000, seed=60 + sh_deg, sh_deg=sh_deg)
+    p = str(tmp_path / "scene.ply")
+    synth.write_ply(p, rows, sh_deg, comments=["mip=false", "kernel_size=0.125", "background_color=1,0.5,0.25"], big_endian=big)
+    got = ws.read_ply(p)
+    assert got.num_points == 3000 and got.sh_deg == sh_deg and not got.compressed
+    g, s = oracle.ply_rows_convert(rows, sh_deg)
+    assert np.array_equal(got.gaussians, g) and np.array_equal(got.sh_coefs, s)          # byte-exact blobs
+    bbox, center, up = oracle.pointcloud_stats(g, 28, oracle.make_aabb([0, 0, 0], [0, 0, 0]))
+    assert np.array_equal(np.float32(got.aabb.min), np.float32(list(bbox.min)))
+    assert np.array_equal(np.float32(got.aabb.max), np.float32(list(bbox.max)))
+    assert np.array_equal(np.float32(got.center), np.float32(center))
+    assert (got.up is None) == (up is None) and (up is None or np.allclose(got.up, up))
+    assert got.mip_splatting is False and got.kernel_size == 0.125 and np.allclose(got.background_color, [1, 0.5, 0.25])
+    # the same file through the rows path of the Python binding
+    ref = ws.GenericGaussianPointCloud.from_ply_rows(rows, sh_deg)
+    assert np.array_equal(ref.gaussians, got.gaussians) and np.array_equal(ref.sh_coefs, got.sh_coefs)
+
+
+def test_ply_reader_errors(ws, tmp_path):
+    rows = synth.scene_c1(n=100, seed=3, sh_deg=3)
+    p = str(tmp_path / "ok.ply")
+    synth.write_ply(p, rows, 3)
+    raw = open(p, "rb").read()
+    head_end = raw.index(b"end_header\n") + len(b"end_header\n")
+
+    def expect(data, match=None):
+        q = str(tmp_path / "bad.ply")
+        open(q, "wb").write(data)
+        with pytest.raises(ws.WebSplatError, match=match):
+            ws.read_ply(q)
+
+    expect(b"plx\n" + raw[4:], "magic")
+    expect(raw[:head_end - len(b"end_header\n")], "end_header")
+    expect(raw[:-40], "truncated")
+    expect(raw.replace(b"binary_little_endian", b"ascii"), "ascii")
+    expect(raw.replace(b"element vertex 100", b"element vertex 4000000000"), "truncated")     # header lies about N
+    expect(raw.replace(b"property float f_rest_44\n", b""), "sh degree|layout")
+    expect(raw.replace(b"property float opacity", b"property double opacity"), "sh degree|layout")
+    expect(raw.replace(b"element vertex 100", b"element vertex 0"), "layout")
+    with pytest.raises(ws.WebSplatError, match="cannot open"):
+        ws.read_ply(str(tmp_path / "nope.ply"))
+    q = str(tmp_path / "mip.ply")
+    synth.write_ply(q, rows, 3, comments=["mip=maybe"])
+    with pytest.raises(ws.WebSplatError, match="mip"):
+        ws.read_ply(q)
+    synth.write_ply(q, rows, 3, comments=["background_color=red"])       # only warned about in the reference
+    assert ws.read_ply(q).background_color is None
+
+
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(st.data())
+def test_ply_reader_mutations_never_crash(ws, tmp_path_factory, data):
+    global _PLY_BASE
+    try:
+        raw = _PLY_BASE
+    except NameError:
+        p = str(tmp_path_factory.mktemp("fuzz") / "base.ply")
+        synth.write_ply(p, synth.scene_c1(n=50, seed=4, sh_deg=2), 2, comments=["mip=true", "kernel_size=0.3"])
+        raw = _PLY_BASE = open(p, "rb").read()
+    head_end = raw.index(b"end_header\n") + 11
+    kind = data.draw(st.sampled_from(["truncate", "header_byte", "header_del", "body", "number"]))
+    buf = bytearray(raw)
+    if kind == "truncate":
+        buf = buf[:data.draw(st.integers(0, len(raw) - 1))]
+    elif kind == "header_byte":
+        buf[data.draw(st.integers(0, head_end - 1))] = data.draw(st.integers(0, 255))
+    elif kind == "header_del":
+        lo = data.draw(st.integers(0, head_end - 1))
+        del buf[lo:lo + data.draw(st.integers(1, 40))]
+    elif kind == "body":
+        lo = data.draw(st.integers(head_end, len(raw) - 1))
+        buf[lo:lo + 8] = data.draw(st.binary(min_size=8, max_size=8))[:len(raw) - lo]
+    else:
+        buf = bytearray(bytes(buf).replace(b"element vertex 50", b"element vertex " + str(data.draw(st.integers(0, 2 ** 40))).encode()))
+    path = str(tmp_path_factory.mktemp("fuzz") / "m.ply")
+    open(path, "wb").write(bytes(buf))
+    try:
+        got = ws.read_ply(path)
+    except ws.WebSplatError:
+        return
+    assert got.num_points > 0 and got.gaussians.shape == (got.num_points, 28)

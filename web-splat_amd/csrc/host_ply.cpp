@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -86,11 +87,16 @@ bool comment_value(const PlyHeader& h, const char* key, std::string* value) {
 
 }  // namespace
 
-extern "C" int ws_pointcloud_load_ply(ws_context* ctx, const char* path, ws_pointcloud** out) {
-    if (!ctx || !path || !out) return fail(WS_ERR_INVALID, "ws_pointcloud_load_ply: null argument");
+struct ws_ply_cloud_impl {
+    ws_ply_cloud pub;  // first member: the public view
+    std::vector<uint8_t> gaussians, sh;
+};
+
+extern "C" int ws_ply_read(const char* path, ws_ply_cloud** out) {
+    if (!path || !out) return fail(WS_ERR_INVALID, "ws_ply_read: null argument");
     *out = nullptr;
     FILE* f = std::fopen(path, "rb");
-    if (!f) return fail(WS_ERR_IO, std::string("ws_pointcloud_load_ply: cannot open ") + path);
+    if (!f) return fail(WS_ERR_IO, std::string("ws_ply_read: cannot open ") + path);
     PlyHeader h;
     int rc = parse_header(f, &h);
     if (rc) {
@@ -110,43 +116,66 @@ extern "C" int ws_pointcloud_load_ply(ws_context* ctx, const char* path, ws_poin
         std::fclose(f);
         return fail(WS_ERR_IO, "ply: vertex layout is not the INRIA 3DGS layout (x,y,z,n*,f_dc*,f_rest*,opacity,scale*,rot*)");
     }
+    // the body must actually be there before anything is sized by the header's vertex count
+    std::fseek(f, 0, SEEK_END);
+    const long file_size = std::ftell(f);
+    const uint64_t need = (uint64_t)h.num_vertices * row_len * sizeof(float);
+    if (file_size < 0 || (uint64_t)(file_size - h.body_offset) < need) {
+        std::fclose(f);
+        return fail(WS_ERR_IO, "ply: truncated vertex data");
+    }
     std::vector<float> rows;
+    auto* impl = new (std::nothrow) ws_ply_cloud_impl();
     try {
+        if (!impl) throw std::bad_alloc();
         rows.resize((size_t)h.num_vertices * row_len);
+        impl->gaussians.resize((size_t)h.num_vertices * 28);
+        impl->sh.resize((size_t)h.num_vertices * 96);
     } catch (...) {
         std::fclose(f);
+        delete impl;
         return fail(WS_ERR_OOM, "ply: host allocation failed");
     }
     std::fseek(f, h.body_offset, SEEK_SET);
     const size_t got = std::fread(rows.data(), sizeof(float), rows.size(), f);
     std::fclose(f);
-    if (got != rows.size()) return fail(WS_ERR_IO, "ply: truncated vertex data");
+    if (got != rows.size()) {
+        delete impl;
+        return fail(WS_ERR_IO, "ply: truncated vertex data");
+    }
     if (!h.little_endian) {
         uint32_t* w = reinterpret_cast<uint32_t*>(rows.data());
         for (size_t i = 0; i < rows.size(); ++i) w[i] = __builtin_bswap32(w[i]);
     }
-    std::vector<uint8_t> gaussians((size_t)h.num_vertices * 28), sh((size_t)h.num_vertices * 96);
-    if ((rc = ws_ply_rows_convert(rows.data(), h.num_vertices, sh_deg, gaussians.data(), sh.data()))) return rc;
+    if ((rc = ws_ply_rows_convert(rows.data(), h.num_vertices, sh_deg, impl->gaussians.data(), impl->sh.data()))) {
+        delete impl;
+        return rc;
+    }
     rows.clear();
     rows.shrink_to_fit();
 
-    ws_pointcloud_desc d;
+    ws_ply_cloud& d = impl->pub;
     std::memset(&d, 0, sizeof d);
     d.num_points = h.num_vertices;
     d.sh_deg = sh_deg;
-    d.compressed = 0;
-    d.gaussians = gaussians.data();
-    d.gaussians_bytes = gaussians.size();
-    d.sh_coefs = sh.data();
-    d.sh_coefs_bytes = sh.size();
+    d.gaussians = impl->gaussians.data();
+    d.gaussians_bytes = impl->gaussians.size();
+    d.sh_coefs = impl->sh.data();
+    d.sh_coefs_bytes = impl->sh.size();
     ws_aabb zero;  // Aabb::zeroed(), io/mod.rs:74
     std::memset(&zero, 0, sizeof zero);
-    if ((rc = ws_pointcloud_stats(gaussians.data(), h.num_vertices, 28, &zero, &d.bbox, d.center, &d.has_up, d.up))) return rc;
+    if ((rc = ws_pointcloud_stats(impl->gaussians.data(), h.num_vertices, 28, &zero, &d.bbox, d.center, &d.has_up, d.up))) {
+        delete impl;
+        return rc;
+    }
     std::string v;
     if (comment_value(h, "mip", &v)) {  // io/ply.rs:123-130 (parse::<bool>)
         d.has_mip_splatting = 1;
         d.mip_splatting = (v == "true") ? 1 : 0;
-        if (v != "true" && v != "false") return fail(WS_ERR_IO, "ply: bad mip comment");
+        if (v != "true" && v != "false") {
+            delete impl;
+            return fail(WS_ERR_IO, "ply: bad mip comment");
+        }
     }
     if (comment_value(h, "kernel_size", &v)) {
         d.has_kernel_size = 1;
@@ -159,5 +188,40 @@ extern "C" int ws_pointcloud_load_ply(ws_context* ctx, const char* path, ws_poin
             std::memcpy(d.background_color, c, sizeof c);
         }  // parse failures are only warned about in the reference (io/ply.rs:36-38)
     }
-    return ws_pointcloud_create(ctx, &d, out);
+    *out = &impl->pub;
+    return WS_OK;
+}
+
+extern "C" void ws_ply_free(ws_ply_cloud* pc) {
+    if (pc) delete reinterpret_cast<ws_ply_cloud_impl*>(pc);  // pub is the first member
+}
+
+extern "C" int ws_pointcloud_load_ply(ws_context* ctx, const char* path, ws_pointcloud** out) {
+    if (!ctx || !path || !out) return fail(WS_ERR_INVALID, "ws_pointcloud_load_ply: null argument");
+    *out = nullptr;
+    ws_ply_cloud* h = nullptr;
+    int rc = ws_ply_read(path, &h);
+    if (rc) return rc;
+    ws_pointcloud_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.num_points = h->num_points;
+    d.sh_deg = h->sh_deg;
+    d.compressed = 0;
+    d.gaussians = h->gaussians;
+    d.gaussians_bytes = h->gaussians_bytes;
+    d.sh_coefs = h->sh_coefs;
+    d.sh_coefs_bytes = h->sh_coefs_bytes;
+    d.bbox = h->bbox;
+    std::memcpy(d.center, h->center, sizeof d.center);
+    d.has_up = h->has_up;
+    std::memcpy(d.up, h->up, sizeof d.up);
+    d.has_mip_splatting = h->has_mip_splatting;
+    d.mip_splatting = h->mip_splatting;
+    d.has_kernel_size = h->has_kernel_size;
+    d.kernel_size = h->kernel_size;
+    d.has_background_color = h->has_background_color;
+    std::memcpy(d.background_color, h->background_color, sizeof d.background_color);
+    rc = ws_pointcloud_create(ctx, &d, out);
+    ws_ply_free(h);
+    return rc;
 }

@@ -107,6 +107,16 @@ class ws_npz_cloud(C.Structure):
                 ("has_background_color", C.c_int32), ("background_color", C.c_float * 3)]
 
 
+class ws_ply_cloud(C.Structure):
+    _fields_ = [("num_points", C.c_uint32), ("sh_deg", C.c_uint32),
+                ("gaussians", C.c_void_p), ("gaussians_bytes", C.c_size_t),
+                ("sh_coefs", C.c_void_p), ("sh_coefs_bytes", C.c_size_t),
+                ("bbox", ws_aabb), ("center", C.c_float * 3), ("has_up", C.c_int32), ("up", C.c_float * 3),
+                ("has_mip_splatting", C.c_int32), ("mip_splatting", C.c_int32),
+                ("has_kernel_size", C.c_int32), ("kernel_size", C.c_float),
+                ("has_background_color", C.c_int32), ("background_color", C.c_float * 3)]
+
+
 class ws_scene_camera(C.Structure):
     _fields_ = [("id", C.c_uint32), ("img_name", C.c_char * 128), ("width", C.c_uint32), ("height", C.c_uint32),
                 ("position", C.c_float * 3), ("rotation", C.c_float * 9), ("fx", C.c_float), ("fy", C.c_float),
@@ -161,6 +171,8 @@ SIGNATURES = {
     "ws_pointcloud_stats": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(ws_aabb), C.POINTER(ws_aabb), _f32p,
                                       C.POINTER(C.c_int32), _f32p]),
     "ws_pointcloud_load_ply": (C.c_int, [_P, C.c_char_p, _PP]),
+    "ws_ply_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(ws_ply_cloud))]),
+    "ws_ply_free": (None, [C.POINTER(ws_ply_cloud)]),
     "ws_npz_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(ws_npz_cloud))]),
     "ws_npz_free": (None, [C.POINTER(ws_npz_cloud)]),
     "ws_pointcloud_load_npz": (C.c_int, [_P, C.c_char_p, _PP]),

@@ -229,6 +229,24 @@ class GenericGaussianPointCloud:
         return GenericGaussianPointCloud(g, s, sh_deg, n, aabb, center, up=up, **meta)
 
 
+def read_ply(path: str) -> GenericGaussianPointCloud:
+    """io/ply.rs:28-196 PlyReader::read + io/mod.rs:63-105 through the library's host-side reader (no GPU)."""
+    pp = C.POINTER(L.ws_ply_cloud)()
+    check(lib.ws_ply_read(str(path).encode(), C.byref(pp)))
+    try:
+        c = pp.contents
+        g = np.ctypeslib.as_array((C.c_uint8 * c.gaussians_bytes).from_address(c.gaussians)).copy().reshape(-1, 28)
+        sh = np.ctypeslib.as_array((C.c_uint8 * c.sh_coefs_bytes).from_address(c.sh_coefs)).copy().reshape(-1, 96)
+        return GenericGaussianPointCloud(
+            g, sh, int(c.sh_deg), int(c.num_points), Aabb(list(c.bbox.min), list(c.bbox.max)), list(c.center),
+            up=list(c.up) if c.has_up else None,
+            kernel_size=c.kernel_size if c.has_kernel_size else None,
+            mip_splatting=bool(c.mip_splatting) if c.has_mip_splatting else None,
+            background_color=list(c.background_color) if c.has_background_color else None)
+    finally:
+        lib.ws_ply_free(pp)
+
+
 def read_npz(path: str) -> GenericGaussianPointCloud:
     """io/npz.rs:59-225 NpzReader::read + io/mod.rs:107-150 new_compressed, through the library's native reader."""
     pp = C.POINTER(L.ws_npz_cloud)()
