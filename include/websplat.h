@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 1
+#define WS_ABI_VERSION 2
 
 typedef enum ws_status {
     WS_OK = 0,
@@ -285,6 +285,12 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
 /* GaussianRenderer::num_visible_points (syncs) */
 int ws_renderer_num_visible(ws_renderer* r, uint32_t* out);
 int ws_renderer_frame_stats(ws_renderer* r, ws_frame_stats* out); /* syncs */
+/* Error bits of EVERY frame this renderer drew since creation / the last reset (syncs): bit 0 = the (tile, splat)
+ * entry list overflowed its capacity (entries_needed = what the last frame would have needed), bits 1..3 = a
+ * look-back spin timed out.  The reference has no counterpart: wgpu validates sizes up front and the ROPs cannot
+ * overflow; here the binned entry list can, and a caller that enqueues frames back to back (bin/measure.rs:98-153)
+ * checks once after its wait. */
+int ws_renderer_errors(ws_renderer* r, uint32_t* bits, uint32_t* entries_needed, int reset);
 /* GPUStopwatch::take_measurements for the last frame (syncs); needs ws_renderer_enable_timers(r,1) */
 /* enable: 0 = off, 1 = the four stage labels, 2 = additionally one HIP event pair per kernel launch */
 int ws_renderer_enable_timers(ws_renderer* r, int enable);
@@ -384,6 +390,7 @@ uint32_t ws_view_batch_frames_in_flight(const ws_view_batch* b);
 int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_splatting_args* views, uint32_t num_views,
                          void* const* d_targets, size_t row_pitch_bytes, const float background[4]);
 int ws_view_batch_sync(ws_view_batch* b);
+int ws_view_batch_errors(ws_view_batch* b, uint32_t* bits, int reset); /* OR of ws_renderer_errors over the slots (syncs) */
 ws_renderer* ws_view_batch_renderer(ws_view_batch* b, uint32_t slot); /* the renderer of a slot (stats, timers) */
 
 /* Display::render (renderer.rs:548-582) + display.wgsl:37-55: the splat image (premultiplied RGBA, renderer

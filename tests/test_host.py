@@ -24,7 +24,7 @@ def test_abi_exports_every_declared_symbol(ws):
     assert not missing, f"declared in websplat.h but not exported: {missing}"
     unbound = sorted(declared - set(_lib.SIGNATURES))
     assert not unbound, f"declared in websplat.h but not bound by the Python stub: {unbound}"
-    assert ws.lib.ws_abi_version() == 1
+    assert ws.lib.ws_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure(ws):

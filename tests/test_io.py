@@ -86,6 +86,84 @@ def test_npz_reader_errors(ws, tmp_path):
         ws.read_npz(str(tmp_path / "nope.npz"))
 
 
+def _npy_member(header: str, payload: bytes = b"") -> bytes:
+    """A version-1 .npy member with a hand-written header dict (what np.save would never emit)."""
+    h = header.encode()
+    pad = (64 - (10 + len(h) + 1) % 64) % 64
+    h = h + b" " * pad + b"\n"
+    return b"\x93NUMPY\x01\x00" + len(h).to_bytes(2, "little") + h + payload
+
+
+def test_npz_reader_crafted_headers(ws, tmp_path):
+    """Archives whose .npy headers or ZIP64 records overflow 64-bit size arithmetic must come back as errors, not as
+    out-of-bounds reads or C++ exceptions across the ABI (each of these crashed or aborted an earlier build)."""
+    import zipfile
+    a = synth.c3dgs_arrays(n=300, n_geometry=20, n_sh=20, seed=2, sh_deg=1)
+    base = str(tmp_path / "base.npz")
+    synth.write_npz(base, a, compressed=False)
+
+    def rewrite(name, member_bytes, out):
+        with zipfile.ZipFile(base) as zin, zipfile.ZipFile(out, "w", zipfile.ZIP_STORED) as zout:
+            for it in zin.infolist():
+                zout.writestr(it.filename, member_bytes if it.filename == name + ".npy" else zin.read(it.filename))
+
+    crafted = {
+        # count() * item wraps to 0: the length check passed and elem_i32 read out of bounds
+        "wrap_to_zero": ("gaussian_indices", _npy_member("{'descr': '<i8', 'fortran_order': False, 'shape': (2305843009213693952,), }")),
+        # 'fortran_order': with no value -> std::out_of_range from compare()
+        "fortran_novalue": ("xyz", _npy_member("{'descr': '<f2', 'shape': (300, 3), 'fortran_order':")),
+        # hoff + hlen + bytes wraps, assign() threw length_error
+        "huge_dim": ("opacity", _npy_member("{'descr': '|i1', 'fortran_order': False, 'shape': (18446744073709551615,), }")),
+        "two_dims_overflow": ("scaling", _npy_member("{'descr': '|i1', 'fortran_order': False, 'shape': (4294967296, 4294967296), }")),
+        "no_colon": ("rotation", _npy_member("{'descr' '|i1', 'shape' (20, 4)}")),
+    }
+    for tag, (name, blob) in crafted.items():
+        out = str(tmp_path / f"{tag}.npz")
+        rewrite(name, blob, out)
+        with pytest.raises(ws.WebSplatError):
+            ws.read_npz(out)
+
+    # ZIP64 end record whose offsets wrap: locator -> z near 2^64, central directory offset + size wrapping
+    raw = bytearray(open(base, "rb").read())
+    eocd = raw.rfind(b"PK\x05\x06")
+    for cd_off, cd_size, z in ((2**64 - 8, 16, None), (16, 2**64 - 8, None), (0, 0, 2**64 - 40)):
+        z64 = (b"PK\x06\x06" + (44).to_bytes(8, "little") + b"\x2d\x00\x2d\x00" + bytes(8) + (1).to_bytes(8, "little") +
+               (1).to_bytes(8, "little") + cd_size.to_bytes(8, "little") + cd_off.to_bytes(8, "little"))
+        zpos = eocd if z is None else z
+        loc = b"PK\x06\x07" + bytes(4) + zpos.to_bytes(8, "little") + (1).to_bytes(4, "little")
+        tail = bytearray(raw[eocd:eocd + 22])
+        tail[10:12] = b"\xff\xff"
+        tail[12:16] = b"\xff\xff\xff\xff"
+        tail[16:20] = b"\xff\xff\xff\xff"
+        out = str(tmp_path / "z64.npz")
+        open(out, "wb").write(bytes(raw[:eocd]) + z64 + loc + bytes(tail))
+        with pytest.raises(ws.WebSplatError):
+            ws.read_npz(out)
+    # a member whose local header offset / compressed size point outside the file
+    for field, val in ((42, 0xFFFFFFF0), (20, 0x7FFFFFFF)):
+        bad = bytearray(raw)
+        cd = bad.find(b"PK\x01\x02")
+        bad[cd + field:cd + field + 4] = val.to_bytes(4, "little")
+        out = str(tmp_path / "off.npz")
+        open(out, "wb").write(bytes(bad))
+        with pytest.raises(ws.WebSplatError):
+            ws.read_npz(out)
+
+
+def test_compressed_layout_follows_the_point_cloud(ws):
+    """The int8 SH record stride is the POINT CLOUD's (3 * (deg + 1)^2 bytes); a degree-1 c3dgs cloud drawn by a
+    default (degree-3) renderer must not be read with 48-byte records.  Host-side check only: prepare() on a renderer
+    of lower degree is refused, of higher degree accepted (the GPU test renders it)."""
+    # (the refusal itself needs a device; here: the descriptor the loader builds carries the cloud's own degree)
+    a = synth.c3dgs_arrays(n=200, n_geometry=10, n_sh=10, seed=4, sh_deg=1)
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "d1.npz")
+        synth.write_npz(p, a)
+        g = ws.read_npz(p)
+    assert g.sh_deg == 1 and g.sh_coefs.size == 10 * 3 * 4
+
+
 def _cams_json(n=19, seed=3):
     rng = np.random.default_rng(seed)
     cams = [c.to_json() for c in synth.orbit_cameras(n, 640, 480, 500.0, 510.0)]
@@ -279,10 +357,16 @@ def test_ply_reader_errors(ws, tmp_path):
     expect(raw[:head_end - len(b"end_header\n")], "end_header")
     expect(raw[:-40], "truncated")
     expect(raw.replace(b"binary_little_endian", b"ascii"), "ascii")
-    expect(raw.replace(b"element vertex 100", b"element vertex 4000000000"), "truncated")     # header lies about N
+    expect(raw.replace(b"element vertex 100", b"element vertex 400000000"), "truncated")      # header lies about N
+    expect(raw.replace(b"element vertex 100", b"element vertex 4000000000"), "2\\^30")          # must not be truncated to u32
+    expect(raw.replace(b"element vertex 100", b"element vertex 4294967297"), "2\\^30")          # 2^32 + 1 is not "1 vertex"
     expect(raw.replace(b"property float f_rest_44\n", b""), "sh degree|layout")
     expect(raw.replace(b"property float opacity", b"property double opacity"), "sh degree|layout")
-    expect(raw.replace(b"element vertex 100", b"element vertex 0"), "layout")
+    # zero vertices: the reference's reader loops zero times and succeeds (io/ply.rs:164-196); bbox zeroed, centre 0/0
+    q0 = str(tmp_path / "empty.ply")
+    open(q0, "wb").write(raw[:head_end].replace(b"element vertex 100", b"element vertex 0"))
+    empty = ws.read_ply(q0)
+    assert empty.num_points == 0 and np.isnan(np.asarray(empty.center)).all()
     with pytest.raises(ws.WebSplatError, match="cannot open"):
         ws.read_ply(str(tmp_path / "nope.ply"))
     q = str(tmp_path / "mip.ply")
@@ -291,6 +375,14 @@ def test_ply_reader_errors(ws, tmp_path):
         ws.read_ply(q)
     synth.write_ply(q, rows, 3, comments=["background_color=red"])       # only warned about in the reference
     assert ws.read_ply(q).background_color is None
+    for junk in ("kernel_size=abc", "kernel_size=", "kernel_size= 0.3", "kernel_size=0.3x"):   # parse::<f32>()? fails
+        synth.write_ply(q, rows, 3, comments=[junk])
+        with pytest.raises(ws.WebSplatError, match="kernel_size"):
+            ws.read_ply(q)
+    synth.write_ply(q, rows, 3, comments=["kernel_size=0.25"])
+    assert ws.read_ply(q).kernel_size == 0.25
+    with pytest.raises(ValueError, match="rows of"):                      # row length must fit the SH degree
+        ws.GenericGaussianPointCloud.from_ply_rows(rows[:, :50], 3)
 
 
 @settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])

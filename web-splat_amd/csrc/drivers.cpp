@@ -133,8 +133,22 @@ int ws_render_views(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* sc
         }
         ws_splatting_args a;
         offline_args(cams[i], pc, w, h, &a);
-        if ((rc = ws_renderer_prepare(r, pc, &a, nullptr))) break;
-        if ((rc = ws_renderer_render(r, pc, clear, target, (size_t)w * 8, nullptr))) break;
+        // Entries are emitted far -> near and truncated at the capacity, so an overflowing frame would silently lose
+        // its NEAREST splats: render, look at the frame's error bits, grow the entry list and render again if needed.
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            if ((rc = ws_renderer_prepare(r, pc, &a, nullptr))) break;
+            if ((rc = ws_renderer_render(r, pc, clear, target, (size_t)w * 8, nullptr))) break;
+            uint32_t bits = 0, needed = 0;
+            if ((rc = ws_renderer_errors(r, &bits, &needed, 1))) break;
+            if (bits == 0) break;
+            if ((bits & ~1u) != 0 || attempt == 2) {
+                rc = fail(WS_ERR_OVERFLOW, "ws_render_views: the frame reported device-side errors (tile-entry overflow or a "
+                                           "look-back time-out)");
+                break;
+            }
+            ws_renderer_set_tile_entry_capacity(r, (uint64_t)needed + needed / 4 + 4096);
+        }
+        if (rc) break;
         rgba.resize((size_t)w * h * 4);
         if ((rc = ws_download_texture_rgba8(ctx, target, WS_FORMAT_RGBA16_FLOAT, w, h, (size_t)w * 8, rgba.data(), nullptr))) break;
         char name[32];
@@ -186,6 +200,11 @@ int ws_measure(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, 
         if (rc == WS_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(WS_ERR_HIP, "ws_measure: device sync failed");  // device.poll(Wait)
         const float secs = std::chrono::duration<float>(std::chrono::steady_clock::now() - start).count();
         if (rc == WS_OK) *fps = 1.0f / (secs / ((float)n * (float)num_samples));
+        for (uint32_t k = 0; k < frames_in_flight && rc == WS_OK; ++k) {  // a rate over frames that dropped entries is not a rate
+            uint32_t bits = 0;
+            rc = ws_renderer_errors(rs[k], &bits, nullptr, 0);
+            if (rc == WS_OK && bits) rc = fail(WS_ERR_OVERFLOW, "ws_measure: frames reported device-side errors (tile-entry overflow or a look-back time-out)");
+        }
     }
     for (uint32_t k = 0; k < frames_in_flight; ++k) {
         if (rs[k]) ws_renderer_destroy(rs[k]);
@@ -267,6 +286,18 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
 int ws_view_batch_sync(ws_view_batch* b) {
     if (!b) return fail(WS_ERR_INVALID, "ws_view_batch_sync: null batch");
     for (hipStream_t s : b->streams) WS_HIP(hipStreamSynchronize(s));
+    return WS_OK;
+}
+
+int ws_view_batch_errors(ws_view_batch* b, uint32_t* bits, int reset) {
+    if (!b || !bits) return fail(WS_ERR_INVALID, "ws_view_batch_errors: null argument");
+    *bits = 0;
+    for (ws_renderer* r : b->renderers) {
+        uint32_t one = 0;
+        int rc = ws_renderer_errors(r, &one, nullptr, reset);
+        if (rc) return rc;
+        *bits |= one;
+    }
     return WS_OK;
 }
 

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,8 @@ struct NpyArray {
     bool little = true;
     std::vector<uint64_t> shape;
     std::vector<uint8_t> data;  // raw element bytes (C order)
+    // product of the dimensions; npy_parse() rejects headers whose product (times the item size) overflows or
+    // exceeds the member, so this never wraps for an array that was returned to a caller
     size_t count() const {
         size_t n = 1;
         for (uint64_t s : shape) n *= (size_t)s;
@@ -67,15 +70,16 @@ int zip_directory(const std::vector<uint8_t>& f, std::vector<ZipMember>* out) {
         // ZIP64: locator (PK\6\7) sits right before the EOCD and points at the zip64 EOCD record (PK\6\6)
         if (eocd < 20 || rd32(&f[eocd - 20]) != 0x07064b50u) return fail(WS_ERR_IO, "npz: zip64 locator missing");
         const uint64_t z = rd64(&f[eocd - 20 + 8]);
-        if (z + 56 > n || rd32(&f[z]) != 0x06064b50u) return fail(WS_ERR_IO, "npz: zip64 end record missing");
+        if (z > n || n - z < 56 || rd32(&f[z]) != 0x06064b50u) return fail(WS_ERR_IO, "npz: zip64 end record missing");
         entries = rd64(&f[z + 32]);
         cd_size = rd64(&f[z + 40]);
         cd_off = rd64(&f[z + 48]);
     }
-    if (cd_off + cd_size > n) return fail(WS_ERR_IO, "npz: central directory out of bounds");
+    if (cd_off > n || cd_size > n - cd_off) return fail(WS_ERR_IO, "npz: central directory out of bounds");
+    if (entries > cd_size / 46) return fail(WS_ERR_IO, "npz: central directory entry count does not fit its size");
     size_t p = (size_t)cd_off;
     for (uint64_t e = 0; e < entries; ++e) {
-        if (p + 46 > n || rd32(&f[p]) != 0x02014b50u) return fail(WS_ERR_IO, "npz: bad central directory entry");
+        if (p > n || n - p < 46 || rd32(&f[p]) != 0x02014b50u) return fail(WS_ERR_IO, "npz: bad central directory entry");
         ZipMember m;
         m.method = rd16(&f[p + 10]);
         m.crc = rd32(&f[p + 16]);
@@ -83,13 +87,14 @@ int zip_directory(const std::vector<uint8_t>& f, std::vector<ZipMember>* out) {
         m.usize = rd32(&f[p + 24]);
         const uint16_t nlen = rd16(&f[p + 28]), xlen = rd16(&f[p + 30]), clen = rd16(&f[p + 32]);
         m.local_off = rd32(&f[p + 42]);
-        if (p + 46 + nlen + xlen + clen > n) return fail(WS_ERR_IO, "npz: central directory entry out of bounds");
+        if ((size_t)nlen + xlen + clen > n - p - 46) return fail(WS_ERR_IO, "npz: central directory entry out of bounds");
         m.name.assign(reinterpret_cast<const char*>(&f[p + 46]), nlen);
         // zip64 extended information (header id 1): the fields that overflowed, in this fixed order
         size_t x = p + 46 + nlen;
         const size_t xend = x + xlen;
         while (x + 4 <= xend) {
             const uint16_t id = rd16(&f[x]), sz = rd16(&f[x + 2]);
+            if ((size_t)sz > xend - x - 4) break;  // a field that runs past the extra area: ignore the rest
             if (id == 1) {
                 size_t q = x + 4;
                 if (m.usize == 0xFFFFFFFFu && q + 8 <= xend) { m.usize = rd64(&f[q]); q += 8; }
@@ -106,9 +111,12 @@ int zip_directory(const std::vector<uint8_t>& f, std::vector<ZipMember>* out) {
 
 int zip_extract(const std::vector<uint8_t>& f, const ZipMember& m, std::vector<uint8_t>* out) {
     const size_t n = f.size();
-    if (m.local_off + 30 > n || rd32(&f[m.local_off]) != 0x04034b50u) return fail(WS_ERR_IO, "npz: bad local header of " + m.name);
+    if (m.local_off > n || n - m.local_off < 30 || rd32(&f[m.local_off]) != 0x04034b50u)
+        return fail(WS_ERR_IO, "npz: bad local header of " + m.name);
     const size_t data = (size_t)m.local_off + 30 + rd16(&f[m.local_off + 26]) + rd16(&f[m.local_off + 28]);
-    if (data + m.csize > n) return fail(WS_ERR_IO, "npz: member data out of bounds: " + m.name);
+    if (data > n || m.csize > n - data) return fail(WS_ERR_IO, "npz: member data out of bounds: " + m.name);
+    // a DEFLATE stream expands at most 1032:1; anything larger is a forged size, not a big array
+    if (m.usize > (1ull << 40) || (m.method == 8 && m.usize / 1032 > m.csize + 1)) return fail(WS_ERR_IO, "npz: implausible member size: " + m.name);
     try {
         out->resize((size_t)m.usize);
     } catch (...) {
@@ -161,12 +169,13 @@ int npy_parse(const std::vector<uint8_t>& b, const std::string& name, NpyArray* 
     } else {
         return fail(WS_ERR_UNSUPPORTED, "npz: unknown .npy version in " + name);
     }
-    if (hoff + hlen > b.size()) return fail(WS_ERR_IO, "npz: truncated npy header in " + name);
+    if (hlen > b.size() - hoff) return fail(WS_ERR_IO, "npz: truncated npy header in " + name);
     const std::string h(reinterpret_cast<const char*>(&b[hoff]), hlen);
     auto value_after = [&](const char* key) -> size_t {
         const size_t k = h.find(key);
         if (k == std::string::npos) return std::string::npos;
-        return h.find(':', k) + 1;
+        const size_t c = h.find(':', k);
+        return c == std::string::npos ? std::string::npos : c + 1;
     };
     size_t p = value_after("'descr'");
     if (p == std::string::npos) return fail(WS_ERR_IO, "npz: descr missing in " + name);
@@ -185,8 +194,11 @@ int npy_parse(const std::vector<uint8_t>& b, const std::string& name, NpyArray* 
     if (!(a->kind == 'f' || a->kind == 'i' || a->kind == 'u' || a->kind == 'b') || a->item < 1 || a->item > 8)
         return fail(WS_ERR_UNSUPPORTED, "npz: dtype '" + descr + "' of " + name);
     p = value_after("'fortran_order'");
-    if (p != std::string::npos && h.compare(h.find_first_not_of(' ', p), 4, "True") == 0)
-        return fail(WS_ERR_UNSUPPORTED, "npz: fortran-ordered array " + name);
+    if (p != std::string::npos) {
+        const size_t v = h.find_first_not_of(' ', p);
+        if (v == std::string::npos) return fail(WS_ERR_IO, "npz: fortran_order without a value in " + name);
+        if (h.compare(v, 4, "True") == 0) return fail(WS_ERR_UNSUPPORTED, "npz: fortran-ordered array " + name);
+    }
     p = value_after("'shape'");
     if (p == std::string::npos) return fail(WS_ERR_IO, "npz: shape missing in " + name);
     const size_t s0 = h.find('(', p), s1 = h.find(')', s0);
@@ -198,8 +210,19 @@ int npy_parse(const std::vector<uint8_t>& b, const std::string& name, NpyArray* 
         a->shape.push_back(std::strtoull(h.c_str() + i, nullptr, 10));
         while (i < s1 && h[i] != ',') ++i;
     }
-    const size_t bytes = a->count() * (size_t)a->item;
-    if (hoff + hlen + bytes > b.size()) return fail(WS_ERR_IO, "npz: truncated data in " + name);
+    // element count and byte size with overflow checks: no dimension may exceed what the member can hold
+    const size_t avail = b.size() - hoff - hlen;
+    size_t bytes = (size_t)a->item;
+    bool empty = false;
+    for (uint64_t dim : a->shape) empty = empty || dim == 0;  // e.g. features_rest of a degree-0 cloud: (n, 0, 3)
+    if (empty) bytes = 0;
+    for (uint64_t dim : a->shape) {
+        if (empty) break;
+        if (dim > avail || __builtin_mul_overflow(bytes, (size_t)dim, &bytes) || bytes > avail) {
+            a->shape.clear();
+            return fail(WS_ERR_IO, "npz: truncated data in " + name);
+        }
+    }
     a->data.assign(b.begin() + hoff + hlen, b.begin() + hoff + hlen + bytes);
     if (!a->little && a->item > 1)
         for (size_t i = 0; i < bytes; i += a->item)
@@ -319,9 +342,7 @@ struct ws_npz_cloud_impl {
 
 extern "C" {
 
-int ws_npz_read(const char* path, ws_npz_cloud** out) {
-    if (!path || !out) return fail(WS_ERR_INVALID, "ws_npz_read: null argument");
-    *out = nullptr;
+static int npz_read_impl(const char* path, ws_npz_cloud** out) {
     Npz z;
     int rc = npz_open(path, &z);
     if (rc) return rc;
@@ -340,12 +361,15 @@ int ws_npz_read(const char* path, ws_npz_cloud** out) {
     }
     auto* impl = new (std::nothrow) ws_npz_cloud_impl();
     if (!impl) return fail(WS_ERR_OOM, "ws_npz_read: host allocation failed");
+    struct Guard {  // frees the cloud on every early exit, exceptions included; released on success
+        ws_npz_cloud_impl* p;
+        ~Guard() { delete p; }
+    } guard{impl};
     ws_npz_cloud& pc = impl->pub;
     std::memset(&pc, 0, sizeof pc);
 #define NPZ_TRY(expr)        \
     do {                     \
         if ((rc = (expr))) { \
-            delete impl;     \
             return rc;       \
         }                    \
     } while (0)
@@ -360,7 +384,6 @@ int ws_npz_read(const char* path, ws_npz_cloud** out) {
         NpyArray bg;
         NPZ_TRY(z.get("background_color", &bg));
         if (bg.count() != 3) {
-            delete impl;
             return fail(WS_ERR_IO, "npz: background_color must have 3 elements");
         }
         pc.has_background_color = 1;
@@ -392,7 +415,6 @@ int ws_npz_read(const char* path, ws_npz_cloud** out) {
     NpyArray xyz, scaling, rotation, opacity, features_dc, fidx, gidx;
     NPZ_TRY(z.get("xyz", &xyz));
     if (xyz.kind != 'f' || xyz.count() % 3 != 0) {
-        delete impl;
         return fail(WS_ERR_IO, "npz: xyz must be a float array of 3-vectors");
     }
     NPZ_TRY(z.get("scaling", &scaling));
@@ -404,7 +426,6 @@ int ws_npz_read(const char* path, ws_npz_cloud** out) {
     NPZ_TRY(z.get("features_dc", &features_dc));
     NPZ_TRY(expect_i8(features_dc, "features_dc"));
     if (features_rest.data.empty() && !z.has("features_rest")) {
-        delete impl;
         return fail(WS_ERR_IO, "npz: array features_rest missing");  // try_get_npz_array, npz.rs:152
     }
     NPZ_TRY(expect_i8(features_rest, "features_rest"));
@@ -420,7 +441,6 @@ int ws_npz_read(const char* path, ws_npz_cloud** out) {
     if (num_points == 0 || num_points >= (1u << 30) || opacity.count() < num_points || scaling.count() / 3 < n_geo ||
         features_rest.count() < n_sh * rest_len || (has_sf && scaling_factor.count() < num_points) ||
         (has_fidx && fidx.count() < num_points) || (has_gidx && gidx.count() < num_points)) {
-        delete impl;
         return fail(WS_ERR_IO, "npz: array lengths are inconsistent");
     }
     try {
@@ -428,7 +448,6 @@ int ws_npz_read(const char* path, ws_npz_cloud** out) {
         impl->sh.resize(n_sh * ncoef * 3);
         impl->covars.resize(n_geo * 12);
     } catch (...) {
-        delete impl;
         return fail(WS_ERR_OOM, "ws_npz_read: host allocation failed");
     }
     // GaussianCompressed (pointcloud.rs:14-22): xyz f32 x3, opacity i8, scale_factor i8, pad, geometry_idx, sh_idx
@@ -492,8 +511,23 @@ int ws_npz_read(const char* path, ws_npz_cloud** out) {
     pc.quantization.color_rest = {rest_zp, rest_scale, {0, 0}};
     pc.quantization.opacity = {opacity_zp, opacity_scale, {0, 0}};
     pc.quantization.scaling_factor = {sf_zp, sf_scale, {0, 0}};
+    guard.p = nullptr;
     *out = &impl->pub;
     return WS_OK;
+}
+
+// No C++ exception may cross the C ABI: allocation failures and any std:: range error raised while picking a crafted
+// archive apart come back as error codes.
+int ws_npz_read(const char* path, ws_npz_cloud** out) {
+    if (!path || !out) return fail(WS_ERR_INVALID, "ws_npz_read: null argument");
+    *out = nullptr;
+    try {
+        return npz_read_impl(path, out);
+    } catch (const std::bad_alloc&) {
+        return fail(WS_ERR_OOM, "ws_npz_read: host allocation failed");
+    } catch (...) {
+        return fail(WS_ERR_IO, "ws_npz_read: malformed archive");
+    }
 }
 
 void ws_npz_free(ws_npz_cloud* pc) {

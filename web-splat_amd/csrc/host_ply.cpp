@@ -60,10 +60,14 @@ int parse_header(FILE* f, PlyHeader* h) {
             h->comments.push_back(line.substr(8));
         } else if (line.rfind("element ", 0) == 0) {
             char name[64];
-            unsigned long cnt = 0;
-            if (std::sscanf(line.c_str(), "element %63s %lu", name, &cnt) != 2) return fail(WS_ERR_IO, "ply: bad element line");
+            unsigned long long cnt = 0;
+            if (std::sscanf(line.c_str(), "element %63s %llu", name, &cnt) != 2) return fail(WS_ERR_IO, "ply: bad element line");
             in_vertex = std::strcmp(name, "vertex") == 0;
-            if (in_vertex) h->num_vertices = (uint32_t)cnt;
+            if (in_vertex) {
+                // the device side indexes Gaussians with 30 bits; a count that does not fit must not be truncated
+                if (cnt >= (1ull << 30)) return fail(WS_ERR_UNSUPPORTED, "ply: more than 2^30-1 vertices");
+                h->num_vertices = (uint32_t)cnt;
+            }
         } else if (line.rfind("property ", 0) == 0 && in_vertex) {
             char type[32], name[64];
             if (std::sscanf(line.c_str(), "property %31s %63s", type, name) != 2) return fail(WS_ERR_IO, "ply: bad property line");
@@ -92,9 +96,22 @@ struct ws_ply_cloud_impl {
     std::vector<uint8_t> gaussians, sh;
 };
 
+static int ply_read_impl(const char* path, ws_ply_cloud** out);
+
+// No C++ exception crosses the C ABI.
 extern "C" int ws_ply_read(const char* path, ws_ply_cloud** out) {
     if (!path || !out) return fail(WS_ERR_INVALID, "ws_ply_read: null argument");
     *out = nullptr;
+    try {
+        return ply_read_impl(path, out);
+    } catch (const std::bad_alloc&) {
+        return fail(WS_ERR_OOM, "ply: host allocation failed");
+    } catch (...) {
+        return fail(WS_ERR_IO, "ply: malformed file");
+    }
+}
+
+static int ply_read_impl(const char* path, ws_ply_cloud** out) {
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(WS_ERR_IO, std::string("ws_ply_read: cannot open ") + path);
     PlyHeader h;
@@ -112,7 +129,7 @@ extern "C" int ws_ply_read(const char* path, ws_ply_cloud** out) {
     }
     const uint32_t sh_deg = root - 1;
     const uint32_t row_len = 3 + 3 + 3 * ncoef + 1 + 3 + 4;
-    if (h.num_props != row_len || h.num_vertices == 0) {
+    if (h.num_props != row_len) {
         std::fclose(f);
         return fail(WS_ERR_IO, "ply: vertex layout is not the INRIA 3DGS layout (x,y,z,n*,f_dc*,f_rest*,opacity,scale*,rot*)");
     }
@@ -145,7 +162,8 @@ extern "C" int ws_ply_read(const char* path, ws_ply_cloud** out) {
     }
     if (!h.little_endian) {
         uint32_t* w = reinterpret_cast<uint32_t*>(rows.data());
-        for (size_t i = 0; i < rows.size(); ++i) w[i] = __builtin_bswap32(w[i]);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)rows.size(); ++i) w[i] = __builtin_bswap32(w[i]);
     }
     if ((rc = ws_ply_rows_convert(rows.data(), h.num_vertices, sh_deg, impl->gaussians.data(), impl->sh.data()))) {
         delete impl;
@@ -164,7 +182,13 @@ extern "C" int ws_ply_read(const char* path, ws_ply_cloud** out) {
     d.sh_coefs_bytes = impl->sh.size();
     ws_aabb zero;  // Aabb::zeroed(), io/mod.rs:74
     std::memset(&zero, 0, sizeof zero);
-    if ((rc = ws_pointcloud_stats(impl->gaussians.data(), h.num_vertices, 28, &zero, &d.bbox, d.center, &d.has_up, d.up))) {
+    if (h.num_vertices == 0) {
+        // The reference's reader accepts an empty vertex list (io/ply.rs:164-196 loops zero times): bbox stays
+        // Aabb::zeroed() and the centroid is 0/0 (io/mod.rs:74-84).  Such a cloud can be read, not uploaded
+        // (ws_pointcloud_create rejects it, as wgpu rejects zero-sized bindings).
+        d.bbox = zero;
+        d.center[0] = d.center[1] = d.center[2] = std::nanf("");
+    } else if ((rc = ws_pointcloud_stats(impl->gaussians.data(), h.num_vertices, 28, &zero, &d.bbox, d.center, &d.has_up, d.up))) {
         delete impl;
         return rc;
     }
@@ -177,9 +201,15 @@ extern "C" int ws_ply_read(const char* path, ws_ply_cloud** out) {
             return fail(WS_ERR_IO, "ply: bad mip comment");
         }
     }
-    if (comment_value(h, "kernel_size", &v)) {
+    if (comment_value(h, "kernel_size", &v)) {  // io/ply.rs:131-138: parse::<f32>()? -- junk is an error, not 0.0
+        char* end = nullptr;
+        const float ks = std::strtof(v.c_str(), &end);
+        if (v.empty() || v[0] == ' ' || v[0] == '\t' || end == v.c_str() || *end != 0) {
+            delete impl;
+            return fail(WS_ERR_IO, "ply: bad kernel_size comment");
+        }
         d.has_kernel_size = 1;
-        d.kernel_size = std::strtof(v.c_str(), nullptr);
+        d.kernel_size = ks;
     }
     if (comment_value(h, "background_color", &v)) {
         float c[3];

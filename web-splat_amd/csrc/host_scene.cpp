@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -224,9 +225,8 @@ bool png_chunk(FILE* f, const char type[4], const uint8_t* data, uint32_t len) {
 extern "C" {
 
 // Scene::from_json (scene.rs:140-154) on an in-memory document
-int ws_scene_from_json_text(const char* text, size_t len, ws_scene** out) {
-    if (!text || !out) return fail(WS_ERR_INVALID, "ws_scene_from_json_text: null argument");
-    *out = nullptr;
+static int scene_load_json_impl(const char* path, ws_scene** out);
+static int scene_from_json_text_impl(const char* text, size_t len, ws_scene** out) {
     JParser jp{text, text + len, {}};
     JValue root;
     if (!jp.parse(&root)) return fail(WS_ERR_IO, "cameras.json: " + jp.err);
@@ -242,6 +242,10 @@ int ws_scene_from_json_text(const char* text, size_t len, ws_scene** out) {
     }
     ws_scene* s = new (std::nothrow) ws_scene();
     if (!s) return fail(WS_ERR_OOM, "ws_scene_from_json_text: host allocation failed");
+    struct Guard {
+        ws_scene* p;
+        ~Guard() { delete p; }
+    } guard{s};
     // max_distance (scene.rs:189-201): O(n^2) over ALL cameras of the file, squared distances, one sqrt
     float max_d2 = 0.0f;
     for (size_t i = 0; i < cams.size(); ++i)
@@ -253,13 +257,37 @@ int ws_scene_from_json_text(const char* text, size_t len, ws_scene** out) {
         }
     s->extend = std::sqrt(max_d2);
     for (const ws_scene_camera& c : cams) s->cameras[c.id] = c;  // a later duplicate replaces the earlier one
+    guard.p = nullptr;
     *out = s;
     return WS_OK;
+}
+
+// No C++ exception crosses the C ABI (allocation failures while building the DOM of a huge or hostile file included).
+int ws_scene_from_json_text(const char* text, size_t len, ws_scene** out) {
+    if (!text || !out) return fail(WS_ERR_INVALID, "ws_scene_from_json_text: null argument");
+    *out = nullptr;
+    try {
+        return scene_from_json_text_impl(text, len, out);
+    } catch (const std::bad_alloc&) {
+        return fail(WS_ERR_OOM, "ws_scene_from_json_text: host allocation failed");
+    } catch (...) {
+        return fail(WS_ERR_IO, "cameras.json: malformed input");
+    }
 }
 
 int ws_scene_load_json(const char* path, ws_scene** out) {
     if (!path || !out) return fail(WS_ERR_INVALID, "ws_scene_load_json: null argument");
     *out = nullptr;
+    try {
+        return scene_load_json_impl(path, out);
+    } catch (const std::bad_alloc&) {
+        return fail(WS_ERR_OOM, "ws_scene_load_json: host allocation failed");
+    } catch (...) {
+        return fail(WS_ERR_IO, "ws_scene_load_json: malformed input");
+    }
+}
+
+static int scene_load_json_impl(const char* path, ws_scene** out) {
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(WS_ERR_IO, std::string("ws_scene_load_json: cannot open ") + path);
     std::string text;

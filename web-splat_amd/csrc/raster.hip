@@ -145,6 +145,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
             if (bid != 0) lb::st(status + bid, lb::pack(epoch, lb::FLAG_INCL, incl));
             if (bid == nblocks - 1) {
                 uint32_t d = incl;
+                counters->entries_needed = incl;
                 if (d > entry_cap) {
                     atomicOr(&counters->overflow, 1u);
                     d = entry_cap;
@@ -392,6 +393,13 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     __shared__ uint32_t s_txy[16];  // tx | ty << 16, or 0xFFFFFFFF for a slot outside the image
     __shared__ uint32_t s_dbg_max;  // capture mode: most records any wave walked in the current batch
 
+    // The frame's error bits (entry overflow, look-back spin time-outs) live in the per-frame zero arena; the last
+    // kernel of the frame folds them into a word that survives the next frame's memset, so a batch of frames enqueued
+    // back to back can be checked once at the end (ws_renderer_errors / ws_view_batch_errors).
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.sticky) {
+        const uint32_t bits = p.counters->overflow;
+        if (bits) atomicOr(p.sticky, bits);
+    }
     const BlendShape shape = blend_shape(QW, QH);
     const BlendBlock blk = blend_block_of(blockIdx.x, p.tiles_x, p.tiles_y, shape, tpw_log2);
     if (!blk.valid) return;  // block-uniform
@@ -594,6 +602,10 @@ template <int FORMAT>
 __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
     // blockIdx -> (tile, quadrant): workgroup b runs on XCD b % 8 (observed; used for locality only)
     const uint32_t b = blockIdx.x;
+    if (b == 0 && threadIdx.x == 0 && p.sticky) {  // as in k_blend
+        const uint32_t bits = p.counters->overflow;
+        if (bits) atomicOr(p.sticky, bits);
+    }
     const uint32_t xcd = b & 7u, j = b >> 3;
     const uint32_t nq = p.qw * p.qh;
     const uint32_t q = j % nq;

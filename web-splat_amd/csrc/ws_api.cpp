@@ -117,6 +117,7 @@ struct ws_renderer {
     FrameCounters* counters = nullptr;  // = &zero->counters
     SortScratch sort_depth, sort_tiles;
     uint32_t epoch = 0;
+    uint32_t* sticky = nullptr;      // device error word that survives the per-frame memset (ws_renderer_errors)
 
     // last prepared frame
     bool prepared = false;
@@ -260,6 +261,9 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     r->vw = vw;
     r->vh = vh;
     r->epoch = 0;  // fresh (zeroed) status arrays
+    // The allocation-time memsets above ran on the null stream; frames run on hipStreamNonBlocking streams, which are
+    // not ordered against it, and recycled memory may still hold a previous renderer's epoch-tagged words.
+    WS_HIP(hipDeviceSynchronize());
     return WS_OK;
 }
 
@@ -515,6 +519,11 @@ int ws_renderer_create(ws_context* ctx, ws_color_format format, uint32_t sh_deg,
             return fail(WS_ERR_HIP, "ws_renderer_create: hipEventCreate failed");
         }
     }
+    if (hipMalloc(reinterpret_cast<void**>(&r->sticky), sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(r->sticky, 0, sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        ws_renderer_destroy(r);
+        return fail(WS_ERR_HIP, "ws_renderer_create: error word allocation failed");
+    }
     *out = r;
     return WS_OK;
 }
@@ -523,6 +532,7 @@ void ws_renderer_destroy(ws_renderer* r) {
     if (!r) return;
     (void)hipDeviceSynchronize();
     renderer_free_scratch(r);
+    dfree(r->sticky);
     for (auto& e : r->ev)
         if (e) (void)hipEventDestroy(e);
     r->marks.destroy();
@@ -570,6 +580,8 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     }
     if (pc->compressed && args->max_sh_deg > r->sh_deg)
         return fail(WS_ERR_INVALID, "ws_renderer_prepare: max_sh_deg exceeds the renderer's SH layout degree");
+    if (pc->compressed && pc->sh_deg > r->sh_deg)
+        return fail(WS_ERR_INVALID, "ws_renderer_prepare: compressed point cloud has a higher SH degree than the renderer was created for");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     r->prepared = false;
     int rc = renderer_ensure_scratch(r, pc->num_points, args->viewport[0], args->viewport[1]);
@@ -581,7 +593,9 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     if ((rc = ws_build_settings_uniform(args, pc, &kp.rs))) return rc;
     kp.quant = pc->quant;
     kp.num_points = pc->num_points;
-    kp.sh_deg_layout = (r->sh_deg + 1) * (r->sh_deg + 1);
+    // stride of the packed int8 SH records: the POINT CLOUD's degree (the records were laid out by its loader); a
+    // renderer created for another degree must not re-interpret them (WebGPU would clamp the reads, HIP would not)
+    kp.sh_deg_layout = (pc->sh_deg + 1) * (pc->sh_deg + 1);
     kp.tiles_x = r->tiles_x;
     kp.tiles_y = r->tiles_y;
     kp.tile_w_log2 = r->ctx->tile_qw == 4 ? 5u : 4u;
@@ -741,6 +755,8 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.pitch = row_pitch_bytes;
     bp.format = (int)r->format;
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
+    bp.counters = r->counters;
+    bp.sticky = r->sticky;
     bp.debug_consumed = r->capture ? r->debug_consumed : nullptr;
     bp.debug_walked = r->capture ? r->debug_walked : nullptr;
     if (bp.debug_consumed) {
@@ -772,6 +788,18 @@ int ws_renderer_frame_stats(ws_renderer* r, ws_frame_stats* out) {
     out->num_tile_entries = fc.num_entries;
     out->tile_entries_capacity = r->entry_cap;
     out->overflow = fc.overflow;
+    return WS_OK;
+}
+
+int ws_renderer_errors(ws_renderer* r, uint32_t* bits, uint32_t* entries_needed, int reset) {
+    if (!r || !bits) return fail(WS_ERR_INVALID, "ws_renderer_errors: null argument");
+    *bits = 0;
+    if (entries_needed) *entries_needed = 0;
+    if (!r->prepared) return WS_OK;  // nothing rendered yet
+    WS_HIP(hipStreamSynchronize(r->last_stream));
+    WS_HIP(hipMemcpy(bits, r->sticky, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (entries_needed) WS_HIP(hipMemcpy(entries_needed, &r->counters->entries_needed, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (reset && *bits) WS_HIP(hipMemset(r->sticky, 0, sizeof(uint32_t)));
     return WS_OK;
 }
 
@@ -908,6 +936,7 @@ int ws_sorter_create(ws_context* ctx, uint32_t max_n, ws_sorter** out) {
     s->ctx = ctx;
     int rc = alloc_sort_scratch(s->sc, max_n, true, ctx->sort_algo == 1);
     if (rc == WS_OK) rc = dmalloc(&s->zero, 1);
+    if (rc == WS_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(WS_ERR_HIP, "ws_sorter_create: device sync failed");
     if (rc == WS_OK) {
         s->sc.tickets = s->zero->tickets;
         s->sc.error = &s->zero->error;

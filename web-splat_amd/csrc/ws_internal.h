@@ -42,7 +42,8 @@ struct FrameCounters {
     uint32_t overflow;       // bit 0: D exceeded capacity; bits 1..3: a look-back spin timed out (K1/bin/sort)
     uint32_t sort_ticket[8]; // per-pass tile dispensers: [0..3] depth sort, [4..7] tile sort
     uint32_t bin_ticket;     // block dispenser of the binning prefix kernel
-    uint32_t _pad[3];
+    uint32_t entries_needed; // D before clamping to the capacity (what a retry has to allocate)
+    uint32_t _pad[2];
 };
 static_assert(sizeof(FrameCounters) == 64, "FrameCounters layout");
 
@@ -192,6 +193,8 @@ struct BlendParams {
     size_t pitch;
     int format;
     int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
+    const FrameCounters* counters;  // this frame's counters: the error bits are folded into *sticky by the blend
+    uint32_t* sticky;           // per-renderer error word that is NOT zeroed per frame (ws_renderer_errors)
     uint32_t* debug_consumed;   // nullptr, or [tiles]: entries of each tile's list the blend walked (capture mode)
     uint32_t* debug_walked;     // nullptr, or [tiles][17]: records walked per wave, [16] = sum over batches of the per-batch maximum
 };

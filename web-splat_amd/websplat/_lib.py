@@ -194,6 +194,8 @@ SIGNATURES = {
     "ws_view_batch_frames_in_flight": (C.c_uint32, [_P]),
     "ws_view_batch_render": (C.c_int, [_P, _P, C.POINTER(ws_splatting_args), C.c_uint32, _PP, C.c_size_t, _f32p]),
     "ws_view_batch_sync": (C.c_int, [_P]),
+    "ws_view_batch_errors": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int]),
+    "ws_renderer_errors": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]),
     "ws_view_batch_renderer": (C.c_void_p, [_P, C.c_uint32]),
     "ws_display_composite": (C.c_int, [_P, _P, C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, _f32p, C.c_int, _P,
                                        C.c_size_t, _P]),

@@ -220,6 +220,9 @@ class GenericGaussianPointCloud:
     def from_ply_rows(rows: np.ndarray, sh_deg: int, **meta):
         """io/ply.rs:50-100 + io/mod.rs:63-105 through the library's host-side loader code."""
         rows = np.ascontiguousarray(rows, dtype=np.float32)
+        want = 14 + 3 * (int(sh_deg) + 1) ** 2  # x,y,z, n*, f_dc*, f_rest*, opacity, scale*, rot*  (io/ply.rs:54-88)
+        if rows.ndim != 2 or rows.shape[1] != want:
+            raise ValueError(f"from_ply_rows: sh_deg {sh_deg} needs rows of {want} floats, got shape {rows.shape}")
         n = rows.shape[0]
         g = np.empty((n, 28), dtype=np.uint8)
         s = np.empty((n, 96), dtype=np.uint8)
@@ -235,8 +238,11 @@ def read_ply(path: str) -> GenericGaussianPointCloud:
     check(lib.ws_ply_read(str(path).encode(), C.byref(pp)))
     try:
         c = pp.contents
-        g = np.ctypeslib.as_array((C.c_uint8 * c.gaussians_bytes).from_address(c.gaussians)).copy().reshape(-1, 28)
-        sh = np.ctypeslib.as_array((C.c_uint8 * c.sh_coefs_bytes).from_address(c.sh_coefs)).copy().reshape(-1, 96)
+        if c.num_points == 0:  # an empty vertex list reads fine in the reference too (it cannot be uploaded)
+            g, sh = np.empty((0, 28), np.uint8), np.empty((0, 96), np.uint8)
+        else:
+            g = np.ctypeslib.as_array((C.c_uint8 * c.gaussians_bytes).from_address(c.gaussians)).copy().reshape(-1, 28)
+            sh = np.ctypeslib.as_array((C.c_uint8 * c.sh_coefs_bytes).from_address(c.sh_coefs)).copy().reshape(-1, 96)
         return GenericGaussianPointCloud(
             g, sh, int(c.sh_deg), int(c.num_points), Aabb(list(c.bbox.min), list(c.bbox.max)), list(c.center),
             up=list(c.up) if c.has_up else None,
@@ -612,6 +618,12 @@ class GaussianRenderer:
         return {"num_visible": s.num_visible, "num_tile_entries": s.num_tile_entries,
                 "tile_entries_capacity": s.tile_entries_capacity, "overflow": s.overflow}
 
+    def errors(self, reset=False):
+        """(bits, entries_needed): error bits of every frame drawn since creation / the last reset (syncs)."""
+        bits, need = C.c_uint32(), C.c_uint32()
+        check(lib.ws_renderer_errors(self.handle, C.byref(bits), C.byref(need), int(bool(reset))))
+        return bits.value, need.value
+
     def stage_times(self):
         s = L.ws_stage_times()
         check(lib.ws_renderer_stage_times(self.handle, C.byref(s)))
@@ -668,6 +680,12 @@ class ViewBatch:
 
     def sync(self):
         check(lib.ws_view_batch_sync(self.handle))
+
+    def errors(self, reset=False):
+        """OR of the slots' sticky error bits (tile-entry overflow, look-back time-outs); syncs."""
+        bits = C.c_uint32()
+        check(lib.ws_view_batch_errors(self.handle, C.byref(bits), int(bool(reset))))
+        return bits.value
 
     def renderer(self, slot: int) -> "GaussianRenderer":
         """A non-owning view of slot's renderer (frame_stats, timers)."""
