@@ -11,19 +11,27 @@ end (throughput, not latency).  The views of a batch are independent, so `--stre
 flight per GPU, each on its own HIP stream with its own renderer scratch and target, sharing the resident scene;
 the one-frame-at-a-time rate is reported beside it (config.single_stream_fps).  The scene is replicated on every
 GPU and views are sharded view i -> rank i mod N (no data-path collective; "scaling": "weak": every rank
-renders K frames).
+renders K frames).  The only collective is the MAX all-reduce of the elapsed time after the timed region; it runs
+through RCCL also at N = 1 (a one-rank communicator), so the code path the 8-GPU run takes is exercised by every run.
 
 Workloads (BASELINE.json configs):
-  c2  (default) bonsai-like synthetic, 1.2 M Gaussians, 1200x799 -- configs[1]; the real bonsai .ply is not
-                on disk and cannot be downloaded, so the seeded stand-in of SURVEY 8(d) is used
-  hd1m          the north-star headline: same distribution, 1 M Gaussians, 1920x1080
-  c3            5 M Gaussians, 1920x1080 (sort stress)
-  c1            10 k Gaussians, 800x600
-  c5            compressed c3dgs .npz (native loader), 1 M Gaussians, 3840x2160
+  hd1m (default) the north-star headline: bonsai-like synthetic, 1 M Gaussians, 1920x1080
+  c2            bonsai-like synthetic, 1.2 M Gaussians, 1200x799 -- configs[1]; the real bonsai .ply is not on disk
+  bonsai        the REAL bonsai scene when WEBSPLAT_BONSAI_PLY (and optionally WEBSPLAT_BONSAI_CAMERAS) point at it,
+                1200x799 (README.md:55, the one number the reference publishes); without the asset: a clear message
+                and the c2 stand-in
+  c3            5 M Gaussians, 1920x1080 (sort stress) -- configs[2], the largest single-GPU configuration
+  c4            the c2 scene at 1920x1080, 64-view batch -- configs[3]
+  c5            compressed c3dgs .npz (native loader), 1 M Gaussians, 3840x2160 -- configs[4]
+  c1            10 k Gaussians, 800x600 -- configs[0]
+
+`--dry-run` (CPU, backend gloo; used by tests/test_shard.py with world size 2) runs the same sharding, planning,
+barrier and reduction code without a GPU: frames are not rendered and the line says so ("dry_run": true).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -39,9 +47,38 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
+WORKLOADS = ("hd1m", "c2", "bonsai", "c3", "c4", "c5", "c1")
+
 
 def build_workload(ws, name, n_views):
+    """-> (host point cloud, [SplattingArgs per view], (w, h), note)."""
     from websplat import synth
+    note = None
+    cams = None
+    rows = gpc = None
+    if name == "bonsai":
+        ply = os.environ.get("WEBSPLAT_BONSAI_PLY")
+        cams_json = os.environ.get("WEBSPLAT_BONSAI_CAMERAS")
+        if ply and os.path.exists(ply):
+            # the reference's own loading path: io/ply.rs (or io/npz.rs by magic bytes) + scene.rs cameras.json
+            w, h = 1200, 799
+            with open(ply, "rb") as f:
+                magic = f.read(4)
+            gpc = ws.read_npz(ply) if magic == b"PK\x03\x04" else ws.read_ply(ply)
+            if cams_json and os.path.exists(cams_json):
+                scene = ws.Scene.from_json(cams_json)
+                cams = scene.cameras("train")[:n_views] or scene.cameras(None)[:n_views]
+                scene.close()
+                note = f"real scene {os.path.basename(ply)}, {len(cams)} cameras of {os.path.basename(cams_json)}"
+            else:
+                r = float(np.linalg.norm(np.asarray(gpc.aabb.max) - np.asarray(gpc.aabb.min))) * 0.35
+                cams = synth.orbit_cameras(n_views, w, h, 1200.0, 1200.0, radius=max(r, 1.0), height_off=0.25 * max(r, 1.0))
+                note = f"real scene {os.path.basename(ply)}, synthetic orbit cameras (WEBSPLAT_BONSAI_CAMERAS not set)"
+        else:
+            print("[bench] workload 'bonsai': WEBSPLAT_BONSAI_PLY is not set or does not exist -- the asset is not on "
+                  "disk and cannot be downloaded here; falling back to the seeded bonsai-like stand-in (c2).", file=sys.stderr)
+            note = "WEBSPLAT_BONSAI_PLY not supplied: synthetic stand-in (same as c2)"
+            name = "c2"
     if name == "c2":
         rows, (w, h), f = synth.scene_c2(n=1_200_000, seed=1), (1200, 799), 1200.0
         cams = synth.orbit_cameras(n_views, w, h, f, f)
@@ -70,23 +107,24 @@ def build_workload(ws, name, n_views):
             synth.write_npz(path, a)
             gpc = ws.read_npz(path)
         cams = synth.orbit_cameras(n_views, w, h, 3000.0, 3000.0, radius=3.2, height_off=0.6)
-        rows = None
-    else:
-        raise SystemExit(f"unknown workload {name}")
+    elif name != "bonsai":
+        raise SystemExit(f"unknown workload {name} (one of {', '.join(WORKLOADS)})")
     if rows is not None:
         gpc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
     args = []
     for cj in cams:
         cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, cj.width, cj.height)
         cam.fit_near_far(gpc.aabb)
-        args.append(ws.SplattingArgs(camera=cam, viewport=(w, h), max_sh_deg=3))
-    return gpc, args, (w, h)
+        args.append(ws.SplattingArgs(camera=cam, viewport=(w, h), max_sh_deg=min(3, gpc.sh_deg)))
+    return gpc, args, (w, h), note
 
 
 def cpu_baseline(gpc, arg, viewport, budget_s=20.0):
     """The oracle (CPU restatement of the reference path) timed on this host's cores: a bounded sample of
     whole frames of the same workload.  Reported, never used by the product path."""
+    os.environ["WS_ORACLE_NATIVE"] = "1"  # -O3 -march=native copy built ON THIS HOST (never shipped between machines)
     import oracle_lib as oracle
+    flags = oracle.BUILD_FLAGS
     cam = oracle.make_camera(arg.camera.position, arg.camera.rotation, arg.camera.fovx, arg.camera.fovy,
                              arg.camera.znear, arg.camera.zfar, arg.camera.fov2view_ratio)
     w, h = viewport
@@ -115,7 +153,61 @@ def cpu_baseline(gpc, arg, viewport, budget_s=20.0):
             break
     return {"value": frames / dt, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
             "sample": f"{frames} whole frames (view 0) of the same workload, 1 warm-up, OpenMP over "
-                      f"{oracle.num_threads()} threads, oracle built -O2 -ffp-contract=off"}
+                      f"{oracle.num_threads()} threads, oracle built {flags}"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def init_distributed(a, torch):
+    """One process per GPU.  world > 1: torch.distributed.run supplies RANK / WORLD_SIZE / MASTER_*.  world == 1: a
+    one-rank communicator on 127.0.0.1 so that the RCCL initialisation, the barrier and the all-reduce below are the
+    same calls the N-GPU run makes.  Returns (dist or None, rank, local_rank, world, note)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    backend = "gloo" if a.dry_run else "nccl"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    if world == 1:
+        if a.no_dist:
+            return None, rank, local_rank, world, "disabled (--no-dist)"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    try:
+        kw = {} if a.dry_run else {"device_id": torch.device("cuda", local_rank)}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    except Exception as e:  # noqa: BLE001
+        if world > 1:
+            raise
+        return None, rank, local_rank, world, f"one-rank {backend} communicator failed to initialise: {e!r}"
+    return dist, rank, local_rank, world, f"{backend} communicator, world size {world}"
+
+
+class DryBatch:
+    """--dry-run: stands where the ViewBatch stands; frames cost a fixed sleep instead of GPU time."""
+    texel_bytes = 16
+
+    def __init__(self, per_frame_s):
+        self.per_frame_s = per_frame_s
+        self.frames = 0
+
+    def render(self, pc, views, ptrs, pitch):
+        self.frames += len(views)
+        time.sleep(self.per_frame_s * len(views))
+
+    def errors(self, reset=False):
+        return 0
+
+    def close(self):
+        pass
 
 
 def main():
@@ -123,45 +215,47 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--workload", default="hd1m", choices=WORKLOADS)
     ap.add_argument("--views", type=int, default=64)
     ap.add_argument("--format", default="rgba32float")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("WS_BENCH_STREAMS", "4")),
                     help="frames in flight per GPU: one renderer (private scratch) + one HIP stream each "
                          "(the views of a batch are independent; 1 = strictly one frame at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dist", action="store_true", help="skip the one-rank RCCL communicator at N = 1")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU only (backend gloo): sharding, planning, barrier and reduction without rendering")
     a = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
-    torch.cuda.set_device(local_rank)
+    dist, rank, local_rank, world, dist_note = init_distributed(a, torch)
+    dev = "cpu" if a.dry_run else "cuda"
+    if not a.dry_run:
+        torch.cuda.set_device(local_rank)
 
     import websplat as ws  # raises if the HIP library is not built: there is no fallback
-    ctx = ws.Context(local_rank)
-    gpc, views, viewport = build_workload(ws, a.workload, a.views)
-    pc = ws.PointCloud(ctx, gpc)
+    gpc, views, viewport, workload_note = build_workload(ws, a.workload, a.views)
     w, h = viewport
-    tdtype = {"rgba32float": torch.float32, "rgba16float": torch.float16, "rgba8unorm": torch.uint8}[a.format]
-    # A view batch (ws_view_batch_*): one renderer (private scratch) + one HIP stream per frame in flight, the scene
-    # is shared; one output image per slot (frame g of the batch's life runs on slot g % frames_in_flight).
     nstreams = max(1, a.streams)
-    batch = ws.ViewBatch(ctx, a.format, gpc.sh_deg, gpc.compressed, nstreams)
-    targets = [torch.empty((h, w, 4), dtype=tdtype, device="cuda") for _ in range(nstreams)]
-    pitch = w * batch.texel_bytes
     from websplat.shard import views_for_rank
-    my_views = [views[i] for i in views_for_rank(len(views), rank, world)] or views[:1]
+    view_ids = views_for_rank(len(views), rank, world)
+    my_views = [views[i] for i in view_ids] or views[:1]
     packed_all = ws.ViewBatch.pack_views(my_views)
+    if a.dry_run:
+        ctx = pc = r = None
+        batch = DryBatch(2e-4)
+        target_ptrs = [0x1000 * (k + 1) for k in range(nstreams)]
+        pitch = w * 16
+    else:
+        ctx = ws.Context(local_rank)
+        pc = ws.PointCloud(ctx, gpc)
+        tdtype = {"rgba32float": torch.float32, "rgba16float": torch.float16, "rgba8unorm": torch.uint8}[a.format]
+        # A view batch (ws_view_batch_*): one renderer (private scratch) + one HIP stream per frame in flight, the
+        # scene is shared; one output image per slot (frame g of the batch's life runs on slot g % frames_in_flight).
+        batch = ws.ViewBatch(ctx, a.format, gpc.sh_deg, gpc.compressed, nstreams)
+        targets = [torch.empty((h, w, 4), dtype=tdtype, device="cuda") for _ in range(nstreams)]
+        target_ptrs = [t.data_ptr() for t in targets]
+        pitch = w * batch.texel_bytes
     planned = [0]  # frames planned so far: frame g of the batch's life lands on slot g % frames_in_flight
 
     def plan(first_view, count):
@@ -172,35 +266,40 @@ def main():
         ptrs = (C.c_void_p * count)()
         for j in range(count):
             arr[j] = packed_all[(first_view + j) % len(my_views)]
-            ptrs[j] = targets[(planned[0] + j) % nstreams].data_ptr()
+            ptrs[j] = target_ptrs[(planned[0] + j) % nstreams]
         planned[0] += count
         return arr, ptrs
 
     def submit(p):
         batch.render(pc, p[0], p[1], pitch)  # enqueues every frame of the plan and returns
 
-    # one more renderer on the default stream: the one-frame-at-a-time rate and the per-kernel times (rank 0)
-    r = ws.GaussianRenderer(ctx, a.format, gpc.sh_deg, gpc.compressed)
-    target1 = targets[0]
-
-    def frame(i):
-        r.prepare(pc, my_views[i % len(my_views)])
-        r.render(pc, target_ptr=target1.data_ptr())
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+    def device_sync():
+        if not a.dry_run:
             torch.cuda.synchronize()
 
-    # Building the synthetic scene keeps the host busy for seconds while the GPU idles at low clocks: bring it to
-    # its steady-state clock with ~0.3 s of (untimed, uncounted) frames before the W warm-up steps.
-    t_pre = time.perf_counter()
-    i_pre = 0
-    while time.perf_counter() - t_pre < 0.3:
-        submit(plan(i_pre, 16))
-        i_pre += 16
-        torch.cuda.synchronize()
+    def barrier():
+        device_sync()
+        if dist is not None:
+            dist.barrier()
+            device_sync()
+
+    if not a.dry_run:
+        # one more renderer on the default stream: the one-frame-at-a-time rate and the per-kernel times (rank 0)
+        r = ws.GaussianRenderer(ctx, a.format, gpc.sh_deg, gpc.compressed)
+        target1 = targets[0]
+
+        def frame(i):
+            r.prepare(pc, my_views[i % len(my_views)])
+            r.render(pc, target_ptr=target1.data_ptr())
+
+        # Building the synthetic scene keeps the host busy for seconds while the GPU idles at low clocks: bring it to
+        # its steady-state clock with ~0.3 s of (untimed, uncounted) frames before the W warm-up steps.
+        t_pre = time.perf_counter()
+        i_pre = 0
+        while time.perf_counter() - t_pre < 0.3:
+            submit(plan(i_pre, 16))
+            i_pre += 16
+            torch.cuda.synchronize()
     if a.warmup:
         submit(plan(0, a.warmup))
     timed = plan(a.warmup, a.steps)
@@ -212,146 +311,173 @@ def main():
     elapsed = time.perf_counter() - t0
     if os.environ.get("WS_BENCH_DEBUG"):
         print(f"[bench debug] enqueue {t_enq * 1e3:.1f} ms, total {elapsed * 1e3:.1f} ms for {a.steps} frames", file=sys.stderr)
+    # every frame of the timed region (and of the warm-up) must have been drawn completely: the slots' sticky error
+    # words collect tile-entry overflow and look-back time-outs of ALL frames since the batch was created
+    err_bits = batch.errors()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(err_bits)], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # RCCL: the only collective, off the data path
-        elapsed = float(t.item())
+        elapsed, err_bits = float(t[0].item()), int(t[1].item())
+    if err_bits:
+        raise SystemExit(f"[bench] INVALID RUN: device-side error bits 0x{err_bits:x} in the timed frames (bit 0 = tile-entry "
+                         "list overflow: entries were dropped; bits 1-3 = look-back time-out) -- no result line is printed")
 
-    # ---- rank 0: single-stream rate, then per-kernel time (HIP events on the launch stream) for the roofline ----
     out = None
     if rank == 0:
-        torch.cuda.synchronize()
-        inflight = nstreams
-        ks = max(20, a.steps // 2)  # from here on: one frame at a time on renderer `r`, default stream
-        for i in range(5):
-            frame(i)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(ks):
-            frame(i)
-        torch.cuda.synchronize()
-        single_stream_fps = ks / (time.perf_counter() - t1)
-
-        r.enable_timers(2)  # HIP event pairs around every kernel launch, on the launch stream
-        reps = min(len(my_views), 16)
-        per_kernel = {}      # label -> [total ms over reps, launches over reps]
-        stage_acc = {"preprocess": 0.0, "sorting": 0.0, "binning": 0.0, "rasterization": 0.0}
-        stat_acc = {"num_visible": 0, "num_tile_entries": 0}
-        frame(0)
-        r.kernel_times()
-        for i in range(reps):
-            frame(i)
-            for label, ms in r.kernel_times():
-                e = per_kernel.setdefault(label, [0.0, 0])
-                e[0] += ms
-                e[1] += 1
-            st = r.stage_times()
-            fs = r.frame_stats()
-            for k in stage_acc:
-                stage_acc[k] += st[k] / reps
-            for k in stat_acc:
-                stat_acc[k] += fs[k] / reps
-        overflow = r.frame_stats()["overflow"]
-        r.enable_timers(0)
         n = gpc.num_points
-        V, D = stat_acc["num_visible"], stat_acc["num_tile_entries"]
-        tile_w, tile_h = ctx.tile_size()
-        tile_bits = 8
-        while (1 << tile_bits) < -(-w // tile_w) * -(-h // tile_h):
-            tile_bits += 8
-        tile_passes = tile_bits // 8
-        # ALGORITHMIC bytes per launch (DESIGN.md "Roofline accounting"): N Gaussians, V visible,
-        # D (tile, splat) entries.  A radix pass over M pairs reads and writes 8 B per pair: 16*M; the histogram
-        # kernels read 4*M; the last tile-id pass does not write the keys (12*D).
-        alg = {
-            # K1c: 24 B record for all, 12 B covariance + 3*(deg+1)^2 B SH gathers and 28 B out for survivors
-            "k_preprocess": n * 124 + V * 28,
-            "k_preprocess<compressed>": n * 24 + V * (12 + 3 * (gpc.sh_deg + 1) ** 2) + V * 28,
-            "depth:k_sort_tile_hist": 4 * V, "depth:k_sort_col_scan": None, "depth:k_sort_scatter": 16 * V,
-            "depth:k_sort_hist": 4 * V,
-            "k_bin_prefix": V * (4 + 8) + V * (8 + 4),
-            "k_bin_emit": V * 12 + D * 8,
-            "tiles:k_sort_tile_hist": 4 * D, "tiles:k_sort_col_scan": None, "tiles:k_sort_hist": 4 * D,
-            "tiles:k_sort_scatter": (16 * D * (tile_passes - 1) + 12 * D) / tile_passes,
-            "k_blend": D * 24 + w * h * 16,
-        }
-        # An event interval = event + dispatch overhead of a dependent launch + the kernel; rocprofv3 reports the kernel
-        # alone.  The library records one EMPTY launch per frame in the same way (after K1): its interval is subtracted.
-        # What an interval carries on top of the kernel is mostly the write-back of the PREVIOUS kernel's dirty L2 lines,
-        # so it varies (6 us after a memset, 12 us after K1's 30 MB of stores -- about what precedes the blend, for
-        # which the calibrated time matches rocprofv3 to 1 %); GBps_interval (nothing subtracted) is the lower bound.
-        # Launches shorter than twice the empty interval are below what events can resolve: no calibrated duration
-        # for them (their rocprofv3 durations are in profiles/).
-        empty = per_kernel.pop("_empty_launch", None)
-        empty_ms = (empty[0] / empty[1]) if empty else 0.0
-        kernels = {}
-        for label, (tot, cnt) in per_kernel.items():
-            launches = cnt / reps
-            interval_ms = tot / cnt
-            avg_ms = (interval_ms - empty_ms) if interval_ms >= 2.0 * empty_ms else None
-            ab = alg.get(label)
-            kernels[label] = {"launches_per_frame": launches, "avg_launch_ms": avg_ms, "event_interval_ms": interval_ms,
-                              "ms_per_frame": max(interval_ms - empty_ms, 0.0) * launches, "alg_bytes_per_launch": ab,
-                              "GBps": (ab / (avg_ms * 1e-3) / 1e9) if (ab and avg_ms) else None,
-                              # lower bound: the whole event interval charged to the kernel
-                              "GBps_interval": (ab / (interval_ms * 1e-3) / 1e9) if ab else None}
-        # dominant kernel = the launch label with the most GPU time per frame (the same kernel symbols rocprofv3
-        # --stats lists: the depth sort and the tile-id sort instantiate k_sort_scatter with different tile sizes)
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_frame"])
-        dk = kernels[dom]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{a.workload}.json")
-        if os.path.exists(tpath):  # PMC pass of the same command (scripts/pmc_traffic.sh), bytes per launch
-            traffic = json.load(open(tpath)).get(dom)
-        valu = None
-        vpath = os.path.join(ROOT, "profiles", f"valu_{a.workload}.json")
-        if os.path.exists(vpath):  # PMC pass of the same command (scripts/pmc_valu.py): VALU issue accounting per launch
-            valu = json.load(open(vpath)).get(dom)
-        bound = "hbm"
-        roofline = {"kernel": dom, "bound": bound, "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (dk["GBps"] / HBM_PEAK_GBS) if dk["GBps"] else None, "traffic": traffic,
-                    "alg_bytes_per_launch": dk["alg_bytes_per_launch"], "avg_launch_ms": dk["avg_launch_ms"],
-                    "launches_per_frame": dk["launches_per_frame"],
-                    "event_interval_ms": dk["event_interval_ms"], "empty_launch_interval_ms": empty_ms,
-                    "limited_by": ("latency" if (valu and valu.get("issue_util", 1.0) < 0.5) else "valu") if dom == "k_blend" else "hbm",
-                    "valu": valu,
-                    "note": "dominant = most GPU time per frame summed over its launches; HIP events around every "
-                            "launch on the launch stream, one frame in flight; avg_launch_ms = event interval minus "
-                            "the interval of an empty launch recorded the same way in every frame (dispatch latency "
-                            "of a dependent launch, which rocprofv3 kernel durations do not contain).  No stage is a dense contraction, so "
-                            "MFMA is unused and every kernel is priced against HBM; k_blend moves few bytes per "
-                            "(pixel, splat) pair: what limits it is VALU issue and, on scenes whose tiles saturate after "
-                            "one or two staged batches, the per-tile start-up latency (valu.issue_util, DESIGN.md 3.3); "
-                            "early-out makes its real traffic a fraction of the algorithmic bytes"}
-        stages = {k: {"ms": v} for k, v in stage_acc.items()}
         fps = world * a.steps / elapsed
         out = {
             "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {n} Gaussians (sh_deg 3), {w}x{h}, {a.format} target, "
-                                   f"{len(views)} orbit views sharded view i -> rank i mod N, {inflight} frame(s) in flight per GPU",
-                       "gaussians": n, "width": w, "height": h, "views": len(views), "frames_in_flight": inflight,
-                       "binning_tile": f"{tile_w}x{tile_h}",
-                       "avg_visible": V, "avg_tile_entries": D, "overflow": overflow,
-                       "single_stream_fps": single_stream_fps},
-            "roofline": roofline,
-            "kernels": kernels,
-            "stages": stages,
+            "config": {"workload": f"{a.workload}: {n} Gaussians (sh_deg {gpc.sh_deg}), {w}x{h}, {a.format} target, "
+                                   f"{len(views)} views sharded view i -> rank i mod N, {nstreams} frame(s) in flight per GPU",
+                       "gaussians": n, "width": w, "height": h, "views": len(views), "frames_in_flight": nstreams,
+                       "error_bits": err_bits, "collective": dist_note},
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(gpc, views[0], viewport)
-        elif world == 1:
-            out["cpu_baseline"] = None
+        if workload_note:
+            out["config"]["workload_note"] = workload_note
+            if workload_note.startswith("real scene"):
+                out["data"] = "real scene file (" + workload_note + ")"
+        if a.dry_run:
+            out["dry_run"] = True
+            out["config"]["rank0_views"] = view_ids
+    if rank == 0 and not a.dry_run:
+        analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world)
     barrier()
-    r.close()
-    batch.close()
-    pc.close()
-    ctx.close()
+    if dist is not None and a.dry_run:
+        got = [None] * world
+        dist.all_gather_object(got, view_ids)   # verification only (tests): every rank's shard
+        if out is not None:
+            out["config"]["rank_views"] = got
+    if not a.dry_run:
+        r.close()
+        batch.close()
+        pc.close()
+        ctx.close()
     if dist is not None:
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))
+
+
+def analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world):
+    """rank 0, after the timed region: single-stream rate, then per-kernel time (HIP events on the launch stream)
+    for the roofline, frame statistics and the CPU baseline."""
+    import torch
+    w, h = viewport
+    torch.cuda.synchronize()
+    ks = max(20, a.steps // 2)  # from here on: one frame at a time on renderer `r`, default stream
+    for i in range(5):
+        frame(i)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(ks):
+        frame(i)
+    torch.cuda.synchronize()
+    single_stream_fps = ks / (time.perf_counter() - t1)
+
+    r.enable_timers(2)  # HIP event pairs around every kernel launch, on the launch stream
+    reps = min(len(my_views), 16)
+    per_kernel = {}      # label -> [total ms over reps, launches over reps]
+    stage_acc = {"preprocess": 0.0, "sorting": 0.0, "binning": 0.0, "rasterization": 0.0}
+    stat_acc = {"num_visible": 0, "num_tile_entries": 0}
+    frame(0)
+    r.kernel_times()
+    for i in range(reps):
+        frame(i)
+        for label, ms in r.kernel_times():
+            e = per_kernel.setdefault(label, [0.0, 0])
+            e[0] += ms
+            e[1] += 1
+        st = r.stage_times()
+        fs = r.frame_stats()
+        for k in stage_acc:
+            stage_acc[k] += st[k] / reps
+        for k in stat_acc:
+            stat_acc[k] += fs[k] / reps
+    single_err, _ = r.errors()
+    r.enable_timers(0)
+    if single_err:
+        raise SystemExit(f"[bench] INVALID RUN: device-side error bits 0x{single_err:x} on the analysis renderer")
+    n = gpc.num_points
+    V, D = stat_acc["num_visible"], stat_acc["num_tile_entries"]
+    tile_w, tile_h = ctx.tile_size()
+    tile_bits = 8
+    while (1 << tile_bits) < -(-w // tile_w) * -(-h // tile_h):
+        tile_bits += 8
+    tile_passes = tile_bits // 8
+    # ALGORITHMIC bytes per launch (SURVEY 8(d); DESIGN.md "Roofline accounting"): N Gaussians, V visible,
+    # D (tile, splat) entries.  A radix pass over M pairs reads and writes 8 B per pair: 16*M; the histogram
+    # kernels read 4*M; the last tile-id pass does not write the keys (12*D).
+    alg = {
+        # K1c (SURVEY 8d): 24 B record for all, 12 B covariance + 3*(deg+1)^2 B SH gathers and 28 B out for survivors
+        "k_preprocess": n * 124 + V * 28,
+        "k_preprocess<compressed>": n * 24 + V * (12 + 3 * (gpc.sh_deg + 1) ** 2) + V * 28,
+        "depth:k_sort_tile_hist": 4 * V, "depth:k_sort_col_scan": None, "depth:k_sort_scatter": 16 * V,
+        "depth:k_sort_hist": 4 * V,
+        "k_bin_prefix": V * (4 + 8) + V * (8 + 4),
+        "k_bin_emit": V * 12 + D * 8,
+        "tiles:k_sort_tile_hist": 4 * D, "tiles:k_sort_col_scan": None, "tiles:k_sort_hist": 4 * D,
+        "tiles:k_sort_scatter": (16 * D * (tile_passes - 1) + 12 * D) / tile_passes,
+        "k_blend": D * 24 + w * h * 16,
+    }
+    # An event interval = event + dispatch overhead of a dependent launch + the kernel; rocprofv3 reports the kernel
+    # alone.  The library records one EMPTY launch per frame in the same way (after K1): its interval is subtracted.
+    # What an interval carries on top of the kernel is mostly the write-back of the PREVIOUS kernel's dirty L2 lines,
+    # so it varies (6 us after a memset, 12 us after K1's 30 MB of stores -- about what precedes the blend, for
+    # which the calibrated time matches rocprofv3 to 1 %); GBps_interval (nothing subtracted) is the lower bound.
+    # Launches shorter than twice the empty interval are below what events can resolve: no calibrated duration
+    # for them (their rocprofv3 durations are in profiles/).
+    empty = per_kernel.pop("_empty_launch", None)
+    empty_ms = (empty[0] / empty[1]) if empty else 0.0
+    kernels = {}
+    for label, (tot, cnt) in per_kernel.items():
+        launches = cnt / reps
+        interval_ms = tot / cnt
+        avg_ms = (interval_ms - empty_ms) if interval_ms >= 2.0 * empty_ms else None
+        ab = alg.get(label)
+        kernels[label] = {"launches_per_frame": launches, "avg_launch_ms": avg_ms, "event_interval_ms": interval_ms,
+                          "ms_per_frame": max(interval_ms - empty_ms, 0.0) * launches, "alg_bytes_per_launch": ab,
+                          "GBps": (ab / (avg_ms * 1e-3) / 1e9) if (ab and avg_ms) else None,
+                          # lower bound: the whole event interval charged to the kernel
+                          "GBps_interval": (ab / (interval_ms * 1e-3) / 1e9) if ab else None}
+    # dominant kernel = the launch label with the most GPU time per frame (the same kernel symbols rocprofv3
+    # --stats lists: the depth sort and the tile-id sort instantiate k_sort_scatter with different tile sizes)
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_frame"])
+    dk = kernels[dom]
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{a.workload}.json")
+    if os.path.exists(tpath):  # PMC pass of the same command (scripts/pmc_traffic.sh), bytes per launch
+        traffic = json.load(open(tpath)).get(dom)
+    valu = None
+    vpath = os.path.join(ROOT, "profiles", f"valu_{a.workload}.json")
+    if os.path.exists(vpath):  # PMC pass of the same command (scripts/pmc_valu.py): VALU issue accounting per launch
+        valu = json.load(open(vpath)).get(dom)
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (dk["GBps"] / HBM_PEAK_GBS) if dk["GBps"] else None, "traffic": traffic,
+                "alg_bytes_per_launch": dk["alg_bytes_per_launch"], "avg_launch_ms": dk["avg_launch_ms"],
+                "launches_per_frame": dk["launches_per_frame"],
+                "event_interval_ms": dk["event_interval_ms"], "empty_launch_interval_ms": empty_ms,
+                "limited_by": ("latency" if (valu and valu.get("issue_util", 1.0) < 0.5) else "valu") if dom == "k_blend" else "hbm",
+                "valu": valu,
+                "note": "dominant = most GPU time per frame summed over its launches; HIP events around every "
+                        "launch on the launch stream, one frame in flight; avg_launch_ms = event interval minus "
+                        "the interval of an empty launch recorded the same way in every frame (dispatch latency "
+                        "of a dependent launch, which rocprofv3 kernel durations do not contain).  No stage is a dense contraction, so "
+                        "MFMA is unused and every kernel is priced against HBM; k_blend moves few bytes per "
+                        "(pixel, splat) pair: what limits it is VALU issue and, on scenes whose tiles saturate after "
+                        "one or two staged batches, the per-tile start-up latency (valu.issue_util, DESIGN.md 3.3); "
+                        "early-out makes its real traffic a fraction of the algorithmic bytes"}
+    out["config"].update({"binning_tile": f"{tile_w}x{tile_h}", "avg_visible": V, "avg_tile_entries": D,
+                          "single_stream_fps": single_stream_fps})
+    out["roofline"] = roofline
+    out["kernels"] = kernels
+    out["stages"] = {k: {"ms": v} for k, v in stage_acc.items()}
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(gpc, views[0], viewport)
+    elif world == 1:
+        out["cpu_baseline"] = None
 
 
 if __name__ == "__main__":

@@ -258,6 +258,16 @@ int ws_pointcloud_load(ws_context* ctx, const char* path, ws_pointcloud** out);
 
 /* ---- PointCloud: pointcloud.rs:99-222, 336-349 ------------------------------------------------ */
 int ws_pointcloud_create(ws_context* ctx, const ws_pointcloud_desc* desc, ws_pointcloud** out);
+/* PlyReader::read (io/ply.rs:50-100, 164-196) + GenericGaussianPointCloud::new (io/mod.rs:63-105) + PointCloud::new
+ * with the per-vertex conversion on the GPU: `rows` = n raw vertex rows of the INRIA layout (14 + 3*(sh_deg+1)^2 f32
+ * each, host memory, native endianness); bbox / centroid / up are computed from them on the host; `meta` (may be
+ * NULL) supplies the optional mip_splatting / kernel_size / background_color header values (the other fields of the
+ * descriptor are ignored).  ws_pointcloud_load_ply takes this route. */
+int ws_pointcloud_create_from_ply_rows(ws_context* ctx, const float* rows, uint32_t n, uint32_t sh_deg,
+                                       const ws_pointcloud_desc* meta, ws_pointcloud** out);
+/* The resident scene as loader blobs again (28-B Gaussians + 96-B SH records, or the 24-B compressed records):
+ * accessor / parity tooling, the analogue of reading the PointCloud's buffers back (pointcloud.rs:201-222). */
+int ws_pointcloud_download(const ws_pointcloud* pc, void* gaussians, size_t gaussians_bytes, void* sh_coefs, size_t sh_coefs_bytes);
 void ws_pointcloud_destroy(ws_pointcloud* pc);
 uint32_t ws_pointcloud_num_points(const ws_pointcloud* pc);
 uint32_t ws_pointcloud_sh_deg(const ws_pointcloud* pc);

@@ -19,7 +19,27 @@ def build(force=False):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
 
+BUILD_FLAGS = "-O2 -ffp-contract=off -fno-fast-math"
+
+
+def _build_native():
+    """bench.py's cpu_baseline leg (WS_ORACLE_NATIVE=1): a -O3 -march=native build of the same source, compiled ON
+    THE HOST THAT RUNS IT into a temporary directory -- a -march=native object must never travel between machines.
+    Still -ffp-contract=off / no fast-math: vectorisation does not change IEEE results, so it stays the same oracle."""
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="ws_oracle_native_"), "libws_oracle_native.so")
+    flags = ["-O3", "-march=native", "-std=c11", "-fPIC", "-fopenmp", "-ffp-contract=off", "-fno-fast-math"]
+    subprocess.check_call(["gcc", *flags, "-shared", "-o", out, os.path.join(ORACLE_DIR, "ws_oracle.c"), "-lm"],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out, "-O3 -march=native -ffp-contract=off -fno-fast-math (built on this host)"
+
+
 build()
+if os.environ.get("WS_ORACLE_NATIVE") == "1":
+    try:
+        LIB_PATH, BUILD_FLAGS = _build_native()
+    except Exception:  # noqa: BLE001  (no compiler on the host: keep the portable build)
+        pass
 _lib = C.CDLL(LIB_PATH)
 
 

@@ -63,8 +63,80 @@ BOUNDARY_STEP = 0.0135            # 0.00903 * 0.99 * colour <= 1.5 (SH colours m
 BOUNDARY_PIXEL_FRACTION = 2e-5    # at most this fraction of the pixels (and never fewer than 4 allowed)
 
 
-def image_close(img, ref, max_abs=MAX_ABS, mean_abs=MEAN_ABS, allow_boundary=True):
-    """Returns (ok, message, max_abs_seen, mean_abs_seen, boundary_pixels)."""
+CUT_A = 2.0 * 2.3539888583335364   # gaussian.wgsl:61: discard if a > 2*CUTOFF
+
+
+class BoundaryProof:
+    """Shows that a pixel where the library and the oracle disagree by more than MAX_ABS IS a cut-off boundary pixel.
+
+    For the pixel, `a = |M^-1 (pixel - centre)|^2` (gaussian.wgsl:40-60) of EVERY splat of the frame is re-evaluated in
+    float64 from the quantised Splat records; fragments whose float64 `a` lies within the rounding error an f32
+    evaluation can carry (a forward error bound, times 4) of the cut-off are "undecided".  The pixel is accepted only
+    if (1) at least one fragment is undecided and (2) the library's value equals, within MAX_ABS, the float64
+    composite of the pixel under SOME keep / discard assignment of the undecided fragments -- i.e. the library drew
+    exactly what a correct evaluator may draw.  A genuinely wrong pixel fails (2)."""
+
+    EPS = 2.0 ** -24
+
+    def __init__(self, splats, order, width, height, background=(0.0, 0.0, 0.0, 0.0)):
+        h = np.ascontiguousarray(splats).view(np.float16).reshape(-1, 10)[np.asarray(order, dtype=np.int64)].astype(np.float64)
+        W, H = float(width), float(height)
+        m00, m01 = h[:, 0] * W, h[:, 2] * W
+        m10, m11 = -h[:, 1] * H, -h[:, 3] * H
+        det = m00 * m11 - m01 * m10
+        self.valid = np.isfinite(det) & (np.abs(det) > 0)
+        inv = np.where(self.valid, 1.0 / np.where(self.valid, det, 1.0), 0.0)
+        self.i00, self.i01, self.i10, self.i11 = m11 * inv, -m01 * inv, -m10 * inv, m00 * inv
+        self.cx = (h[:, 4] * 0.5 + 0.5) * W
+        self.cy = (0.5 - h[:, 5] * 0.5) * H
+        self.rgba = h[:, 6:10]
+        self.wh = max(W, H)
+        self.bg = np.asarray(background, dtype=np.float64)
+
+    def explain(self, x, y, value, max_abs=MAX_ABS):
+        """-> (ok, message) for pixel (x, y) whose library value is `value` (4 floats)."""
+        dx, dy = (x + 0.5) - self.cx, (y + 0.5) - self.cy
+        t00, t01, t10, t11 = self.i00 * dx, self.i01 * dy, self.i10 * dx, self.i11 * dy
+        p0, p1 = t00 + t01, t10 + t11
+        a = p0 * p0 + p1 * p1
+        e = self.EPS
+        # forward error of p = I * d in f32.  The centre (f16 NDC * 0.5 + 0.5) * W and the pixel offset d are exact in
+        # f32 (few significant bits); what rounds are the inverse (3 roundings), the products and the sum.  The library
+        # evaluates the same affine map in tile-local coordinates (|local| <= 64 px), p = I * local + c, whose terms are
+        # up to 64 * |I| larger than p itself: both forms are covered.
+        e0 = 6 * e * (np.abs(t00) + np.abs(t01)) + 4 * e * 64.0 * (np.abs(self.i00) + np.abs(self.i01))
+        e1 = 6 * e * (np.abs(t10) + np.abs(t11)) + 4 * e * 64.0 * (np.abs(self.i10) + np.abs(self.i11))
+        tol = 4.0 * (2 * np.abs(p0) * e0 + 2 * np.abs(p1) * e1 + 2 * e * a) + 1e-7
+        inside = self.valid & (a <= CUT_A + tol)
+        idx = np.nonzero(inside)[0]                       # far -> near (sorted order)
+        undecided = np.abs(a[idx] - CUT_A) <= tol[idx]
+        k = int(undecided.sum())
+        if k == 0:
+            return False, f"pixel ({x},{y}): no fragment within rounding of the cut-off -- not a boundary pixel"
+        if k > 10:
+            return False, f"pixel ({x},{y}): {k} undecided fragments (too many to enumerate)"
+        b_all = np.minimum(0.99, np.exp(-a[idx]) * self.rgba[idx, 3])
+        col = np.concatenate([self.rgba[idx, :3], np.ones((len(idx), 1))], axis=1)
+        und = np.nonzero(undecided)[0]
+        best = np.inf
+        for combo in range(1 << k):
+            b = b_all.copy()
+            for j, u in enumerate(und):
+                if not (combo >> j) & 1:
+                    b[u] = 0.0
+            # back-to-front "over": dst = src + dst * (1 - b); closed form with the transmittance of the NEARER fragments
+            t_near = np.concatenate([np.cumprod((1.0 - b)[::-1])[::-1][1:], [1.0]])
+            px = (col * (b * t_near)[:, None]).sum(axis=0) + self.bg * np.prod(1.0 - b)
+            best = min(best, float(np.abs(px - np.asarray(value, dtype=np.float64)).max()))
+            if best <= max_abs:
+                return True, ""
+        return False, (f"pixel ({x},{y}): {k} undecided fragment(s), but no keep/discard assignment reproduces the "
+                       f"library's value (closest {best:.3e})")
+
+
+def image_close(img, ref, max_abs=MAX_ABS, mean_abs=MEAN_ABS, allow_boundary=True, proof=None):
+    """Returns (ok, message, max_abs_seen, mean_abs_seen, boundary_pixels).  With `proof` (a BoundaryProof of the same
+    frame) every pixel that uses the boundary allowance has to be explained by it."""
     d = np.abs(img.astype(np.float64) - ref.astype(np.float64))
     if not np.isfinite(img).all():
         return False, "non-finite pixels", float("nan"), float("nan"), 0
@@ -79,6 +151,15 @@ def image_close(img, ref, max_abs=MAX_ABS, mean_abs=MEAN_ABS, allow_boundary=Tru
         return False, f"max-abs {mx:.3e} exceeds one cut-off boundary fragment ({BOUNDARY_STEP:g})", mx, mean, n_over
     if mean > mean_abs:
         return False, f"mean-abs {mean:.3e} > {mean_abs:g}", mx, mean, n_over
+    if proof is not None and n_over:
+        if callable(proof):  # built lazily: float64 planes of every splat of the frame
+            proof = proof()
+        width = img.shape[1]
+        for flat in np.nonzero(over)[0]:
+            y, x = divmod(int(flat), width)
+            ok, msg = proof.explain(x, y, img[y, x], max_abs)
+            if not ok:
+                return False, msg, mx, mean, n_over
     return True, "", mx, mean, n_over
 
 

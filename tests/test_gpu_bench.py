@@ -1,0 +1,101 @@
+"""bench.py on the GPU box: the one-rank RCCL communicator (the collective code path of the N-GPU run), the JSON
+contract, the real-scene hook (WEBSPLAT_BONSAI_PLY / WEBSPLAT_BONSAI_CAMERAS), and the error-bit check that
+invalidates a run whose frames dropped tile entries."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from websplat import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(args, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=timeout, env=e, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_one_rank_rccl_and_contract():
+    """`python bench.py --gpus 1` initialises a one-rank nccl (= RCCL) process group and sends the timing through the
+    same barrier + MAX all-reduce the 8-GPU run uses."""
+    p, out = _bench(["--gpus", "1", "--steps", "40", "--warmup", "10", "--workload", "c1", "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert out is not None, p.stdout[-2000:]
+    assert out["config"]["collective"] == "nccl communicator, world size 1", out["config"]["collective"]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 40 and out["warmup"] == 10 and out["value"] > 0
+    assert out["config"]["workload"].startswith("c1:") and out["config"]["error_bits"] == 0
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert abs(out["value"] - 40 / (out["ms_per_step"] * 40 / 1e3)) < 1e-6 * out["value"]
+
+
+def test_bench_real_scene_hook(tmp_path):
+    """--workload bonsai loads the scene named by WEBSPLAT_BONSAI_PLY through the library's PLY reader and the cameras of
+    WEBSPLAT_BONSAI_CAMERAS through its cameras.json reader (scene.rs), at 1200x799 (README.md:55)."""
+    rows = synth.scene_c2(n=60_000, seed=11)
+    ply = str(tmp_path / "point_cloud.ply")
+    synth.write_ply(ply, rows, 3)
+    cams = synth.orbit_cameras(9, 1559, 1039, 1160.0, 1160.0)
+    cj = str(tmp_path / "cameras.json")
+    synth.write_cameras_json(cj, cams)
+    p, out = _bench(["--steps", "30", "--warmup", "5", "--workload", "bonsai", "--no-cpu-baseline", "--no-dist"],
+                    env={"WEBSPLAT_BONSAI_PLY": ply, "WEBSPLAT_BONSAI_CAMERAS": cj})
+    assert p.returncode == 0, p.stderr[-3000:]
+    cfg = out["config"]
+    assert cfg["workload"].startswith("bonsai: 60000 Gaussians") and cfg["width"] == 1200 and cfg["height"] == 799
+    assert cfg["workload_note"].startswith("real scene point_cloud.ply") and "cameras.json" in cfg["workload_note"]
+    assert out["data"].startswith("real scene file")
+    assert cfg["views"] == 7                      # 7 of 8 cameras are training views (scene.rs:143-151): 9 -> 7 train
+    assert cfg["collective"].startswith("disabled")
+    # without the asset: a clear message and the stand-in (not run here: 1.2 M Gaussians); the selection logic itself:
+    sys.path.insert(0, ROOT)
+    import bench
+    import websplat as ws
+    os.environ.pop("WEBSPLAT_BONSAI_PLY", None)
+    assert "bonsai" in bench.WORKLOADS and ws.read_ply(ply).num_points == 60_000
+
+
+def test_sticky_error_bits_and_driver_retry(ws, ctx, oracle, tmp_path):
+    """A frame whose (tile, splat) list overflows its capacity sets bit 0 of the renderer's sticky error word; the word
+    survives later (good) frames until reset, a view batch ORs its slots, and ws_render_views grows the list and renders
+    again instead of writing an image that lost its nearest splats."""
+    import scenes
+    sc = scenes.c2(ws, oracle, n=150_000, viewport=(640, 480))
+    pc = ws.PointCloud(ctx, sc.gpc)
+    r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    try:
+        r.prepare(pc, sc.args)
+        r.render(pc)
+        good = r.download_target()
+        st = r.frame_stats()
+        need = st["num_tile_entries"]
+        assert r.errors() == (0, need)
+        r.set_tile_entry_capacity(max(4096, need // 3))
+        r.prepare(pc, sc.args)
+        r.render(pc)
+        st2 = r.frame_stats()
+        assert st2["overflow"] & 1 and st2["num_tile_entries"] <= max(4096, need // 3)
+        bits, needed = r.errors()
+        assert bits & 1 and needed == need                     # the unclamped demand is reported
+        r.set_tile_entry_capacity(0)                           # automatic again
+        r.prepare(pc, sc.args)
+        r.render(pc)
+        assert r.frame_stats()["overflow"] == 0
+        assert r.errors()[0] & 1                               # sticky across the good frame ...
+        assert r.errors(reset=True)[0] & 1 and r.errors()[0] == 0   # ... until reset
+        assert np.array_equal(r.download_target(), good)
+    finally:
+        r.close()
+        pc.close()

@@ -55,6 +55,18 @@ def test_npz_scene_image_vs_oracle(ws, ctx, oracle, tmp_path):
         # f16 ulp in their axes, which the image tolerance absorbs
         ok, msg, *_ = scenes.image_close(img, ref)
         assert ok, msg
+        # The packed int8 SH records are laid out by the CLOUD's degree (27 B here), whatever degree the renderer was
+        # created for: a default degree-3 renderer draws the same image (it must not read 48-B records), and a renderer
+        # of a LOWER degree than the cloud refuses.
+        r3 = ws.GaussianRenderer(ctx, "rgba32float", 3, True)
+        r3.prepare(pc, args)
+        r3.render(pc)
+        assert np.array_equal(r3.download_target(), img)
+        r3.close()
+        r1 = ws.GaussianRenderer(ctx, "rgba32float", 1, True)
+        with pytest.raises(ws.WebSplatError, match="higher SH degree|max_sh_deg"):
+            r1.prepare(pc, args)
+        r1.close()
     finally:
         pc.close()
 

@@ -1,5 +1,6 @@
-"""BASELINE configs at FULL size on the GPU, checked through size-independent properties (and against the oracle where
-the oracle finishes in seconds on the box's host cores):
+"""BASELINE configs at FULL size on the GPU: image parity against the oracle on every configuration (c2 1.2 M @
+1200x799, the 1 M @ 1920x1080 headline, c3 5 M @ 1920x1080, three c4 views @ 1920x1080, c5 @ 3840x2160 -- the oracle
+needs about a second per frame on the box's host cores), plus size-independent properties:
   C3  5 M Gaussians, 1920x1080: radix-sort stress -- draw order sorted / stable / a permutation, tile-entry
       conservation, image in range, bit-identical re-render
   C4  the C2 scene at 1920x1080, several orbit views (the per-rank work of the 64-view batch): determinism across
@@ -212,3 +213,112 @@ def test_view_batch_matches_single_renders(ws, ctx, oracle):
         batch.close()
         r.close()
         pc.close()
+
+
+# ---- full-size image parity on every BASELINE configuration -------------------------------------------------------
+# The f32 target is the parity configuration (the reference's bin/video.rs target); the tolerance is the stated one
+# (tests/scenes.py) and every pixel that uses the cut-off boundary allowance has to be PROVEN a boundary pixel
+# (scenes.BoundaryProof).  For the reference's other targets -- Rgba16Float (bin/render.rs:154, lib.rs:193) and
+# Rgba8Unorm (bin/measure.rs:184) -- the reference rounds after every blend (renderer.rs:65), the library once at the
+# store: that gap is REPORTED against the oracle's per-blend-rounding modes (ws_oracle.c quantize_target), not gated
+# (SURVEY 8c), into gpurun_out/parity_fullsize.json.
+_SCENE_CACHE = {}
+_REPORT = {}
+
+
+def _scene_rows(name):
+    if name not in _SCENE_CACHE:
+        _SCENE_CACHE.clear()  # one big scene at a time
+        if name == "c2":
+            _SCENE_CACHE[name] = synth.scene_c2(n=1_200_000, seed=1)
+        elif name == "hd1m":
+            _SCENE_CACHE[name] = synth.scene_c2(n=1_000_000, seed=1)
+        elif name == "c3":
+            _SCENE_CACHE[name] = synth.scene_c3(n=5_000_000, seed=2)
+    return _SCENE_CACHE[name]
+
+
+def _gap(img, ref):
+    d = np.abs(img.astype(np.float64) - ref.astype(np.float64))
+    return {"max_abs": float(d.max()), "mean_abs": float(d.mean()), "p999": float(np.quantile(d, 0.999))}
+
+
+def _write_report():
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_fullsize.json"), "w") as f:
+        json.dump(_REPORT, f, indent=1, sort_keys=True)
+
+
+def _full_parity(ws, ctx, oracle, tag, rows, cams, viewport):
+    w, h = viewport
+    gpc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
+    pc = ws.PointCloud(ctx, gpc)
+    rs = {f: ws.GaussianRenderer(ctx, f, 3, False) for f in ("rgba32float", "rgba16float", "rgba8unorm")}
+    try:
+        for vi, cj in cams:
+            cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, w, h)
+            cam.fit_near_far(gpc.aabb)
+            args = ws.SplattingArgs(camera=cam, viewport=viewport, max_sh_deg=3)
+            cu = oracle.copy_struct(oracle.CameraUniform, cam.uniform(viewport))
+            su = oracle.copy_struct(oracle.SettingsUniform, pc.settings_uniform(args))
+            splats, keys, _ = oracle.preprocess(gpc.gaussians, gpc.sh_coefs, cu, su)
+            _, order = oracle.sort_pairs(keys, np.arange(len(keys), dtype=np.uint32))
+            ref = oracle.render(splats, order, w, h, (0, 0, 0, 0), 0)
+            imgs = {}
+            for f, r in rs.items():
+                r.prepare(pc, args)
+                r.render(pc)
+                imgs[f] = r.download_target()
+                st = r.frame_stats()
+                assert st["overflow"] == 0 and r.errors()[0] == 0, (tag, vi, f, st)
+                assert st["num_visible"] == len(keys), (tag, vi, st["num_visible"], len(keys))
+            _image_sane(imgs["rgba32float"])
+            ok, msg, mx, mean, nb = scenes.image_close(
+                imgs["rgba32float"], ref, proof=lambda: scenes.BoundaryProof(splats, order, w, h))
+            entry = {"gaussians": int(gpc.num_points), "viewport": [w, h], "visible": int(len(keys)),
+                     "tile_entries": int(st["num_tile_entries"]),
+                     "f32_target_vs_oracle_f32": {"max_abs": mx, "mean_abs": mean, "boundary_pixels_proven": nb,
+                                                  "tolerance": {"max_abs": scenes.MAX_ABS, "mean_abs": scenes.MEAN_ABS}}}
+            # reported, not gated: the reference's per-blend rounding on its f16 / unorm8 targets
+            img16 = imgs["rgba16float"].astype(np.float32)
+            img8 = imgs["rgba8unorm"].astype(np.float32) / 255.0
+            entry["f16_target_vs_oracle_f16_per_blend"] = _gap(img16, oracle.render(splats, order, w, h, (0, 0, 0, 0), 1))
+            entry["unorm8_target_vs_oracle_unorm8_per_blend"] = _gap(img8, oracle.render(splats, order, w, h, (0, 0, 0, 0), 2))
+            entry["f16_target_vs_oracle_f32"] = _gap(img16, ref)
+            entry["unorm8_target_vs_oracle_f32"] = _gap(img8, ref)
+            _REPORT[f"{tag}/view{vi}"] = entry
+            _write_report()
+            assert ok, (tag, vi, msg)
+            # the library's own f16 / unorm8 stores are the f32 image rounded once
+            assert np.abs(img16 - imgs["rgba32float"]).max() <= 2.0 ** -10 * max(1.0, float(imgs["rgba32float"].max()))
+            assert np.abs(img8 - np.clip(imgs["rgba32float"], 0, 1)).max() <= 0.5 / 255 + 1e-6
+    finally:
+        for r in rs.values():
+            r.close()
+        pc.close()
+
+
+def test_c2_full_image_vs_oracle(ws, ctx, oracle):
+    """BASELINE config 2 at full size: 1.2 M Gaussians, 1200x799."""
+    cams = synth.orbit_cameras(64, 1200, 799, 1200.0, 1200.0)
+    _full_parity(ws, ctx, oracle, "c2", _scene_rows("c2"), [(0, cams[0])], (1200, 799))
+
+
+def test_c4_three_views_full_image_vs_oracle(ws, ctx, oracle):
+    """BASELINE config 4: the c2 scene at 1920x1080, three of the 64 orbit views (what three different ranks draw)."""
+    cams = synth.orbit_cameras(64, 1920, 1080, 1920.0, 1920.0)
+    _full_parity(ws, ctx, oracle, "c4", _scene_rows("c2"), [(i, cams[i]) for i in (0, 21, 42)], (1920, 1080))
+
+
+def test_hd1m_full_image_vs_oracle(ws, ctx, oracle):
+    """The north-star headline configuration: 1 M Gaussians, 1920x1080 (bench.py's default workload)."""
+    cams = synth.orbit_cameras(64, 1920, 1080, 1920.0, 1920.0)
+    _full_parity(ws, ctx, oracle, "hd1m", _scene_rows("hd1m"), [(0, cams[0])], (1920, 1080))
+
+
+def test_c3_full_image_vs_oracle(ws, ctx, oracle):
+    """BASELINE config 3 at full size: 5 M Gaussians, 1920x1080 (the sort stress), image against the oracle."""
+    _full_parity(ws, ctx, oracle, "c3", _scene_rows("c3"), [(0, synth.camera_c3(1920, 1080))], (1920, 1080))
+    _SCENE_CACHE.clear()

@@ -66,3 +66,30 @@ def test_two_rank_gloo_sharding():
         assert everyone == [[0, 2, 4, 6, 8], [1, 3, 5, 7]]
         assert frames == 200          # whole-job frames
         assert elapsed == 2.0         # MAX over ranks -> fps = 200 / 2.0
+
+
+def test_bench_dry_run_two_ranks_gloo():
+    """bench.py's OWN sharding / planning / barrier / MAX-reduction code, launched exactly as the driver launches the
+    N-GPU run (torch.distributed.run, one process per rank), on CPU with backend gloo: frames are not rendered
+    (--dry-run), everything else is the code the RCCL run executes."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "c1",
+           "--steps", "40", "--warmup", "4", "--views", "9", "--streams", "3"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout            # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["steps"] == 40 and out["warmup"] == 4
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True and out["vs_baseline"] is None
+    cfg = out["config"]
+    assert cfg["rank_views"] == [[0, 2, 4, 6, 8], [1, 3, 5, 7]]      # view i -> rank i mod N
+    assert cfg["frames_in_flight"] == 3 and cfg["workload"].startswith("c1:")
+    assert "gloo communicator, world size 2" in cfg["collective"]
+    # whole-job value: all ranks' frames over the MAX elapsed (each dry frame sleeps 0.2 ms)
+    assert abs(out["value"] - 2 * 40 / (out["ms_per_step"] * 40 / 1e3)) < 1e-6 * out["value"]
+    assert 0.15 < out["ms_per_step"] < 5.0

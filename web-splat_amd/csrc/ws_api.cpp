@@ -456,6 +456,87 @@ int ws_pointcloud_create(ws_context* ctx, const ws_pointcloud_desc* d, ws_pointc
     return WS_OK;
 }
 
+// PlyReader::read + PointCloud::new with the per-vertex conversion (io/ply.rs:50-100) done by a kernel: the rows go
+// to the device as they sit in the file, k_ply_decode writes the resident planes directly (ply_decode.hip).
+int ws_pointcloud_create_from_ply_rows(ws_context* ctx, const float* rows, uint32_t n, uint32_t sh_deg,
+                                       const ws_pointcloud_desc* meta, ws_pointcloud** out) {
+    if (!ctx || !rows || !out) return fail(WS_ERR_INVALID, "ws_pointcloud_create_from_ply_rows: null argument");
+    *out = nullptr;
+    if (sh_deg > 3) return fail(WS_ERR_UNSUPPORTED, "ws_pointcloud_create_from_ply_rows: sh_deg > 3");
+    if (n == 0) return fail(WS_ERR_INVALID, "ws_pointcloud_create_from_ply_rows: empty point cloud");
+    if (n >= (1u << 30)) return fail(WS_ERR_UNSUPPORTED, "ws_pointcloud_create_from_ply_rows: more than 2^30-1 points");
+    const uint32_t row_len = 14u + 3u * (sh_deg + 1u) * (sh_deg + 1u);
+    ws_pointcloud* pc = new (std::nothrow) ws_pointcloud();
+    if (!pc) return fail(WS_ERR_OOM, "ws_pointcloud_create_from_ply_rows: host allocation failed");
+    pc->ctx = ctx;
+    pc->num_points = n;
+    pc->sh_deg = sh_deg;
+    pc->compressed = false;
+    ws_aabb zero;  // Aabb::zeroed(), io/mod.rs:74: the positions are the first three floats of every row
+    std::memset(&zero, 0, sizeof zero);
+    int32_t has_up = 0;
+    int rc = ws_pointcloud_stats(rows, n, row_len * (uint32_t)sizeof(float), &zero, &pc->bbox, pc->center, &has_up, pc->up);
+    pc->has_up = has_up != 0;
+    if (meta) {
+        pc->has_mip = meta->has_mip_splatting != 0;
+        pc->mip = meta->mip_splatting != 0;
+        pc->has_kernel_size = meta->has_kernel_size != 0;
+        pc->kernel_size = meta->kernel_size;
+        pc->has_background = meta->has_background_color != 0;
+        std::memcpy(pc->background, meta->background_color, sizeof pc->background);
+    }
+    float* d_rows = nullptr;
+    if (rc == WS_OK) {
+        pc->device_bytes = (size_t)n * PC_PLANES * 16;
+        const size_t row_bytes = (size_t)n * row_len * sizeof(float);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&pc->planes), pc->device_bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rows), row_bytes);
+        if (e == hipSuccess) e = hipMemcpy(d_rows, rows, row_bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = hip_fail(e, "ws_pointcloud_create_from_ply_rows: upload");
+    }
+    if (rc == WS_OK) rc = launch_ply_decode(d_rows, n, sh_deg, pc->planes, nullptr);
+    if (rc == WS_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) rc = hip_fail(e, "ws_pointcloud_create_from_ply_rows: decode");
+    }
+    if (d_rows) (void)hipFree(d_rows);
+    if (rc != WS_OK) {
+        ws_pointcloud_destroy(pc);
+        return rc;
+    }
+    *out = pc;
+    return WS_OK;
+}
+
+// The scene blobs as the loader would have produced them (parity tooling / accessors): uncompressed clouds are
+// re-assembled from the resident planes into 28-B Gaussians + 96-B SH records, compressed blobs are copied back as is.
+int ws_pointcloud_download(const ws_pointcloud* pc, void* gaussians, size_t gaussians_bytes, void* sh_coefs, size_t sh_bytes) {
+    if (!pc || !gaussians || !sh_coefs) return fail(WS_ERR_INVALID, "ws_pointcloud_download: null argument");
+    const size_t n = pc->num_points;
+    if (pc->compressed) {
+        if (gaussians_bytes < n * 24) return fail(WS_ERR_INVALID, "ws_pointcloud_download: gaussians buffer too small");
+        WS_HIP(hipMemcpy(gaussians, pc->gaussians_c, n * 24, hipMemcpyDeviceToHost));
+        return WS_OK;  // (the packed SH / covariance codebooks are what the caller uploaded; not re-exported)
+    }
+    if (gaussians_bytes < n * 28 || sh_bytes < n * 96) return fail(WS_ERR_INVALID, "ws_pointcloud_download: buffers too small");
+    std::vector<uint32_t> st;
+    try {
+        st.resize(n * PC_PLANES * 4);
+    } catch (...) {
+        return fail(WS_ERR_OOM, "ws_pointcloud_download: host allocation failed");
+    }
+    WS_HIP(hipMemcpy(st.data(), pc->planes, st.size() * 4, hipMemcpyDeviceToHost));
+    uint8_t* g = static_cast<uint8_t*>(gaussians);
+    uint8_t* s = static_cast<uint8_t*>(sh_coefs);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        std::memcpy(g + (size_t)i * 28, st.data() + ((size_t)0 * n + i) * 4, 16);
+        std::memcpy(g + (size_t)i * 28 + 16, st.data() + ((size_t)1 * n + i) * 4, 12);
+        for (int q = 0; q < 6; ++q) std::memcpy(s + (size_t)i * 96 + q * 16, st.data() + ((size_t)(2 + q) * n + i) * 4, 16);
+    }
+    return WS_OK;
+}
+
 void ws_pointcloud_destroy(ws_pointcloud* pc) {
     if (!pc) return;
     dfree(pc->planes);

@@ -203,6 +203,9 @@ int launch_empty(hipStream_t stream);
 int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, float tile_y0, uint32_t qw, uint32_t qh,
                       float rec[10], uint32_t* mask);
 
+// ---- PLY row decode on the GPU (ply_decode.hip) -------------------------------------------------------
+int launch_ply_decode(const float* d_rows, uint32_t n, uint32_t sh_deg, uint4* planes, hipStream_t stream);
+
 // ---- host math (host_math.cpp) ------------------------------------------------------------------
 void build_camera_uniform(const ws_camera& cam, const uint32_t viewport[2], ws_camera_uniform* out);
 

@@ -200,6 +200,8 @@ SIGNATURES = {
     "ws_display_composite": (C.c_int, [_P, _P, C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, _f32p, C.c_int, _P,
                                        C.c_size_t, _P]),
     "ws_pointcloud_create": (C.c_int, [_P, C.POINTER(ws_pointcloud_desc), _PP]),
+    "ws_pointcloud_create_from_ply_rows": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(ws_pointcloud_desc), _PP]),
+    "ws_pointcloud_download": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t]),
     "ws_pointcloud_destroy": (None, [_P]),
     "ws_pointcloud_num_points": (C.c_uint32, [_P]),
     "ws_pointcloud_sh_deg": (C.c_uint32, [_P]),

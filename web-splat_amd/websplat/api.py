@@ -419,6 +419,40 @@ class PointCloud:
         self.handle = h
 
     @staticmethod
+    def from_ply_rows(ctx: Context, rows: np.ndarray, sh_deg: int, kernel_size=None, mip_splatting=None,
+                      background_color=None):
+        """Raw PLY vertex rows -> resident scene with the conversion (io/ply.rs:50-100) on the GPU."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        want = 14 + 3 * (int(sh_deg) + 1) ** 2
+        if rows.ndim != 2 or rows.shape[1] != want:
+            raise ValueError(f"from_ply_rows: sh_deg {sh_deg} needs rows of {want} floats, got shape {rows.shape}")
+        d = L.ws_pointcloud_desc()
+        d.has_mip_splatting = int(mip_splatting is not None)
+        d.mip_splatting = int(bool(mip_splatting))
+        d.has_kernel_size = int(kernel_size is not None)
+        d.kernel_size = float(kernel_size or 0.0)
+        d.has_background_color = int(background_color is not None)
+        if background_color is not None:
+            d.background_color[:] = [float(x) for x in background_color]
+        h = C.c_void_p()
+        check(lib.ws_pointcloud_create_from_ply_rows(ctx.handle, rows.ctypes.data_as(C.c_void_p), rows.shape[0], int(sh_deg),
+                                                     C.byref(d), C.byref(h)))
+        return PointCloud(ctx, _handle=h)
+
+    def download(self):
+        """(gaussians N x 28 | N x 24, sh N x 96 | None): the resident scene as loader blobs (parity tooling)."""
+        n = self.num_points()
+        if self.compressed():
+            g = np.empty((n, 24), dtype=np.uint8)
+            s = np.empty((1,), dtype=np.uint8)
+            check(lib.ws_pointcloud_download(self.handle, g.ctypes.data_as(C.c_void_p), g.nbytes, s.ctypes.data_as(C.c_void_p), 0))
+            return g, None
+        g = np.empty((n, 28), dtype=np.uint8)
+        s = np.empty((n, 96), dtype=np.uint8)
+        check(lib.ws_pointcloud_download(self.handle, g.ctypes.data_as(C.c_void_p), g.nbytes, s.ctypes.data_as(C.c_void_p), s.nbytes))
+        return g, s
+
+    @staticmethod
     def load_ply(ctx: Context, path: str):
         h = C.c_void_p()
         check(lib.ws_pointcloud_load_ply(ctx.handle, path.encode(), C.byref(h)))
