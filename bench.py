@@ -227,6 +227,12 @@ def main():
                     help="CPU only (backend gloo): sharding, planning, barrier and reduction without rendering")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line, the result: everything else that writes to file descriptor 1 -- RCCL prints a
+    # version banner through C stdio, flushed at exit -- is sent to stderr for the life of the process.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     dist, rank, local_rank, world, dist_note = init_distributed(a, torch)
     dev = "cpu" if a.dry_run else "cuda"
@@ -358,7 +364,8 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    os.close(result_fd)
 
 
 def analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world):
@@ -416,7 +423,10 @@ def analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world
         "k_preprocess<compressed>": n * 24 + V * (12 + 3 * (gpc.sh_deg + 1) ** 2) + V * 28,
         "depth:k_sort_tile_hist": 4 * V, "depth:k_sort_col_scan": None, "depth:k_sort_scatter": 16 * V,
         "depth:k_sort_hist": 4 * V,
-        "k_bin_prefix": V * (4 + 8) + V * (8 + 4),
+        # range-adaptive depth sort: the histogram kernel reads the keys; a scatter pass moves key + index + packed tile
+        # rectangle in and out (12 B each way)
+        "depth:k_dsort_hist": 4 * V, "depth:k_dsort_scatter": 24 * V, "k_gather_rects": 12 * V,
+        "k_bin_prefix": V * (4 + 4),
         "k_bin_emit": V * 12 + D * 8,
         "tiles:k_sort_tile_hist": 4 * D, "tiles:k_sort_col_scan": None, "tiles:k_sort_hist": 4 * D,
         "tiles:k_sort_scatter": (16 * D * (tile_passes - 1) + 12 * D) / tile_passes,

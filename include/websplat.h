@@ -419,6 +419,11 @@ void ws_sorter_destroy(ws_sorter* s);
  * clamped to n): ascending, stable, in place in d_keys / d_payload (gpu_rs.rs:865-884). */
 int ws_sorter_sort(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, const uint32_t* d_count, uint32_t n,
                    void* stream);
+/* The same contract (record_sort / record_sort_indirect) through the renderer's depth-sort specialisation: three digit
+ * passes whose width follows the range of the keys (typically 3 x 9 bits for a frame's depth keys instead of 4 x 8),
+ * two launches per pass; d_aux (may be NULL) is a 4-byte companion that travels with the payload.  In place. */
+int ws_sorter_sort_depth(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, uint32_t* d_aux, const uint32_t* d_count,
+                         uint32_t n, void* stream);
 /* GPURSSorter::test_sort (gpu_rs.rs:295-331): 8192 reversed f32 keys must come out ascending. 1 = pass */
 int ws_sort_selftest(ws_context* ctx, int* passed);
 

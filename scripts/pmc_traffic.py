@@ -24,10 +24,18 @@ def label_of(name):
         return "k_bin_emit"
     if "k_blend" in name:
         return "k_blend"
-    m = re.search(r"k_sort_(scatter|tile_hist)<(?:(?:false|true), )?(\d+)", name)
+    if "k_dsort_hist" in name:
+        return "depth:k_dsort_hist"
+    if "k_dsort_scatter" in name:
+        return "depth:k_dsort_scatter"
+    m = re.search(r"k_sort_scatter<(?:false|true), (\d+), (?:false|true), (\d+)>", name)
+    if m:  # <LOOKBACK, KPT, RANGES, BITS>: the depth sort uses 8-bit digits, the tile-id sort 6..7 below 2^15 tiles
+        kpt, bits = int(m.group(1)), int(m.group(2))
+        which = "depth" if (bits == 8 and "true, 8>" not in name) or kpt == 4 else "tiles"
+        return f"{which}:k_sort_scatter"
+    m = re.search(r"k_sort_tile_hist<(\d+)>", name)
     if m:
-        which = "depth" if int(m.group(2)) == 4 else "tiles"  # 1024-key tiles = the (small) depth sort
-        return f"{which}:k_sort_{m.group(1)}"
+        return ("depth" if int(m.group(1)) == 4 else "sort") + ":k_sort_tile_hist"
     return None
 
 

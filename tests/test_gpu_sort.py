@@ -8,11 +8,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[1, 0], ids=["onesweep", "reduce_scan"])
+@pytest.fixture(scope="module", params=[1, 0, "depth"], ids=["onesweep", "reduce_scan", "depth3pass"])
 def sort_ctx(ws, request):
+    """Three paths to the same contract: the generic sorter's one-sweep and reduce-then-scan cross-tile prefixes, and
+    the renderer's range-adaptive three-pass depth sort (ws_sorter_sort_depth)."""
     old = os.environ.get("WS_SORT_ALGO")
-    os.environ["WS_SORT_ALGO"] = str(request.param)
+    os.environ["WS_SORT_ALGO"] = str(request.param) if request.param != "depth" else "0"
     c = ws.Context(0)
+    c.depth_mode = request.param == "depth"
     if old is None:
         del os.environ["WS_SORT_ALGO"]
     else:
@@ -30,7 +33,14 @@ def _check(ws, ctx, oracle, keys, count=None):
     n = len(keys)
     sorter = ws.GPURSSorter(ctx, max(n, 1))
     try:
-        k, p = sorter.sort_host(keys, np.arange(n, dtype=np.uint32), count=count)
+        if getattr(ctx, "depth_mode", False):  # a companion value rides along: must arrive with its pair
+            aux_in = (np.arange(n, dtype=np.uint32) * np.uint32(2654435761)) ^ np.uint32(0x5BD1E995)
+            k, p, ax = sorter.sort_host(keys, np.arange(n, dtype=np.uint32), count=count, depth=True, aux=aux_in)
+            mm = n if count is None else min(count, n)
+            assert np.array_equal(ax[:mm], aux_in[p[:mm]]), "companion values separated from their pairs"
+            assert np.array_equal(ax[mm:], aux_in[mm:])
+        else:
+            k, p = sorter.sort_host(keys, np.arange(n, dtype=np.uint32), count=count)
     finally:
         sorter.close()
     m = n if count is None else min(count, n)
@@ -93,7 +103,7 @@ def test_sort_large_sortedness(ws, sort_ctx):
     keys[::7] = keys[0]  # plenty of duplicates to exercise stability
     sorter = ws.GPURSSorter(sort_ctx, n)
     try:
-        k, p = sorter.sort_host(keys, np.arange(n, dtype=np.uint32))
+        k, p = sorter.sort_host(keys, np.arange(n, dtype=np.uint32), depth=getattr(sort_ctx, "depth_mode", False))
     finally:
         sorter.close()
     assert np.all(k[1:] >= k[:-1])
@@ -103,3 +113,23 @@ def test_sort_large_sortedness(ws, sort_ctx):
     assert seen.all()
     ties = k[1:] == k[:-1]
     assert np.all(p[1:][ties] > p[:-1][ties])
+
+
+@pytest.mark.parametrize("nbits", [0, 1, 5, 12, 13, 20, 26, 27, 28, 30, 31, 32])
+def test_depth_sort_digit_width_follows_the_key_range(ws, ctx, oracle, nbits):
+    """The depth sort sizes its three digit passes by bit_length(kmax - kmin): every width from 4 to 11 bits, ranges that
+    start anywhere (kmin is subtracted), including the full 32 bits and a single value."""
+    n = 300_001
+    rng = np.random.default_rng(1000 + nbits)
+    span = (1 << nbits) - 1 if nbits else 0
+    base = 0 if nbits >= 32 else int(rng.integers(0, (1 << 32) - span))
+    keys = (base + rng.integers(0, span + 1, size=n, dtype=np.uint64)).astype(np.uint32)
+    if nbits:
+        keys[0], keys[1] = np.uint32(base), np.uint32(base + span)   # the range is exactly nbits wide
+    sorter = ws.GPURSSorter(ctx, n)
+    try:
+        k, p = sorter.sort_host(keys, np.arange(n, dtype=np.uint32), depth=True)
+    finally:
+        sorter.close()
+    ok, op = oracle.sort_pairs(keys, np.arange(n, dtype=np.uint32))
+    assert np.array_equal(k, ok) and np.array_equal(p, op)

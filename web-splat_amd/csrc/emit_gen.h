@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t pad(uint32_t i) { return i + i / EPT; }  // 
 
 struct Source {
     const uint32_t* sorted_idx;   // [V] store indices in draw order
-    const uint2* rects_sorted;    // [V] tile rectangle by draw position
+    const uint32_t* rects_sorted; // [V] packed tile rectangle (rect_pack) by draw position
     const uint32_t* offsets;      // [V] exclusive prefix of tiles touched, by draw position
     const uint32_t* emit_start;   // draw position owning entry m * EMIT_TILE
     const FrameCounters* counters;
@@ -112,9 +112,9 @@ __device__ __forceinline__ void entry(const Source& src, const Slice& sl, const 
         }
     }
     const uint32_t pos = sl.s_lo + lo;
-    const uint2 r = src.rects_sorted[pos];
-    const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu;
-    const uint32_t w = x1 - x0 + 1u;
+    const uint32_t r = src.rects_sorted[pos];  // x0 | y0 << 8 | (w - 1) << 16 | (h - 1) << 24
+    const uint32_t x0 = r & 0xFFu, y0 = (r >> 8) & 0xFFu;
+    const uint32_t w = ((r >> 16) & 0xFFu) + 1u;
     const uint32_t k = e - (sl.in_lds ? s_off[lo] : sl.goff[lo]);
     // k / w without the integer-division sequence: k < 2^24 always (a rectangle has at most 2^16 x 2^16 tiles
     // but the entry capacity is below 2^30 and rows are at most 65535 wide; one correction step covers rounding)

@@ -132,7 +132,7 @@ __device__ __forceinline__ void eval_sh3(const Sh16& sh, float x, float y, float
 struct SplatOut {
     uint32_t w[5];  // Splat: v(4 x f16) pos(2 x f16) color(4 x f16)
     uint32_t key;
-    uint2 rect;
+    uint32_t rect;  // rect_pack(), RECT_EMPTY = touches no tile
 };
 
 #define VM(c, r) (p.cam.view[(c)*4 + (r)])
@@ -316,7 +316,7 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
         const float rad = 2.1697873f * 1.00001f;  // sqrt(2*CUTOFF), padded
         const float exx = rad * qsqrt(m00 * m00 + m01 * m01) + 1e-3f;
         const float eyy = rad * qsqrt(m10 * m10 + m11 * m11) + 1e-3f;
-        uint2 rect = make_uint2(1u, 0u);  // empty
+        uint32_t rect = RECT_EMPTY;
         const bool ok = (fabsf(det) > 0.0f) && (fabsf(det) < 3.0e38f) && (fabsf(cx) < 1.0e9f) && (fabsf(cy) < 1.0e9f) &&
                         (exx < 1.0e9f) && (eyy < 1.0e9f);
         if (ok) {
@@ -330,7 +330,7 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
             if (x_lo <= x_hi && y_lo <= y_hi) {
                 const uint32_t tx0 = (uint32_t)x_lo >> p.tile_w_log2, tx1 = (uint32_t)x_hi >> p.tile_w_log2;
                 const uint32_t ty0 = (uint32_t)y_lo >> p.tile_h_log2, ty1 = (uint32_t)y_hi >> p.tile_h_log2;
-                rect = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+                rect = rect_pack(tx0, ty0, tx1, ty1);  // < 256 tiles per axis (ws_renderer_prepare checks the viewport)
             }
         }
         out->rect = rect;
@@ -529,6 +529,7 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_cnt[K1_ITEMS][K1_THREADS / 64];
     __shared__ uint32_t s_base;
+    __shared__ uint32_t s_kmax[K1_THREADS / 64], s_kmin_inv[K1_THREADS / 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
     for (int it = 0; it < K1_ITEMS; ++it) {
         so[it].w[0] = so[it].w[1] = so[it].w[2] = so[it].w[3] = so[it].w[4] = 0u;
         so[it].key = 0u;
-        so[it].rect = make_uint2(1u, 0u);
+        so[it].rect = RECT_EMPTY;
     }
     if (!COMPRESSED) {
         const uint32_t safe_idx = block_base < n ? block_base : 0u;  // culled lanes re-read this (cached) record
@@ -613,6 +614,26 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
             if (vis[it]) k1_back_compressed(p, b, fr[it], &so[it]);
     }
 
+    // ---- range of the block's depth keys (the depth sort sizes its digits by the frame's range, sort.hip) ----------
+    {
+        uint32_t kmax = 0u, kmin_inv = 0u;
+#pragma unroll
+        for (int it = 0; it < K1_ITEMS; ++it)
+            if (vis[it]) {
+                kmax = max(kmax, so[it].key);
+                kmin_inv = max(kmin_inv, ~so[it].key);
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+            kmin_inv = max(kmin_inv, (uint32_t)__shfl_xor((int)kmin_inv, o, 64));
+        }
+        if (lane == 0) {
+            s_kmax[wave] = kmax;
+            s_kmin_inv[wave] = kmin_inv;
+        }
+    }
+
     // ---- ordered compaction, part 2: look-back (wave 0) and scatter ----------------------------------------
     if (wave == 0) {
         // (measured: replacing the ordered look-back by one unordered atomicAdd per block does not change this kernel's
@@ -625,6 +646,17 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
         }
     }
     __syncthreads();
+    if (tid == 0 && block_cnt) {  // returnless atomics on this workgroup's slot of the key-range table
+        uint32_t kmax = 0u, kmin_inv = 0u;
+#pragma unroll
+        for (int w = 0; w < K1_THREADS / 64; ++w) {
+            kmax = max(kmax, s_kmax[w]);
+            kmin_inv = max(kmin_inv, s_kmin_inv[w]);
+        }
+        uint32_t* kr = b.key_range + (bid & (KEY_RANGE_SLOTS - 1)) * KEY_RANGE_STRIDE;
+        atomicMax(kr, kmax);
+        atomicMax(kr + 1, kmin_inv);
+    }
     const uint32_t base = s_base;
 #pragma unroll
     for (int it = 0; it < K1_ITEMS; ++it) {

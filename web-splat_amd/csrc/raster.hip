@@ -39,12 +39,6 @@ constexpr int BIN_IPT = WS_BIN_IPT;                // sorted splats per thread (
 
 __device__ __forceinline__ float h2f(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)(h & 0xFFFFu))); }
 
-__device__ __forceinline__ uint32_t rect_count(uint2 r) {
-    const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu, y1 = r.y >> 16;
-    if (x0 > x1 || y0 > y1) return 0u;
-    return (x1 - x0 + 1u) * (y1 - y0 + 1u);
-}
-
 __device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t* s_tmp, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = v;
@@ -68,13 +62,14 @@ __device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t
 }
 
 // ---- k_bin_prefix ------------------------------------------------------------------------------------
-// Draw position i (far -> near) -> rects_sorted[i], offsets[i] = sum of tiles touched by positions < i.
+// Draw position i (far -> near) -> offsets[i] = sum of tiles touched by positions < i.  The packed tile rectangles
+// arrive IN DRAW ORDER: they ride through the depth sort with the splat index (sort.hip), so this kernel streams
+// (it used to gather rects[sorted_idx[i]] at random: every XCD's L2 pulled the whole array, 3.2 x the algorithmic
+// traffic on the 1 M scene and 122 of this kernel's 137 us on 5 M splats).
 // Also records, for every multiple m*EMIT_TILE of the entry index, the draw position whose entry range
 // contains it (emit_start[m]): the emit kernel then needs no global search to find where its slice starts.
 template <int BIN_IPT>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __restrict__ sorted_idx,
-                                                           const uint2* __restrict__ rects,
-                                                           uint2* __restrict__ rects_sorted,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __restrict__ rects_sorted,
                                                            uint32_t* __restrict__ offsets,
                                                            uint32_t* __restrict__ emit_start,
                                                            uint64_t* __restrict__ status,
@@ -108,20 +103,17 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
     // the index loads, 64 B for the stores) this kernel took 176 us on 5 M splats; the look-back was not the problem.
     __shared__ uint32_t s_cnt[BIN_ITEMS + BIN_ITEMS / 32];
     auto pad = [](uint32_t i) -> uint32_t { return i + (i >> 5); };  // blocked reads: stride IPT words -> skew the banks
-    uint2 r[BIN_IPT];
     uint32_t cnt[BIN_IPT];
-    uint32_t sidx[BIN_IPT];
+    uint32_t r[BIN_IPT];
 #pragma unroll
     for (int k = 0; k < BIN_IPT; ++k) {
         const uint32_t i = base + k * BIN_THREADS + tid;
-        sidx[k] = sorted_idx[i < v ? i : v - 1u];
+        r[k] = rects_sorted[i < v ? i : v - 1u];
     }
 #pragma unroll
     for (int k = 0; k < BIN_IPT; ++k) {
         const uint32_t i = base + k * BIN_THREADS + tid;
-        r[k] = rects[sidx[k]];  // (the random 8-B gather: 7 of this kernel's 26 us on c2, 73 of 117 us on c3)
-        if (i >= v) r[k] = make_uint2(1u, 0u);
-        cnt[k] = rect_count(r[k]);
+        cnt[k] = i < v ? rect_tiles(r[k]) : 0u;
         s_cnt[pad(k * BIN_THREADS + tid)] = cnt[k];
     }
     __syncthreads();
@@ -161,7 +153,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
         const uint32_t i = base + k * BIN_THREADS + tid;
         if (i < v) {
             const uint32_t off = block_off + s_cnt[pad(k * BIN_THREADS + tid)];
-            rects_sorted[i] = r[k];
             offsets[i] = off;
             if (cnt[k]) {
                 // multiples of EMIT_TILE inside [off, off + cnt)
@@ -803,8 +794,8 @@ uint32_t bin_prefix_blocks(uint32_t max_points) {
 int launch_bin_prefix(const BinBuffers& b, hipStream_t stream) {
     const uint32_t blocks = bin_prefix_blocks(b.max_points);
     if (blocks == 0) return WS_OK;
-    hipLaunchKernelGGL(k_bin_prefix<BIN_IPT>, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.sorted_idx, b.rects,
-                           b.rects_sorted, b.offsets, b.emit_start, b.block_status, b.counters, b.entry_cap, b.epoch);
+    hipLaunchKernelGGL(k_bin_prefix<BIN_IPT>, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.rects_sorted, b.offsets,
+                       b.emit_start, b.block_status, b.counters, b.entry_cap, b.epoch);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }

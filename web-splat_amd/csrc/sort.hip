@@ -435,6 +435,489 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
     return WS_OK;
 }
 
+
+// =====================================================================================================================
+// Depth sort: three range-adaptive digit passes, two launches per pass (ws_internal.h, DepthSortScratch).
+// =====================================================================================================================
+struct DSortPlan {
+    uint32_t kmin;   // smallest key of the input: digits are taken from key - kmin
+    uint32_t w;      // digit width of all three passes, 4..11
+    uint32_t shift;  // pass * w
+    uint32_t mask;   // (1 << w) - 1
+    uint32_t nb;     // 1 << w bins
+};
+
+// The plan is a pure function of the key range K1 (or k_key_minmax) left in device memory: every workgroup of every
+// launch of the sort derives the same one.  nbits = bit length of (kmax - kmin); three passes of ceil(nbits / 3) bits.
+__device__ __forceinline__ DSortPlan dsort_plan(const uint32_t* __restrict__ key_range, int pass) {
+    uint32_t kmax = 0u, kmin_inv = 0u;
+#pragma unroll
+    for (int sl = 0; sl < KEY_RANGE_SLOTS; ++sl) {
+        kmax = max(kmax, key_range[sl * KEY_RANGE_STRIDE]);
+        kmin_inv = max(kmin_inv, key_range[sl * KEY_RANGE_STRIDE + 1]);
+    }
+    DSortPlan p;
+    p.kmin = ~kmin_inv;
+    const uint32_t range = kmax >= p.kmin ? kmax - p.kmin : 0u;  // (no keys at all: 0)
+    const uint32_t nbits = range ? 32u - (uint32_t)__clz((int)range) : 0u;
+    uint32_t w = (nbits + (uint32_t)DSORT_PASSES - 1u) / (uint32_t)DSORT_PASSES;
+    if (w < 4u) w = 4u;
+    p.w = w;
+    p.shift = (uint32_t)pass * w;
+    p.mask = (1u << w) - 1u;
+    p.nb = 1u << w;
+    return p;
+}
+
+// tiles are grouped for the cross-tile prefix: at most DSORT_MAX_GROUPS groups of `gt` consecutive tiles
+__device__ __forceinline__ uint32_t dsort_group_tiles(uint32_t ntiles) {
+    const uint32_t gt = (ntiles + (uint32_t)DSORT_MAX_GROUPS - 1u) / (uint32_t)DSORT_MAX_GROUPS;
+    return gt ? gt : 1u;
+}
+
+constexpr int DSORT_LB_WINDOW = 16;  // predecessor rows per look-back round trip
+
+// ---- k_dsort_hist: per-tile digit counts + the whole cross-tile prefix, one launch ------------------------------
+// One 1024-thread workgroup = one GROUP of gt consecutive tiles (group ids from an atomic ticket: a workgroup only ever
+// waits for groups that already run).
+//   phase 1  every WAVE counts whole tiles on its own (tiles wave, wave + 16, ... of the group) into a wave-private
+//            LDS histogram of 16-bit counters -- no workgroup barrier inside the loop, sixteen tiles' loads in flight per
+//            CU -- and writes the raw counts to tile_off[t][.].
+//   phase 2  per digit: exclusive prefix over the group's tiles in place (tile_off[t][d] = digits d in the group's
+//            EARLIER tiles); the group's digit counts are published as epoch-tagged 64-bit words; the predecessors'
+//            words are summed (the groups start together, so all of them are published at about the same time: a few
+//            windows of independent loads, not a serial chain) into group_off[g][d]; the last group leaves the
+//            exclusive scan of the digit totals, the first output position of every digit.
+// The scatter kernel adds the three levels: totals[d] + group_off[g][d] + tile_off[t][d].
+constexpr int DH_THREADS = 1024;
+constexpr int DH_WAVES = DH_THREADS / 64;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* s_tmp /*[DH_WAVES]*/, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < DH_WAVES; ++w) {
+        const uint32_t c = s_tmp[w];
+        if (w < wave) wave_off += c;
+        tot += c;
+    }
+    __syncthreads();
+    if (total) *total = tot;
+    return wave_off + incl - v;
+}
+
+template <int KPT>
+__global__ __launch_bounds__(DH_THREADS) void k_dsort_hist(const uint32_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ d_count, uint32_t n, int pass,
+                                                          const uint32_t* __restrict__ key_range,
+                                                          uint32_t* __restrict__ tile_off,
+                                                          uint32_t* __restrict__ group_off,  // [groups][nb] of this pass
+                                                          uint64_t* __restrict__ status,     // [groups][nb] of this pass
+                                                          uint32_t* __restrict__ totals,     // [nb] of this pass: first output position of every digit
+                                                          uint32_t* __restrict__ ticket, uint32_t epoch,
+                                                          uint32_t* __restrict__ error_word) {
+    constexpr int TILE_N = SORT_THREADS * KPT;
+    constexpr int QPL = TILE_N / 256;                      // 16-byte key quads per lane and tile
+    constexpr int MAX_DPT = DSORT_MAX_BINS / DH_THREADS;   // digits per thread in phase 2 (2 at 2048 bins)
+    __shared__ uint32_t s_cnt[DH_WAVES][DSORT_MAX_BINS / 2];  // wave-private, two 16-bit counters per word (a tile has < 65536 keys)
+    __shared__ uint32_t s_group;
+    __shared__ uint32_t s_tmp[DH_WAVES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t count = device_count(d_count, n);
+    if (count == 0u) return;
+    const uint32_t ntiles = (count + TILE_N - 1) / TILE_N;
+    const uint32_t gt = dsort_group_tiles(ntiles);
+    const uint32_t ngroups = (ntiles + gt - 1u) / gt;
+    if (blockIdx.x >= ngroups) return;  // surplus workgroups leave before drawing a ticket
+    if (tid == 0) s_group = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t g = s_group;
+    const DSortPlan pl = dsort_plan(key_range, pass);
+    const uint32_t nb = pl.nb;
+
+    // ---- phase 1: whole tiles per wave ---------------------------------------------------------------------
+    uint32_t* cnt = s_cnt[wave];
+    const uint4* keys4 = reinterpret_cast<const uint4*>(keys);
+    for (uint32_t ti = (uint32_t)wave; ti < gt; ti += DH_WAVES) {
+        const uint32_t t = g * gt + ti;
+        if (t >= ntiles) break;  // wave-uniform
+        for (uint32_t i = lane; i < nb / 2u; i += 64u) cnt[i] = 0u;
+        const uint32_t base = t * TILE_N;
+        uint4 q[QPL];
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) {
+            const uint32_t p4 = base + (uint32_t)(j * 64 + lane) * 4u;
+            if (p4 + 3u < count) {
+                q[j] = keys4[p4 >> 2];
+            } else {  // the last, partial quad(s) of the input
+                q[j].x = p4 < count ? keys[p4] : 0u;
+                q[j].y = p4 + 1u < count ? keys[p4 + 1u] : 0u;
+                q[j].z = p4 + 2u < count ? keys[p4 + 2u] : 0u;
+                q[j].w = 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) {
+            const uint32_t p4 = base + (uint32_t)(j * 64 + lane) * 4u;
+            const uint32_t kk[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (p4 + (uint32_t)e < count) {
+                    const uint32_t d = ((kk[e] - pl.kmin) >> pl.shift) & pl.mask;
+                    atomicAdd(&cnt[d >> 1], 1u << ((d & 1u) * 16u));
+                }
+            }
+        }
+        // raw counts of the tile (LDS operations of one wave execute in order: no barrier needed)
+        uint2* row = reinterpret_cast<uint2*>(tile_off + (size_t)t * nb);
+        for (uint32_t i = lane; i < nb / 2u; i += 64u) {
+            const uint32_t wv = cnt[i];
+            row[i] = make_uint2(wv & 0xFFFFu, wv >> 16);
+        }
+    }
+    __syncthreads();  // workgroup-scope release / acquire: phase 2 reads what the other waves just stored
+
+    // ---- phase 2: thread owns digits tid, tid + 1024 ----------------------------------------------------------
+    const uint32_t t_first = g * gt;
+    const uint32_t t_end = (t_first + gt) < ntiles ? (t_first + gt) : ntiles;
+    uint32_t run[MAX_DPT];
+#pragma unroll
+    for (int j = 0; j < MAX_DPT; ++j) {
+        const uint32_t d = (uint32_t)tid + (uint32_t)j * DH_THREADS;
+        run[j] = 0u;
+        if (d < nb) {
+            uint32_t acc = 0u;
+            for (uint32_t t = t_first; t < t_end; t += 8u) {  // eight independent loads in flight
+                uint32_t c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) c[u] = (t + u < t_end) ? tile_off[(size_t)(t + u) * nb + d] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (t + u < t_end) tile_off[(size_t)(t + u) * nb + d] = acc;
+                    acc += c[u];
+                }
+            }
+            run[j] = acc;
+            // publish first, look back afterwards: successors can use the aggregate at once
+            lb::st(status + (size_t)g * nb + d, lb::pack(epoch, g == 0u ? lb::FLAG_INCL : lb::FLAG_AGG, acc));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAX_DPT; ++j) {
+        const uint32_t d = (uint32_t)tid + (uint32_t)j * DH_THREADS;
+        if (d >= nb) continue;
+        uint32_t prev_sum = 0u;
+        if (g > 0u) {
+            int64_t i = (int64_t)g - 1;  // next predecessor to consume
+            uint32_t spins = 0u;
+            bool done = false;
+            while (!done) {
+                uint64_t wv[DSORT_LB_WINDOW];
+#pragma unroll
+                for (int q2 = 0; q2 < DSORT_LB_WINDOW; ++q2) {
+                    const int64_t idx = i - q2;
+                    wv[q2] = idx >= 0 ? lb::ld(status + (size_t)idx * nb + d) : lb::pack(epoch, lb::FLAG_INCL, 0u);
+                }
+                int consumed = 0;
+#pragma unroll
+                for (int q2 = 0; q2 < DSORT_LB_WINDOW; ++q2) {
+                    if (done || consumed < q2) continue;  // stop at the first unpublished word
+                    const uint32_t flag = lb::flag_of(wv[q2], epoch);
+                    if (flag == 0u) continue;
+                    prev_sum += lb::value_of(wv[q2]);
+                    consumed = q2 + 1;
+                    if (flag == lb::FLAG_INCL) done = true;
+                }
+                i -= consumed;
+                if (!done && consumed < DSORT_LB_WINDOW) {
+                    if (++spins > lb::SPIN_LIMIT) {
+                        if (error_word) atomicOr(error_word, 8u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            lb::st(status + (size_t)g * nb + d, lb::pack(epoch, lb::FLAG_INCL, prev_sum + run[j]));
+        }
+        group_off[(size_t)g * nb + d] = prev_sum;
+        run[j] += prev_sum;  // in the last group: the total count of digit d
+    }
+    // The last group knows the digit totals of the pass: it leaves their exclusive scan, the first output position of
+    // every digit (one workgroup does it once instead of every scatter workgroup redoing it).
+    if (g == ngroups - 1u) {  // block-uniform
+        uint32_t carry = 0u;
+#pragma unroll
+        for (int j = 0; j < MAX_DPT; ++j) {
+            const uint32_t d = (uint32_t)tid + (uint32_t)j * DH_THREADS;
+            const uint32_t c = d < nb ? run[j] : 0u;
+            uint32_t total;
+            const uint32_t ex = block_exclusive_scan_1024(c, s_tmp, &total) + carry;
+            if (d < nb) totals[d] = ex;
+            carry += total;
+        }
+    }
+}
+
+// ---- k_dsort_scatter: one digit pass -------------------------------------------------------------------------------
+// The ranking of k_sort_scatter (wave64 ballots, one leader lane per distinct digit bumps the wave's LDS counter) with a
+// RUN-TIME digit width: up to 2048 bins.  To keep five-ish workgroups per CU at that size the per-wave counters are 16 bit
+// (a wave holds at most 64 * KPT keys; LDS atomics work on the containing 32-bit word) and share their LDS with the
+// reorder buffers (they are dead by the time the pairs move), at the price of one more barrier per tile.
+// CARRY: a 4-byte companion value travels with the payload (the splat's packed tile rectangle).
+#ifndef WS_DSORT_MINWAVES
+#define WS_DSORT_MINWAVES 1
+#endif
+template <int KPT, bool CARRY>
+__global__ __launch_bounds__(SORT_THREADS, WS_DSORT_MINWAVES) void k_dsort_scatter(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, const uint32_t* __restrict__ aux_in,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t* __restrict__ aux_out,
+    const uint32_t* __restrict__ d_count, uint32_t n, int pass, int iota, const uint32_t* __restrict__ key_range,
+    const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ group_off, const uint32_t* __restrict__ totals) {
+    constexpr int TILE_N = SORT_THREADS * KPT;
+    constexpr int POOL_PAIRS = TILE_N * (CARRY ? 3 : 2);
+    constexpr int POOL_WORDS = POOL_PAIRS > WAVES * DSORT_MAX_BINS / 2 ? POOL_PAIRS : WAVES * DSORT_MAX_BINS / 2;
+    __shared__ uint32_t s_pool[POOL_WORDS];           // per-wave 16-bit digit counters, later the reorder buffers
+    __shared__ uint16_t s_local_excl[DSORT_MAX_BINS];  // first position of digit d inside the LDS-ordered tile
+    __shared__ uint32_t s_global_base[DSORT_MAX_BINS]; // + tile-local position = output address
+    __shared__ uint32_t s_tmp[WAVES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t count = device_count(d_count, n);
+    if (count == 0u) return;
+    const DSortPlan pl = dsort_plan(key_range, pass);
+    const uint32_t nb = pl.nb;
+    const uint32_t dpt = nb > (uint32_t)SORT_THREADS ? nb / SORT_THREADS : 1u;  // digits per thread: tid, tid + 256, ...
+    const uint32_t ntiles = (count + TILE_N - 1) / TILE_N;
+    const uint32_t gt = dsort_group_tiles(ntiles);
+    uint16_t* wh = reinterpret_cast<uint16_t*>(s_pool);  // [WAVES][nb]
+    uint32_t* s_keys = s_pool;
+    uint32_t* s_vals = s_pool + TILE_N;
+    uint32_t* s_aux = s_pool + 2 * TILE_N;
+    const uint32_t lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xFFFFFFFFu;
+    const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
+
+    for (uint32_t L = blockIdx.x; (L >> 3) < ((ntiles + 7u) >> 3); L += gridDim.x) {
+        uint32_t t;
+        if (!xcd_tile(L, ntiles, &t)) continue;  // block-uniform
+        const uint32_t tile_base = t * TILE_N;
+        const uint32_t valid = (count - tile_base) < (uint32_t)TILE_N ? (count - tile_base) : (uint32_t)TILE_N;
+        const uint32_t g = t / gt;
+
+        // ---- load (wave-striped: order = (wave, j, lane) = position order); keys become key - kmin, padding sorts last
+        uint32_t nk[KPT];
+        const uint32_t wave_base = tile_base + wave * (64 * KPT) + lane;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t pos = wave_base + j * 64;
+            nk[j] = pos < count ? keys_in[pos] - pl.kmin : 0xFFFFFFFFu;
+        }
+        // output offset of digit `tid` = first position of the digit + digits in earlier groups + in earlier tiles of
+        // the group (issued early: needed only after the ranking; the digits tid + 256, ... of wider passes are loaded below)
+        uint32_t off0 = 0u;
+        if ((uint32_t)tid < nb) off0 = totals[tid] + tile_off[(size_t)t * nb + tid] + group_off[(size_t)g * nb + tid];
+        for (uint32_t i = tid; i < (uint32_t)WAVES * nb / 2u; i += SORT_THREADS) s_pool[i] = 0u;
+        __syncthreads();
+
+        // ---- rank inside the wave (see k_sort_scatter): ballots over the w digit bits, leaders bump the counters
+        uint32_t info[KPT];  // below | leader << 8 | count << 16 (count only on the leader lane, else 0)
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t d = (nk[j] >> pl.shift) & pl.mask;
+            uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
+            for (uint32_t bit = 0; bit < pl.w; ++bit) {
+                const uint32_t B = (uint32_t)(-(int32_t)((d >> bit) & 1u));  // all ones if the bit is set
+                const unsigned long long bal = __ballot(B != 0u);
+                mlo &= ~((uint32_t)bal ^ B);
+                mhi &= ~((uint32_t)(bal >> 32) ^ B);
+            }
+            const uint32_t below = (uint32_t)__popc(mlo & lt_lo) + (uint32_t)__popc(mhi & lt_hi);
+            const uint32_t leader = mlo ? (uint32_t)(__ffs((int)mlo) - 1) : 32u + (uint32_t)(__ffs((int)mhi) - 1);
+            const uint32_t cnt = (below == 0u) ? (uint32_t)(__popc(mlo) + __popc(mhi)) : 0u;  // below == 0 <=> leader
+            info[j] = below | (leader << 8) | (cnt << 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t prev[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t d = (nk[j] >> pl.shift) & pl.mask;
+            prev[j] = 0u;
+            if (info[j] >> 16) {
+                const uint32_t sft = (d & 1u) * 16u;
+                const uint32_t old = atomicAdd(&s_pool[((uint32_t)wave * nb + d) >> 1], (info[j] >> 16) << sft);
+                prev[j] = (old >> sft) & 0xFFFFu;
+            }
+        }
+        uint32_t rank[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) rank[j] = __shfl(prev[j], (int)((info[j] >> 8) & 63u), 64) + (info[j] & 63u);
+        // payload (and companion) are loaded only now -- the ballots above are the register peak of this kernel -- and
+        // are in flight during the per-digit phase below (the scheduling barrier keeps the compiler from hoisting them)
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t val[KPT], aux[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t pos = wave_base + j * 64;
+            val[j] = iota ? pos : (pos < count ? vals_in[pos] : 0u);
+            aux[j] = (CARRY && pos < count) ? aux_in[pos] : 0u;
+        }
+        __syncthreads();
+
+        // ---- per digit (thread tid owns digits tid, tid + 256, ...): prefix over the waves, count in the tile, position
+        // of the digit's run in the LDS-ordered tile and in the output.  One block scan per 256 digits, carried on.
+        uint32_t carry = 0u;
+        for (uint32_t j = 0; j < dpt; ++j) {
+            const uint32_t d = (uint32_t)tid + j * SORT_THREADS;
+            uint32_t off = off0;
+            if (j > 0u) off = totals[d] + tile_off[(size_t)t * nb + d] + group_off[(size_t)g * nb + d];
+            uint32_t tile_cnt = 0u;
+            if (d < nb) {
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) {
+                    const uint32_t c = wh[(uint32_t)w * nb + d];
+                    wh[(uint32_t)w * nb + d] = (uint16_t)tile_cnt;
+                    tile_cnt += c;
+                }
+            }
+            uint32_t total;
+            const uint32_t ex = block_exclusive_scan(tile_cnt, s_tmp, &total) + carry;
+            if (d < nb) {
+                s_local_excl[d] = (uint16_t)ex;
+                s_global_base[d] = off - ex;
+            }
+            carry += total;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {  // rank -> position in the LDS-ordered tile
+            const uint32_t d = (nk[j] >> pl.shift) & pl.mask;
+            rank[j] += (uint32_t)s_local_excl[d] + (uint32_t)wh[(uint32_t)wave * nb + d];
+        }
+        __syncthreads();  // the counters are dead: their LDS becomes the reorder buffers
+
+        // ---- reorder keys, payload (and companion) through LDS, write contiguous digit runs
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            s_keys[rank[j]] = nk[j];
+            s_vals[rank[j]] = val[j];
+            if (CARRY) s_aux[rank[j]] = aux[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t lp = k * SORT_THREADS + tid;
+            const uint32_t kk = s_keys[lp];
+            const uint32_t gpos = s_global_base[(kk >> pl.shift) & pl.mask] + lp;
+            if (lp < valid) {
+                keys_out[gpos] = kk + pl.kmin;
+                vals_out[gpos] = s_vals[lp];
+                if (CARRY) aux_out[gpos] = s_aux[lp];
+            }
+        }
+        __syncthreads();  // LDS is reused by the next tile
+    }
+}
+
+// key range of arbitrary input (stand-alone sorter in depth mode): the same table K1 fills
+__global__ __launch_bounds__(SORT_THREADS) void k_key_minmax(const uint32_t* __restrict__ keys,
+                                                            const uint32_t* __restrict__ d_count, uint32_t n,
+                                                            uint32_t* __restrict__ key_range) {
+    __shared__ uint32_t s_max[WAVES], s_min_inv[WAVES];
+    const uint32_t count = device_count(d_count, n);
+    uint32_t kmax = 0u, kmin_inv = 0u;
+    bool any = false;
+    for (uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x; i < count; i += gridDim.x * SORT_THREADS) {
+        const uint32_t k = keys[i];
+        kmax = max(kmax, k);
+        kmin_inv = max(kmin_inv, ~k);
+        any = true;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+        kmin_inv = max(kmin_inv, (uint32_t)__shfl_xor((int)kmin_inv, o, 64));
+    }
+    const bool wave_any = __ballot(any) != 0ull;
+    if ((threadIdx.x & 63) == 0) {
+        s_max[threadIdx.x >> 6] = wave_any ? kmax : 0u;
+        s_min_inv[threadIdx.x >> 6] = wave_any ? kmin_inv : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0u, b = 0u;
+        for (int w = 0; w < WAVES; ++w) {
+            a = max(a, s_max[w]);
+            b = max(b, s_min_inv[w]);
+        }
+        if (a | b) {
+            uint32_t* kr = key_range + (blockIdx.x & (KEY_RANGE_SLOTS - 1)) * KEY_RANGE_STRIDE;
+            atomicMax(kr, a);
+            atomicMax(kr + 1, b);
+        }
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx,
+                                                            const uint32_t* __restrict__ d_count, uint32_t n,
+                                                            uint32_t* __restrict__ out) {
+    const uint32_t count = device_count(d_count, n);
+    for (uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x; i < count; i += gridDim.x * SORT_THREADS) out[i] = src[idx[i]];
+}
+
+// dst[i] = src[i] for i < count, up to three arrays at once (the stand-alone depth sort brings its result home)
+__global__ __launch_bounds__(SORT_THREADS) void k_copy_counted(const uint32_t* __restrict__ s0, uint32_t* __restrict__ d0,
+                                                              const uint32_t* __restrict__ s1, uint32_t* __restrict__ d1,
+                                                              const uint32_t* __restrict__ s2, uint32_t* __restrict__ d2,
+                                                              const uint32_t* __restrict__ d_count, uint32_t n) {
+    const uint32_t count = device_count(d_count, n);
+    for (uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x; i < count; i += gridDim.x * SORT_THREADS) {
+        d0[i] = s0[i];
+        d1[i] = s1[i];
+        if (s2) d2[i] = s2[i];
+    }
+}
+
+template <int KPT>
+int run_depth_sort(const DepthSortScratch& sc, uint32_t* keys, uint32_t* vals, uint32_t* aux, const uint32_t* d_count,
+                   uint32_t n, bool implicit_iota, uint32_t epoch, hipStream_t stream, KernelMarks* km) {
+    constexpr uint32_t TILE_N = SORT_THREADS * KPT;
+    const uint32_t tiles = sort_grid((n + TILE_N - 1) / TILE_N);
+    const size_t gw = (size_t)DSORT_MAX_GROUPS * DSORT_MAX_BINS;
+    uint32_t *kin = keys, *vin = vals, *ain = aux;
+    uint32_t *kout = sc.keys_alt, *vout = sc.vals_alt, *aout = sc.aux_alt;
+    for (int p = 0; p < DSORT_PASSES; ++p) {
+        hipLaunchKernelGGL(k_dsort_hist<KPT>, dim3(DSORT_MAX_GROUPS), dim3(DH_THREADS), 0, stream, kin, d_count, n, p,
+                           sc.key_range, sc.tile_off, sc.group_off + p * gw, sc.status + p * gw,
+                           sc.totals + (size_t)p * DSORT_MAX_BINS, sc.tickets + p, epoch, sc.error);
+        km_mark(km, "depth:k_dsort_hist");
+        const int iota = (implicit_iota && p == 0) ? 1 : 0;
+        if (aux)
+            hipLaunchKernelGGL((k_dsort_scatter<KPT, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, ain, kout,
+                               vout, aout, d_count, n, p, iota, sc.key_range, sc.tile_off, sc.group_off + p * gw,
+                               sc.totals + (size_t)p * DSORT_MAX_BINS);
+        else
+            hipLaunchKernelGGL((k_dsort_scatter<KPT, false>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
+                               (const uint32_t*)nullptr, kout, vout, (uint32_t*)nullptr, d_count, n, p, iota, sc.key_range,
+                               sc.tile_off, sc.group_off + p * gw, sc.totals + (size_t)p * DSORT_MAX_BINS);
+        km_mark(km, "depth:k_dsort_scatter");
+        WS_HIP(hipGetLastError());
+        uint32_t* t0 = kin; kin = kout; kout = t0;
+        uint32_t* t1 = vin; vin = vout; vout = t1;
+        uint32_t* t2 = ain; ain = aout; aout = t2;
+    }
+    return WS_OK;
+}
+
 }  // namespace
 
 // Grid cap of the tile-strided kernels: 8 workgroups per CU on a 256-CU part; enough to fill the chip at any
@@ -446,6 +929,54 @@ uint32_t sort_grid(uint32_t tiles) {
 }
 
 uint32_t sort_tile_size(uint32_t n) { return n <= SORT_SMALL_MAX ? SORT_THREADS * SORT_KPT_SMALL : SORT_TILE; }
+
+size_t depth_sort_tile_off_words(uint32_t cap) {
+    const uint32_t small_n = cap < SORT_SMALL_MAX ? cap : SORT_SMALL_MAX;
+    const uint32_t small_tiles = (small_n + SORT_THREADS * SORT_KPT_SMALL - 1) / (SORT_THREADS * SORT_KPT_SMALL);
+    const uint32_t big_tiles = (cap + SORT_TILE - 1) / SORT_TILE;
+    const uint32_t tiles = (small_tiles > big_tiles ? small_tiles : big_tiles) + 1u;
+    return (size_t)tiles * DSORT_MAX_BINS;
+}
+size_t depth_sort_group_words() { return (size_t)DSORT_PASSES * DSORT_MAX_GROUPS * DSORT_MAX_BINS; }
+
+int launch_depth_sort(const DepthSortScratch& sc, uint32_t* keys, uint32_t* vals, uint32_t* aux, const uint32_t* d_count,
+                      uint32_t n, bool implicit_iota, uint32_t epoch, hipStream_t stream, KernelMarks* km) {
+    if (n == 0) return WS_OK;
+    if (n > sc.cap) return fail(WS_ERR_INVALID, "depth sort: n exceeds the scratch capacity");
+    if (aux && !sc.aux_alt) return fail(WS_ERR_INVALID, "depth sort: companion values without a companion scratch buffer");
+    if (sort_tile_size(n) == SORT_TILE)
+        return run_depth_sort<SORT_KPT>(sc, keys, vals, aux, d_count, n, implicit_iota, epoch, stream, km);
+    return run_depth_sort<SORT_KPT_SMALL>(sc, keys, vals, aux, d_count, n, implicit_iota, epoch, stream, km);
+}
+
+int launch_copy_counted(const uint32_t* s0, uint32_t* d0, const uint32_t* s1, uint32_t* d1, const uint32_t* s2, uint32_t* d2,
+                        const uint32_t* d_count, uint32_t n, hipStream_t stream) {
+    if (n == 0) return WS_OK;
+    uint32_t blocks = (n + SORT_THREADS * 4 - 1) / (SORT_THREADS * 4);
+    if (blocks > 2048u) blocks = 2048u;
+    hipLaunchKernelGGL(k_copy_counted, dim3(blocks), dim3(SORT_THREADS), 0, stream, s0, d0, s1, d1, s2, d2, d_count, n);
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
+int launch_gather_u32(const uint32_t* src, const uint32_t* idx, const uint32_t* d_count, uint32_t n, uint32_t* out,
+                      hipStream_t stream) {
+    if (n == 0) return WS_OK;
+    uint32_t blocks = (n + SORT_THREADS * 4 - 1) / (SORT_THREADS * 4);
+    if (blocks > 2048u) blocks = 2048u;
+    hipLaunchKernelGGL(k_gather_u32, dim3(blocks), dim3(SORT_THREADS), 0, stream, src, idx, d_count, n, out);
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
+int launch_key_minmax(const uint32_t* keys, const uint32_t* d_count, uint32_t n, uint32_t* key_range, hipStream_t stream) {
+    if (n == 0) return WS_OK;
+    uint32_t blocks = (n + SORT_THREADS * 16 - 1) / (SORT_THREADS * 16);
+    if (blocks > 1024u) blocks = 1024u;
+    hipLaunchKernelGGL(k_key_minmax, dim3(blocks), dim3(SORT_THREADS), 0, stream, keys, d_count, n, key_range);
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
 
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,

@@ -80,11 +80,14 @@ struct SorterZero {
     uint32_t error;
     uint32_t _pad[3];
     uint32_t hist[4 * RADIX];
+    uint32_t key_range[KEY_RANGE_SLOTS * KEY_RANGE_STRIDE];  // depth mode: filled by k_key_minmax
 };
 
 struct ws_sorter {
     ws_context* ctx = nullptr;
     SortScratch sc;
+    DepthSortScratch ds;   // ws_sorter_sort_depth
+    uint32_t* aux_alt = nullptr;
     SorterZero* zero = nullptr;
     uint32_t epoch = 0;
 };
@@ -100,8 +103,7 @@ struct ws_renderer {
     uint32_t vw = 0, vh = 0, tiles_x = 0, tiles_y = 0;
     uint64_t entry_cap_request = 0;
     uint32_t entry_cap = 0;
-    uint2* rects = nullptr;
-    uint2* rects_sorted = nullptr;
+    uint32_t *rects_a = nullptr, *rects_b = nullptr;  // packed tile rectangles: store order / ping-pong of the depth sort
     uint8_t* splats = nullptr;      // Splat[N], 20 B each (pointcloud.rs:103-108 allocates it in PointCloud;
                                     // here it is per renderer so that renderers never share scratch)
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
@@ -116,6 +118,8 @@ struct ws_renderer {
     uint2* tile_ranges = nullptr;    // inside the zero arena
     FrameCounters* counters = nullptr;  // = &zero->counters
     SortScratch sort_depth, sort_tiles;
+    DepthSortScratch dsort;          // range-adaptive three-pass depth sort (the default; WS_DEPTH_SORT=classic: sort_depth)
+    uint32_t* rects_sorted = nullptr;  // where the last frame's draw-ordered rectangles are
     uint32_t epoch = 0;
     uint32_t* sticky = nullptr;      // device error word that survives the per-frame memset (ws_renderer_errors)
 
@@ -123,6 +127,7 @@ struct ws_renderer {
     bool prepared = false;
     const ws_pointcloud* prepared_pc = nullptr;
     uint32_t* sorted_idx = nullptr;
+    uint32_t* sorted_keys = nullptr;
     uint32_t* entries_sorted = nullptr;
     hipStream_t last_stream = nullptr;
 
@@ -172,8 +177,13 @@ static void renderer_free_scratch(ws_renderer* r) {
     dfree(r->keys_b);
     dfree(r->vals_a);
     dfree(r->vals_b);
-    dfree(r->rects);
-    dfree(r->rects_sorted);
+    dfree(r->rects_a);
+    dfree(r->rects_b);
+    dfree(r->dsort.tile_off);
+    dfree(r->dsort.group_off);
+    dfree(r->dsort.status);
+    dfree(r->dsort.totals);
+    r->dsort = DepthSortScratch();
     dfree(r->src_index);
     dfree(r->k1_status);
     dfree(r->bin_status);
@@ -218,8 +228,8 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     if ((rc = dmalloc(&r->keys_b, np))) return rc;
     if ((rc = dmalloc(&r->vals_a, np))) return rc;
     if ((rc = dmalloc(&r->vals_b, np))) return rc;
-    if ((rc = dmalloc(&r->rects, np))) return rc;
-    if ((rc = dmalloc(&r->rects_sorted, np))) return rc;
+    if ((rc = dmalloc(&r->rects_a, np))) return rc;
+    if ((rc = dmalloc(&r->rects_b, np))) return rc;
     if ((rc = dmalloc(&r->src_index, np))) return rc;
     if ((rc = dmalloc(&r->bin_offsets, np))) return rc;
     const size_t k1_words = (size_t)preprocess_blocks(n) + 1, bin_words = (size_t)bin_prefix_blocks(n) + 1;
@@ -257,6 +267,22 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     r->sort_tiles.tickets = r->counters->sort_ticket + 4;
     r->sort_depth.error = &r->counters->overflow;
     r->sort_tiles.error = &r->counters->overflow;
+    {  // depth sort scratch: per-tile / per-group digit offsets, look-back words (zeroed once; epoch-tagged afterwards)
+        DepthSortScratch& ds = r->dsort;
+        ds.cap = n ? n : 1;
+        const size_t gw = depth_sort_group_words();
+        if ((rc = dmalloc(&ds.tile_off, depth_sort_tile_off_words(ds.cap)))) return rc;
+        if ((rc = dmalloc(&ds.group_off, gw))) return rc;
+        if ((rc = dmalloc(&ds.status, gw))) return rc;
+        if ((rc = dmalloc(&ds.totals, (size_t)DSORT_PASSES * DSORT_MAX_BINS))) return rc;
+        WS_HIP(hipMemset(ds.status, 0, gw * sizeof(uint64_t)));
+        ds.keys_alt = r->keys_b;
+        ds.vals_alt = r->vals_b;
+        ds.aux_alt = r->rects_b;
+        ds.key_range = r->zero->key_range;
+        ds.tickets = r->counters->sort_ticket;  // [0..2]; the tile sort uses [4..7]
+        ds.error = &r->counters->overflow;
+    }
     r->cap_points = n;
     r->vw = vw;
     r->vh = vh;
@@ -289,6 +315,8 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->device = hip_device;
     WS_HIP(hipGetDeviceProperties(&ctx->props, hip_device));
     ctx->sort_algo = env_int("WS_SORT_ALGO", 0);
+    if (const char* ds = std::getenv("WS_DEPTH_SORT")) ctx->depth_sort_classic = std::strcmp(ds, "classic") == 0;
+    if (ctx->sort_algo == 1) ctx->depth_sort_classic = true;  // the one-sweep cross-check path is a generic-sorter path
     ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
     ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
@@ -652,9 +680,12 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     if (!r || !pc || !args) return fail(WS_ERR_INVALID, "ws_renderer_prepare: null argument");
     if (pc->compressed != r->compressed)
         return fail(WS_ERR_INVALID, "ws_renderer_prepare: renderer and point cloud disagree on `compressed`");
-    if (args->viewport[0] == 0 || args->viewport[1] == 0 || args->viewport[0] > 65535u * QUAD * r->ctx->tile_qw ||
-        args->viewport[1] > 65535u * QUAD * r->ctx->tile_qh)
-        return fail(WS_ERR_INVALID, "ws_renderer_prepare: bad viewport");
+    // a splat's tile rectangle is packed into 4 bytes (ws_internal.h): at most 256 binning tiles per axis = 8192 px with
+    // the default 32-px tile -- the default wgpu max_texture_dimension_2d of the reference's render targets
+    if (args->viewport[0] == 0 || args->viewport[1] == 0 ||
+        args->viewport[0] > RECT_MAX_TILES_PER_AXIS * QUAD * r->ctx->tile_qw ||
+        args->viewport[1] > RECT_MAX_TILES_PER_AXIS * QUAD * r->ctx->tile_qh)
+        return fail(WS_ERR_INVALID, "ws_renderer_prepare: bad viewport (at most 256 binning tiles per axis: 8192 px at 32-px tiles)");
     if (args->max_sh_deg > 3) return fail(WS_ERR_UNSUPPORTED, "ws_renderer_prepare: max_sh_deg > 3");
     if (!pc->compressed && args->max_sh_deg > pc->sh_deg) {
         // the 96-B record always holds 16 coefficients (zeros above the file's degree): harmless, as in the reference
@@ -696,7 +727,8 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     kb.covars = pc->covars;
     kb.splats = r->splats;
     kb.keys = r->keys_a;
-    kb.rects = r->rects;
+    kb.rects = r->rects_a;
+    kb.key_range = r->zero->key_range;
     kb.src_index = r->capture ? r->src_index : nullptr;
     kb.block_status = r->k1_status;
     kb.counters = r->counters;
@@ -705,6 +737,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     if (++r->epoch == 0) {
         WS_HIP(hipMemsetAsync(r->k1_status, 0, ((size_t)preprocess_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
         WS_HIP(hipMemsetAsync(r->bin_status, 0, ((size_t)bin_prefix_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
+        WS_HIP(hipMemsetAsync(r->dsort.status, 0, depth_sort_group_words() * sizeof(uint64_t), stream));
         if (r->ctx->sort_algo == 1) {
             WS_HIP(hipMemsetAsync(r->sort_depth.status, 0, 4 * (size_t)r->sort_depth.tiles * RADIX * sizeof(uint64_t), stream));
             WS_HIP(hipMemsetAsync(r->sort_tiles.status, 0, 4 * (size_t)r->sort_tiles.tiles * RADIX * sizeof(uint64_t), stream));
@@ -733,12 +766,27 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         r->last_stream = stream;
         return WS_OK;
     }
-    // depth sort: V (key, store index) pairs, 4 x 8 bit, values start as iota (preprocess.wgsl:274)
-    uint32_t *sk = nullptr, *sv = nullptr;
-    if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
-                                true, false, r->ctx->sort_algo, r->epoch, stream, &sk, &sv, km, "depth:")))
-        return rc;
-    r->sorted_idx = sv;
+    // depth sort: V (key, store index) pairs, values start as iota (preprocess.wgsl:274), the packed tile rectangle
+    // rides along.  Default: three range-adaptive digit passes (launch_depth_sort); WS_DEPTH_SORT=classic: the generic
+    // 4 x 8-bit sorter (GPURSSorter's shape), after which the rectangles are gathered into draw order.
+    if (r->ctx->depth_sort_classic) {
+        uint32_t *sk = nullptr, *sv = nullptr;
+        if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
+                                    true, false, r->ctx->sort_algo, r->epoch, stream, &sk, &sv, km, "depth:")))
+            return rc;
+        r->sorted_idx = sv;
+        r->sorted_keys = sk;
+        if ((rc = launch_gather_u32(r->rects_a, sv, &r->counters->num_visible, pc->num_points, r->rects_b, stream))) return rc;
+        km_mark(km, "k_gather_rects");
+        r->rects_sorted = r->rects_b;
+    } else {
+        if ((rc = launch_depth_sort(r->dsort, r->keys_a, r->vals_a, r->rects_a, &r->counters->num_visible, pc->num_points,
+                                    true, r->epoch, stream, km)))
+            return rc;
+        r->sorted_idx = r->vals_b;    // three passes: A -> B -> A -> B
+        r->sorted_keys = r->keys_b;
+        r->rects_sorted = r->rects_b;
+    }
     if (r->timers) WS_HIP(hipEventRecord(r->ev[2], stream));
     if (cut == 2) {  // analysis only (WS_DEBUG_CUT): the image is NOT produced
         r->prepared = true;
@@ -750,7 +798,6 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     // tile binning
     BinBuffers bb;
     bb.sorted_idx = r->sorted_idx;
-    bb.rects = r->rects;
     bb.rects_sorted = r->rects_sorted;
     bb.offsets = r->bin_offsets;
     bb.emit_start = r->emit_start;
@@ -998,8 +1045,7 @@ int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, 
         // the sort permutes the keys in place; un-permute them with the sorted indices so that the caller
         // gets keys in STORE order (what preprocess wrote)
         std::vector<uint32_t> ks(v), idx(v);
-        uint32_t* sorted_keys = (r->sorted_idx == r->vals_a) ? r->keys_a : r->keys_b;
-        WS_HIP(hipMemcpy(ks.data(), sorted_keys, (size_t)v * 4, hipMemcpyDeviceToHost));
+        WS_HIP(hipMemcpy(ks.data(), r->sorted_keys, (size_t)v * 4, hipMemcpyDeviceToHost));
         WS_HIP(hipMemcpy(idx.data(), r->sorted_idx, (size_t)v * 4, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < v; ++i)
             if (idx[i] < v) keys[idx[i]] = ks[i];
@@ -1022,6 +1068,22 @@ int ws_sorter_create(ws_context* ctx, uint32_t max_n, ws_sorter** out) {
         s->sc.tickets = s->zero->tickets;
         s->sc.error = &s->zero->error;
         s->sc.hist = s->zero->hist;
+        DepthSortScratch& ds = s->ds;
+        ds.cap = max_n;
+        const size_t gw = depth_sort_group_words();
+        rc = dmalloc(&ds.tile_off, depth_sort_tile_off_words(max_n));
+        if (rc == WS_OK) rc = dmalloc(&ds.group_off, gw);
+        if (rc == WS_OK) rc = dmalloc(&ds.status, gw);
+        if (rc == WS_OK) rc = dmalloc(&ds.totals, (size_t)DSORT_PASSES * DSORT_MAX_BINS);
+        if (rc == WS_OK) rc = dmalloc(&s->aux_alt, (size_t)max_n + 4);
+        if (rc == WS_OK && (hipMemset(ds.status, 0, gw * sizeof(uint64_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess))
+            rc = fail(WS_ERR_HIP, "ws_sorter_create: look-back word initialisation failed");
+        ds.keys_alt = s->sc.keys_alt;
+        ds.vals_alt = s->sc.vals_alt;
+        ds.aux_alt = s->aux_alt;
+        ds.key_range = s->zero->key_range;
+        ds.tickets = s->zero->tickets;
+        ds.error = &s->zero->error;
     }
     if (rc != WS_OK) {
         ws_sorter_destroy(s);
@@ -1035,6 +1097,11 @@ void ws_sorter_destroy(ws_sorter* s) {
     if (!s) return;
     (void)hipDeviceSynchronize();
     dfree(s->zero);
+    dfree(s->ds.tile_off);
+    dfree(s->ds.group_off);
+    dfree(s->ds.status);
+    dfree(s->ds.totals);
+    dfree(s->aux_alt);
     free_sort_scratch(s->sc, true);
     delete s;
 }
@@ -1055,6 +1122,32 @@ int ws_sorter_sort(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, const ui
     if (rc) return rc;
     if (ok != d_keys) return fail(WS_ERR_STATE, "ws_sorter_sort: internal ping-pong parity error");
     return WS_OK;
+}
+
+// The renderer's depth sort as a stand-alone call: the same result as ws_sorter_sort (stable ascending on the full
+// 32-bit keys), by three digit passes whose width follows the range of the keys (sort.hip); `d_aux` (may be null)
+// is a 4-byte companion value that travels with the payload.  Keys, payload and companion are sorted in place.
+int ws_sorter_sort_depth(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, uint32_t* d_aux, const uint32_t* d_count,
+                         uint32_t n, void* stream_v) {
+    if (!s || !d_keys || !d_payload) return fail(WS_ERR_INVALID, "ws_sorter_sort_depth: null argument");
+    if (n > s->ds.cap) return fail(WS_ERR_INVALID, "ws_sorter_sort_depth: n exceeds the sorter's capacity");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (++s->epoch == 0) {
+        WS_HIP(hipMemsetAsync(s->ds.status, 0, depth_sort_group_words() * sizeof(uint64_t), stream));
+        if (s->ctx->sort_algo == 1)
+            WS_HIP(hipMemsetAsync(s->sc.status, 0, 4 * (size_t)s->sc.tiles * RADIX * sizeof(uint64_t), stream));
+        s->epoch = 1;
+    }
+    WS_HIP(hipMemsetAsync(s->zero, 0, sizeof(SorterZero), stream));
+    if (n == 0) return WS_OK;
+    int rc = launch_key_minmax(d_keys, d_count, n, s->zero->key_range, stream);
+    if (rc) return rc;
+    rc = launch_depth_sort(s->ds, d_keys, d_payload, d_aux, d_count, n, false, s->epoch, stream, nullptr);
+    if (rc) return rc;
+    // three passes leave the result in the scratch buffers: bring the sorted prefix home (elements past the
+    // device-side count are not touched)
+    return launch_copy_counted(s->ds.keys_alt, d_keys, s->ds.vals_alt, d_payload, d_aux ? s->ds.aux_alt : nullptr, d_aux, d_count,
+                               n, stream);
 }
 
 int ws_sort_selftest(ws_context* ctx, int* passed) {

@@ -49,12 +49,34 @@ static_assert(sizeof(FrameCounters) == 64, "FrameCounters layout");
 
 // Everything a frame needs zeroed lives in one contiguous arena: counters, the digit histograms of both
 // sorts, and the tile ranges (appended after this struct).
+// Range of the frame's depth keys, reduced by K1 while it writes them: KEY_RANGE_SLOTS independent {max(key),
+// max(~key)} pairs, one 64-B line each (workgroup b updates slot b % 8), so that the ~1200 returnless atomics of a
+// frame neither serialise on one address (~12 ns each) nor share a line with K1's ticket dispenser.  Zero-initialised
+// maxima: ~min is kept instead of min.  Readers combine the slots (key_range_load).
+constexpr int KEY_RANGE_SLOTS = 8;
+constexpr int KEY_RANGE_STRIDE = 16;  // uint32 words per slot (64 B)
+
 struct FrameZero {
     FrameCounters counters;
     uint32_t depth_hist[4 * RADIX];
     uint32_t tile_hist[4 * RADIX];
+    uint32_t key_range[KEY_RANGE_SLOTS * KEY_RANGE_STRIDE];
     // uint2 tile_ranges[tiles] follows
 };
+
+// ---- tile rectangle of a splat, packed into 4 bytes ----------------------------------------------------------
+// x0 | y0 << 8 | (w - 1) << 16 | (h - 1) << 24 in binning tiles, all four < 256: up to 256 x 256 tiles, i.e. 8192 x 8192
+// pixels with the default 32 x 32 binning tile (the default wgpu limit max_texture_dimension_2d of the reference's
+// targets), 4096 x 4096 with 16 x 16.  0xFFFFFFFF (x0 = 255 with w = 256: impossible for a clamped rectangle) = empty.
+// 4 bytes instead of 8 so that the rectangle can ride through the depth sort with the splat index (sort.hip).
+constexpr uint32_t RECT_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t RECT_MAX_TILES_PER_AXIS = 256u;
+__host__ __device__ inline uint32_t rect_pack(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    return x0 | (y0 << 8) | ((x1 - x0) << 16) | ((y1 - y0) << 24);
+}
+__host__ __device__ inline uint32_t rect_tiles(uint32_t r) {
+    return r == RECT_EMPTY ? 0u : (((r >> 16) & 0xFFu) + 1u) * ((r >> 24) + 1u);
+}
 
 // ---- kernel parameter blocks (passed by value; the analogue of the reference's uniform buffers) ---
 struct K1Params {
@@ -139,6 +161,45 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                       KernelMarks* km = nullptr, const char* tag = "", uint2* ranges = nullptr, uint32_t nranges = 0,
                       int digit_bits = RADIX_BITS, bool key16 = false);
 
+// ---- depth sort: range-adaptive three-pass LSD sort of the frame's depth keys (sort.hip) ------------------------
+// Exactly the order of a stable ascending sort on the full 32-bit keys.  The keys of a frame occupy a narrow range
+// [kmin, kmax] (K1 reduces it while it writes them): only nbits = bit_length(kmax - kmin) bits of key - kmin differ,
+// and three digit passes of w = ceil(nbits / 3) bits (<= 11) sort them -- typically 3 x 9 bits instead of the
+// reference's 4 x 8 (gpu_rs.rs:865-884).  Per pass TWO launches: k_dsort_hist (per-tile digit counts, then a decoupled
+// look-back over groups of tiles: the column scan of the generic path is gone) and k_dsort_scatter.  Optionally a
+// 4-byte companion value (the splat's packed tile rectangle) rides along with the payload, so that the consumer of the
+// draw order needs no gather.
+constexpr int DSORT_PASSES = 3;
+constexpr int DSORT_MAX_BITS = 11;
+constexpr int DSORT_MAX_BINS = 1 << DSORT_MAX_BITS;
+constexpr int DSORT_MAX_GROUPS = 128;
+struct DepthSortScratch {
+    uint32_t* keys_alt = nullptr;   // [cap] ping-pong partners
+    uint32_t* vals_alt = nullptr;
+    uint32_t* aux_alt = nullptr;    // companion values (nullptr when nothing is carried)
+    uint32_t* tile_off = nullptr;   // [tiles_cap][bins]  exclusive prefix of the tile's digit counts INSIDE its group
+    uint32_t* group_off = nullptr;  // [passes][groups][bins]  exclusive prefix over the groups
+    uint64_t* status = nullptr;     // [passes][groups][bins]  epoch-tagged look-back words (never re-zeroed)
+    uint32_t* totals = nullptr;     // [passes][bins]  digit totals of the pass
+    uint32_t* tickets = nullptr;    // [passes] group dispensers, zero on entry
+    const uint32_t* key_range = nullptr;    // [KEY_RANGE_SLOTS][KEY_RANGE_STRIDE]: {max(key), max(~key)} per slot (FrameZero)
+    uint32_t* error = nullptr;      // OR-ed with 8 if a look-back spin times out
+    uint32_t cap = 0, tiles_cap = 0;
+};
+size_t depth_sort_tile_off_words(uint32_t cap);     // allocation sizes for capacity `cap`
+size_t depth_sort_group_words();
+// keys/vals(/aux) in -> sorted vals (and aux) in sc.vals_alt / sc.aux_alt (three passes: A -> B -> A -> B); sorted keys
+// in sc.keys_alt.  implicit_iota: the payload of the first pass is the element position.  aux == nullptr: nothing carried.
+int launch_depth_sort(const DepthSortScratch& sc, uint32_t* keys, uint32_t* vals, uint32_t* aux, const uint32_t* d_count,
+                      uint32_t n, bool implicit_iota, uint32_t epoch, hipStream_t stream, KernelMarks* km = nullptr);
+// stand-alone use (ws_sorter in depth mode): reduce the key range of arbitrary input into key_range (zero on entry)
+// out[i] = src[idx[i]] for i < count (the classic depth-sort path brings the rectangles into draw order with it)
+int launch_gather_u32(const uint32_t* src, const uint32_t* idx, const uint32_t* d_count, uint32_t n, uint32_t* out,
+                      hipStream_t stream);
+int launch_copy_counted(const uint32_t* s0, uint32_t* d0, const uint32_t* s1, uint32_t* d1, const uint32_t* s2, uint32_t* d2,
+                        const uint32_t* d_count, uint32_t n, hipStream_t stream);
+int launch_key_minmax(const uint32_t* keys, const uint32_t* d_count, uint32_t n, uint32_t* key_range, hipStream_t stream);
+
 // ---- preprocess ---------------------------------------------------------------------------------
 struct K1Buffers {
     const uint4* planes;         // uncompressed: PC_PLANES planes
@@ -147,10 +208,11 @@ struct K1Buffers {
     const uint8_t* covars;       // compressed: 12-B covariance codebook
     uint8_t* splats;             // [N] x 20 B  (pointcloud.rs:352-358 Splat)
     uint32_t* keys;              // [N] depth keys
-    uint2* rects;                // [N] tile rect (x0 | y0<<16, x1 | y1<<16), inclusive; x0 > x1 = empty
+    uint32_t* rects;             // [N] packed tile rectangle (rect_pack), RECT_EMPTY = touches no tile
     uint32_t* src_index;         // [N] or nullptr (capture mode)
     uint64_t* block_status;      // [blocks] epoch-tagged look-back words
     FrameCounters* counters;
+    uint32_t* key_range;         // FrameZero::key_range
 };
 int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, hipStream_t stream);
 uint32_t preprocess_blocks(uint32_t n);
@@ -160,8 +222,7 @@ constexpr int EMIT_TILE = SORT_TILE;  // tile entries produced per workgroup of 
 
 struct BinBuffers {
     const uint32_t* sorted_idx;  // [V] store indices in draw order (far -> near)
-    const uint2* rects;          // [N] by store index
-    uint2* rects_sorted;         // [N] by draw position
+    const uint32_t* rects_sorted;  // [N] packed tile rectangles by draw position (carried through the depth sort)
     uint32_t* offsets;           // [N] exclusive prefix of tiles touched, by draw position
     uint32_t* emit_start;        // [cap / EMIT_TILE + 2] draw position owning entry m * EMIT_TILE
     uint64_t* block_status;      // look-back words of the prefix kernel
@@ -223,6 +284,7 @@ struct ws_context {
     int device = 0;
     hipDeviceProp_t props;
     int sort_algo = 0;    // 0 = tile histograms -> column scan -> scatter (default), 1 = one-sweep (look-back)
+    bool depth_sort_classic = false;  // WS_DEPTH_SORT=classic: depth sort by the generic 4 x 8-bit sorter (cross-check)
     int blend_variant = 0;
     int debug_cut = 0;        // WS_DEBUG_CUT (analysis): 0 = whole frame
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic

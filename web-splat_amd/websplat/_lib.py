@@ -230,6 +230,7 @@ SIGNATURES = {
     "ws_sorter_create": (C.c_int, [_P, C.c_uint32, _PP]),
     "ws_sorter_destroy": (None, [_P]),
     "ws_sorter_sort": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P]),
+    "ws_sorter_sort_depth": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, _P]),
     "ws_sort_selftest": (C.c_int, [_P, C.POINTER(C.c_int)]),
 }
 

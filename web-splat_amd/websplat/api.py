@@ -752,23 +752,41 @@ class GPURSSorter:
         check(lib.ws_sorter_sort(self.handle, C.c_void_p(d_keys), C.c_void_p(d_payload),
                                  C.c_void_p(d_count) if d_count else None, int(n), C.c_void_p(stream or 0)))
 
-    def sort_host(self, keys: np.ndarray, payload: np.ndarray, count: int = None):
-        """Convenience for tests: upload, sort, download. `count` exercises the device-side count path."""
+    def sort_depth(self, d_keys: int, d_payload: int, n: int, d_aux: int = None, d_count: int = None, stream=None):
+        """The renderer's range-adaptive three-pass depth sort as a stand-alone call (same result as sort())."""
+        check(lib.ws_sorter_sort_depth(self.handle, C.c_void_p(d_keys), C.c_void_p(d_payload),
+                                       C.c_void_p(d_aux) if d_aux else None, C.c_void_p(d_count) if d_count else None,
+                                       int(n), C.c_void_p(stream or 0)))
+
+    def sort_host(self, keys: np.ndarray, payload: np.ndarray, count: int = None, depth: bool = False, aux: np.ndarray = None):
+        """Convenience for tests: upload, sort, download. `count` exercises the device-side count path; `depth`
+        selects the depth-sort specialisation, `aux` its companion values (returned as a third array)."""
         n = keys.shape[0]
         dk = self.ctx.malloc(max(n, 1) * 4)
         dv = self.ctx.malloc(max(n, 1) * 4)
+        da = self.ctx.malloc(max(n, 1) * 4) if aux is not None else None
         dc = None
         try:
             self.ctx.upload(dk, keys.astype(np.uint32))
             self.ctx.upload(dv, payload.astype(np.uint32))
+            if aux is not None:
+                self.ctx.upload(da, aux.astype(np.uint32))
             if count is not None:
                 dc = self.ctx.malloc(4)
                 self.ctx.upload(dc, np.array([count], dtype=np.uint32))
-            self.sort(dk, dv, n, dc)
+            if depth:
+                self.sort_depth(dk, dv, n, da, dc)
+            else:
+                self.sort(dk, dv, n, dc)
             self.ctx.sync()
-            return self.ctx.download(dk, (n,), np.uint32), self.ctx.download(dv, (n,), np.uint32)
+            out = (self.ctx.download(dk, (n,), np.uint32), self.ctx.download(dv, (n,), np.uint32))
+            if aux is not None:
+                out = out + (self.ctx.download(da, (n,), np.uint32),)
+            return out
         finally:
             self.ctx.free(dk)
             self.ctx.free(dv)
+            if da:
+                self.ctx.free(da)
             if dc:
                 self.ctx.free(dc)
