@@ -194,10 +194,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* 
 // replaces a separate pass over the sorted keys and the final 4-B-per-entry key write.
 // BITS: width of this sort's digits (8 for 32-bit keys; the tile-id sort splits its 12..16 key bits evenly over its
 // passes, e.g. 6 + 6 for 3750 tiles: fewer ballots per key, shorter scans, longer write runs).
-template <bool LOOKBACK, int KPT, bool RANGES, int BITS>
+// CARRY: a 4-byte companion value (aux_in -> aux_out) travels with the payload: the depth sort carries the splat's packed
+// tile rectangle, so that the binning prefix reads it in draw order instead of gathering it (raster.hip).
+template <bool LOOKBACK, int KPT, bool RANGES, int BITS, bool CARRY = false>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ d_count, uint32_t n, int shift, int iota,
+    uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out,
+    const uint32_t* __restrict__ d_count, uint32_t n, int shift, int iota,
     const uint32_t* __restrict__ hist,     // [256] global digit histogram of this pass
     uint64_t* __restrict__ status,         // [tiles][256] epoch-tagged look-back words      (LOOKBACK)
     uint32_t* __restrict__ ticket,         // tile dispenser, zero on entry                  (LOOKBACK)
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     __shared__ uint32_t s_global_base[RADIX];
     __shared__ uint32_t s_keys[TILE_N];
     __shared__ uint32_t s_vals[TILE_N];
+    __shared__ uint32_t s_aux[CARRY ? TILE_N : 1];
     __shared__ uint32_t s_tmp[WAVES];
     __shared__ uint32_t s_tile;
 
@@ -253,6 +257,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     for (int j = 0; j < KPT; ++j) {
         const uint32_t pos = wave_base + j * 64;
         val[j] = iota ? pos : (pos < count ? vals_in[pos] : 0u);
+    }
+    uint32_t aux[CARRY ? KPT : 1];
+    if (CARRY) {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t pos = wave_base + j * 64;
+            aux[j] = pos < count ? aux_in[pos] : 0u;
+        }
     }
     uint32_t my_tile_off = 0u;  // issued early: needed only after the ranking
     if (!LOOKBACK && (uint32_t)tid <= DMASK) my_tile_off = tile_off[(size_t)tid * tiles_cap + t];
@@ -366,6 +378,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         const uint32_t lpos = s_local_excl[d] + s_wave_hist[wave][d] + rank[j];
         s_keys[lpos] = key[j];
         s_vals[lpos] = val[j];
+        if (CARRY) s_aux[lpos] = aux[j];
     }
     __syncthreads();
 #pragma unroll
@@ -377,6 +390,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         const uint32_t gpos = s_global_base[d] + lp;
         if (lp < valid) {
             vals_out[gpos] = vv;
+            if (CARRY) aux_out[gpos] = s_aux[lp];
             if (!RANGES) {
                 if (key16) reinterpret_cast<uint16_t*>(keys_out)[gpos] = (uint16_t)kk;
                 else keys_out[gpos] = kk;
@@ -394,7 +408,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 }
 
 template <int KPT, int BITS>
-int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout,
+int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t* ain,
+                    uint32_t* aout,
                     const uint32_t* d_count, uint32_t n, int begin_bit, int npass, bool implicit_iota,
                     bool first_tile_hist_ready, uint32_t epoch, hipStream_t stream, uint32_t** fk, uint32_t** fv,
                     KernelMarks* km, const char* const* names, uint2* ranges, uint32_t nranges, bool key16) {
@@ -413,14 +428,19 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
         km_mark(km, names[1]);
         if (ranges && p == npass - 1)
             hipLaunchKernelGGL((k_sort_scatter<false, KPT, true, BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
-                               kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr,
-                               (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr, ranges, nranges,
-                               key16 ? 1 : 0);
+                               kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota,
+                               sc.hist + p * RADIX, (uint64_t*)nullptr, (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch,
+                               (uint32_t*)nullptr, ranges, nranges, key16 ? 1 : 0);
+        else if (ain)
+            hipLaunchKernelGGL((k_sort_scatter<false, KPT, false, BITS, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
+                               vin, kout, vout, ain, aout, d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr,
+                               (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr, (uint2*)nullptr,
+                               0u, key16 ? 1 : 0);
         else
             hipLaunchKernelGGL((k_sort_scatter<false, KPT, false, BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
-                               kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr,
-                               (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr,
-                               (uint2*)nullptr, 0u, key16 ? 1 : 0);
+                               kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota,
+                               sc.hist + p * RADIX, (uint64_t*)nullptr, (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch,
+                               (uint32_t*)nullptr, (uint2*)nullptr, 0u, key16 ? 1 : 0);
         km_mark(km, names[2]);
         WS_HIP(hipGetLastError());
         uint32_t* tk = kin;
@@ -429,6 +449,9 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
         uint32_t* tv = vin;
         vin = vout;
         vout = tv;
+        uint32_t* ta = ain;
+        ain = aout;
+        aout = ta;
     }
     *fk = kin;
     *fv = vin;
@@ -981,7 +1004,8 @@ int launch_key_minmax(const uint32_t* keys, const uint32_t* d_count, uint32_t n,
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
                       uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km,
-                      const char* tag, uint2* ranges, uint32_t nranges, int digit_bits, bool key16) {
+                      const char* tag, uint2* ranges, uint32_t nranges, int digit_bits, bool key16, uint32_t* aux,
+                      uint32_t* aux_alt) {
     // labels of the per-kernel timers: "<tag>k_sort_..." with tag = "depth:" / "tiles:"
     const bool depth = tag && tag[0] == 'd';
     static const char* const N_DEPTH[4] = {"depth:k_sort_tile_hist", "depth:k_sort_col_scan", "depth:k_sort_scatter",
@@ -995,6 +1019,8 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
     if (n > sc.cap) return fail(WS_ERR_INVALID, "sort: n exceeds the scratch capacity");
     if (algo == 1) digit_bits = RADIX_BITS;
     if (algo == 1 && key16) return fail(WS_ERR_INVALID, "sort: 16-bit keys are a feature of the scan path");
+    if (algo == 1 && aux) return fail(WS_ERR_INVALID, "sort: companion values are a feature of the scan path");
+    if (aux && (ranges || !aux_alt)) return fail(WS_ERR_INVALID, "sort: companion values need a scratch partner and no range recording");
     if (key16 && end_bit > 16) return fail(WS_ERR_INVALID, "sort: 16-bit keys with more than 16 key bits");
     if (digit_bits < 6 || digit_bits > RADIX_BITS) return fail(WS_ERR_INVALID, "sort: digit width must be 6, 7 or 8 bits");
     if (begin_bit < 0 || end_bit > 32 || begin_bit >= end_bit)
@@ -1012,7 +1038,7 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
         int rc;
         const bool big = sort_tile_size(n) == SORT_TILE;
 #define WS_RUN_SCAN(KPT_, BITS_)                                                                                       \
-    rc = run_passes_scan<KPT_, BITS_>(sc, kin, vin, kout, vout, d_count, n, begin_bit, npass, implicit_iota,          \
+    rc = run_passes_scan<KPT_, BITS_>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass, implicit_iota, \
                                       first_tile_hist_ready, epoch, stream, &kin, &vin, km, names, ranges, nranges, \
                                       key16)
         if (digit_bits == 8) {
@@ -1038,12 +1064,12 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
             const int iota = (implicit_iota && p == 0) ? 1 : 0;
             if (ranges && p == npass - 1)
                 hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, true, RADIX_BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
-                                   vin, kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX,
+                                   vin, kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota, sc.hist + p * RADIX,
                                    sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
                                    0u, epoch, sc.error, ranges, nranges, 0);
             else
                 hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, false, RADIX_BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
-                                   vin, kout, vout, d_count, n, shift, iota, sc.hist + p * RADIX,
+                                   vin, kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota, sc.hist + p * RADIX,
                                    sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
                                    0u, epoch, sc.error, (uint2*)nullptr, 0u, 0);
             km_mark(km, names[2]);

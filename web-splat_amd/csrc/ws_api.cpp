@@ -315,8 +315,8 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->device = hip_device;
     WS_HIP(hipGetDeviceProperties(&ctx->props, hip_device));
     ctx->sort_algo = env_int("WS_SORT_ALGO", 0);
-    if (const char* ds = std::getenv("WS_DEPTH_SORT")) ctx->depth_sort_classic = std::strcmp(ds, "classic") == 0;
-    if (ctx->sort_algo == 1) ctx->depth_sort_classic = true;  // the one-sweep cross-check path is a generic-sorter path
+    if (const char* ds = std::getenv("WS_DEPTH_SORT")) ctx->depth_sort_adaptive = std::strcmp(ds, "adaptive") == 0;
+    if (ctx->sort_algo == 1) ctx->depth_sort_adaptive = false;  // the one-sweep cross-check path is a generic-sorter path
     ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
     ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
@@ -767,18 +767,24 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         return WS_OK;
     }
     // depth sort: V (key, store index) pairs, values start as iota (preprocess.wgsl:274), the packed tile rectangle
-    // rides along.  Default: three range-adaptive digit passes (launch_depth_sort); WS_DEPTH_SORT=classic: the generic
-    // 4 x 8-bit sorter (GPURSSorter's shape), after which the rectangles are gathered into draw order.
-    if (r->ctx->depth_sort_classic) {
+    // rides along as a companion value.  Default: the generic 4 x 8-bit sorter (GPURSSorter's shape);
+    // WS_DEPTH_SORT=adaptive: three range-adaptive digit passes (launch_depth_sort; measured: no faster).
+    if (!r->ctx->depth_sort_adaptive) {
+        const bool carry = r->ctx->sort_algo != 1;  // (the one-sweep cross-check path gathers the rectangles afterwards)
         uint32_t *sk = nullptr, *sv = nullptr;
         if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
-                                    true, false, r->ctx->sort_algo, r->epoch, stream, &sk, &sv, km, "depth:")))
+                                    true, false, r->ctx->sort_algo, r->epoch, stream, &sk, &sv, km, "depth:", nullptr, 0,
+                                    RADIX_BITS, false, carry ? r->rects_a : nullptr, carry ? r->rects_b : nullptr)))
             return rc;
         r->sorted_idx = sv;
         r->sorted_keys = sk;
-        if ((rc = launch_gather_u32(r->rects_a, sv, &r->counters->num_visible, pc->num_points, r->rects_b, stream))) return rc;
-        km_mark(km, "k_gather_rects");
-        r->rects_sorted = r->rects_b;
+        if (carry) {
+            r->rects_sorted = (sv == r->vals_a) ? r->rects_a : r->rects_b;  // where the payload went
+        } else {
+            if ((rc = launch_gather_u32(r->rects_a, sv, &r->counters->num_visible, pc->num_points, r->rects_b, stream))) return rc;
+            km_mark(km, "k_gather_rects");
+            r->rects_sorted = r->rects_b;
+        }
     } else {
         if ((rc = launch_depth_sort(r->dsort, r->keys_a, r->vals_a, r->rects_a, &r->counters->num_visible, pc->num_points,
                                     true, r->epoch, stream, km)))

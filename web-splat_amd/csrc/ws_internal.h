@@ -159,7 +159,9 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
                       uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals,
                       KernelMarks* km = nullptr, const char* tag = "", uint2* ranges = nullptr, uint32_t nranges = 0,
-                      int digit_bits = RADIX_BITS, bool key16 = false);
+                      int digit_bits = RADIX_BITS, bool key16 = false, uint32_t* aux = nullptr, uint32_t* aux_alt = nullptr);
+//   aux / aux_alt (scan path only): a 4-byte companion value per pair travels with the payload; the result lands where
+//     the payload lands (aux for an even pass count, aux_alt for an odd one).
 
 // ---- depth sort: range-adaptive three-pass LSD sort of the frame's depth keys (sort.hip) ------------------------
 // Exactly the order of a stable ascending sort on the full 32-bit keys.  The keys of a frame occupy a narrow range
@@ -284,7 +286,7 @@ struct ws_context {
     int device = 0;
     hipDeviceProp_t props;
     int sort_algo = 0;    // 0 = tile histograms -> column scan -> scatter (default), 1 = one-sweep (look-back)
-    bool depth_sort_classic = false;  // WS_DEPTH_SORT=classic: depth sort by the generic 4 x 8-bit sorter (cross-check)
+    bool depth_sort_adaptive = false;  // WS_DEPTH_SORT=adaptive: three range-adaptive digit passes (sort.hip; cross-check)
     int blend_variant = 0;
     int debug_cut = 0;        // WS_DEBUG_CUT (analysis): 0 = whole frame
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
