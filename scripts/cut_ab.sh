@@ -6,7 +6,7 @@ os.environ["WS_DEBUG_CUT"] = "$c"
 sys.path[:0] = ["web-splat_amd", "tests", "."]
 import torch, websplat as ws, bench
 ctx = ws.Context(0)
-gpc, views, (w, h) = bench.build_workload(ws, "c2", 64)
+gpc, views, (w, h), _ = bench.build_workload(ws, "${WORKLOAD:-c2}", 64)
 pc = ws.PointCloud(ctx, gpc)
 out = []
 for ns in (1, 4):

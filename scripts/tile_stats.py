@@ -8,7 +8,7 @@ import bench
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c2"
 ctx = ws.Context(0)
-gpc, views, (w, h) = bench.build_workload(ws, name, 8)
+gpc, views, (w, h), _ = bench.build_workload(ws, name, 8)
 pc = ws.PointCloud(ctx, gpc)
 r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
 r.enable_capture(True)

@@ -825,13 +825,15 @@ static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
     const uint32_t grid = blend_grid_blocks(p.tiles_x, p.tiles_y, sh, tpw_log2);
     constexpr int NT = 64 * QW * QH;
     const bool capture = p.debug_consumed != nullptr || p.debug_walked != nullptr;  // analysis build of the kernel
+    // tuning knob (WS_BLEND_LDS_PAD_KB): unused dynamic LDS that lowers the number of blend workgroups per CU
+    const size_t pad = (size_t)p.lds_pad_kb * 1024u;
 #define WS_LAUNCH_BLEND(FMT)                                                                                         \
     if (capture)                                                                                                     \
-        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, true>), dim3(grid), dim3(NT), 0, stream, p, tpw_log2);        \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, true>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);      \
     else if (tpw_log2 > 0u)                                                                                          \
-        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, false>), dim3(grid), dim3(NT), 0, stream, p, tpw_log2);       \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);     \
     else                                                                                                             \
-        hipLaunchKernelGGL((k_blend<FMT, QW, QH, false, false>), dim3(grid), dim3(NT), 0, stream, p, tpw_log2)
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, false, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2)
     switch (p.format) {
         case WS_FORMAT_RGBA32_FLOAT:
             WS_LAUNCH_BLEND(WS_FORMAT_RGBA32_FLOAT);

@@ -321,6 +321,8 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
     if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
+    ctx->blend_lds_pad_kb = env_int("WS_BLEND_LDS_PAD_KB", 0);
+    if (ctx->blend_lds_pad_kb < 0 || ctx->blend_lds_pad_kb > 96) ctx->blend_lds_pad_kb = 0;
     if (const char* shape = std::getenv("WS_TILE_SHAPE")) {  // tuning / A-B: quadrants per tile
         const std::string v(shape);
         if (v == "2x2") { ctx->tile_qw = 2; ctx->tile_qh = 2; }
@@ -889,6 +891,7 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.pitch = row_pitch_bytes;
     bp.format = (int)r->format;
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
+    bp.lds_pad_kb = r->ctx->blend_lds_pad_kb;
     bp.counters = r->counters;
     bp.sticky = r->sticky;
     bp.debug_consumed = r->capture ? r->debug_consumed : nullptr;
