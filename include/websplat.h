@@ -329,9 +329,6 @@ int ws_context_tile_size(const ws_context* ctx, uint32_t* width, uint32_t* heigh
  * exp2 domain) and the mask of 8x8-pixel quadrants (bit qy * (tile_w / 8) + qx) the kept ellipse may reach. */
 int ws_debug_stage_splat(const uint32_t splat[5], float viewport_w, float viewport_h, float tile_x0, float tile_y0,
                          uint32_t tile_w, uint32_t tile_h, float rec[10], uint32_t* quadrant_mask);
-/* the same, plus the staged record's 4x4-pixel sub-block mask (bit sy * (tile_w / 4) + sx; lane-group walk of the blend) */
-int ws_debug_stage_splat_sub(const uint32_t splat[5], float viewport_w, float viewport_h, float tile_x0, float tile_y0,
-                             uint32_t tile_w, uint32_t tile_h, float rec[10], uint32_t* quadrant_mask, uint64_t* subblock_mask);
 /* tuning / analysis read-back: per tile, the length of its depth-ordered splat list and (capture mode)
  * how many of its entries the compositing pass walked before every pixel was saturated.  Syncs. */
 int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t* list_len, uint32_t* consumed,

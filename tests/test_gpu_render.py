@@ -471,33 +471,3 @@ def test_wave_stats_capture(ws, ctx, oracle):
     finally:
         r.close()
         pc.close()
-
-
-@pytest.mark.parametrize("shape", ["4x4", "2x2", "4x2"])
-def test_lane_group_walk_on_pixel_sized_splats(ws, oracle, shape, monkeypatch):
-    """Scenes of pixel-sized splats (BASELINE config 3 in small) are composited by the lane-group walk (each 16-lane
-    group of a wave walks the records that reach its 4x4 sub-block): same image as the oracle, and the same image as the
-    quadrant walk (WS_BLEND_SUBWALK=0) up to the early-out threshold (the two stop at different records once a whole
-    quadrant is below T_MIN = 2^-14)."""
-    from websplat import synth
-    monkeypatch.setenv("WS_TILE_SHAPE", shape)
-    rows = synth.scene_c3(n=400_000, seed=5)
-    cj = synth.camera_c3(960, 540)
-    imgs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("WS_BLEND_SUBWALK", mode)
-        c = ws.Context(0)
-        try:
-            sc = scenes.Scene(ws, oracle, rows, 3, cj, (960, 540))
-            pc, img, stats = _render(ws, c, sc)
-            try:
-                assert stats["overflow"] == 0 and stats["num_visible"] > 350_000
-                if mode == "1":
-                    ref, _ = sc.oracle_image(pc)
-                    _assert_close(img, ref)
-                imgs[mode] = img
-            finally:
-                pc.close()
-        finally:
-            c.close()
-    assert np.abs(imgs["1"] - imgs["0"]).max() <= 2.5e-4

@@ -183,48 +183,3 @@ def test_quadrant_mask_never_drops_a_covered_pixel(ws, tile):
         flagged += bin(mask).count("1")
     assert needed > 2000
     assert flagged <= needed * 1.02 + 10
-
-
-@pytest.mark.parametrize("tile", [(16, 16), (32, 16), (32, 32)])
-def test_subblock_mask_never_drops_a_covered_pixel(ws, tile):
-    """The 4x4-pixel sub-block mask (lane-group walk of the blend, scenes of pixel-sized splats) is the bounding box of the
-    kept ellipse: conservative for every splat, and tight for the small ones it is meant for."""
-    rng = np.random.default_rng(11)
-    viewport = (1920.0, 1080.0)
-    cut = np.float32(2 * 2.3539888583335364 * 1.4426950408889634)
-    sbw = tile[0] // 4
-    ys, xs = np.mgrid[0:tile[1], 0:tile[0]]
-    lx = (xs + 0.5).astype(np.float32)
-    ly = (ys + 0.5).astype(np.float32)
-    sblk = (ys // 4) * sbw + (xs // 4)
-    needed = flagged = small_needed = small_flagged = 0
-    for trial in range(6000):
-        origin = (float(tile[0] * rng.integers(0, 40)), float(tile[1] * rng.integers(0, 30)))
-        words = _random_splat_words(rng, viewport, origin, tile)
-        if trial % 2:  # pixel-sized, mildly anisotropic splats inside or next to the tile: the case the mask is for
-            s1 = np.exp(rng.uniform(np.log(0.4), np.log(2.5)))
-            s2 = s1 * np.exp(rng.uniform(-0.5, 0.5))
-            th = rng.uniform(0, 2 * np.pi)
-            c, s = np.cos(th), np.sin(th)
-            cx = origin[0] + rng.uniform(-4, tile[0] + 4)
-            cy = origin[1] + rng.uniform(-4, tile[1] + 4)
-            W, H = viewport
-            words = np.array([c * s1 / W, -s * s1 / H, -s * s2 / W, -c * s2 / H, cx / W * 2 - 1, 1 - cy / H * 2,
-                              0.5, 0.5, 0.5, 0.5], dtype=np.float32).astype(np.float16).view(np.uint32)
-        rec, qmask, sub = ws.stage_splat_sub(words, viewport, origin, tile)
-        if not np.all(np.isfinite(rec[:6])):
-            continue
-        p0 = rec[0] * lx + (rec[1] * ly + rec[2])
-        p1 = rec[3] * lx + (rec[4] * ly + rec[5])
-        kept = (p0 * p0 + p1 * p1) <= cut * np.float32(1.00001)
-        truth = 0
-        for q in np.unique(sblk[kept]):
-            truth |= 1 << int(q)
-        assert truth & ~sub == 0, (trial, hex(truth), hex(sub), words)
-        needed += bin(truth).count("1")
-        flagged += bin(sub).count("1")
-        if trial % 2:
-            small_needed += bin(truth).count("1")
-            small_flagged += bin(sub).count("1")
-    assert small_needed > 3000
-    assert small_flagged <= small_needed * 1.45   # a box around a disc of ~2 px radius: at most ~1.4 x the sub-blocks

@@ -71,34 +71,7 @@ struct Staged {
     float i10, i11, c1;  // row 1
     float alpha, r, g, b;
     uint32_t mask;       // bit (qy * QW + qx): the kept ellipse may reach quadrant (qx, qy) of the tile
-    uint64_t sub;        // bit (sy * 2 QW + sx): its bounding box reaches the 4x4-pixel sub-block (sx, sy) of the tile
 };
-
-// Coverage of the 4x4-pixel sub-blocks (2 QW x 2 QH of them; pixel centres of sub-block column c span
-// [4c + 0.5, 4c + 3.5]) by the BOUNDING BOX of the kept ellipse: half width sqrt(cut C / D), half height sqrt(cut A / D),
-// padded towards "covered".  Used by the compositing pass for scenes of pixel-sized splats, where a record touches a
-// dozen pixels: each 16-lane group of a wave then walks only the records that reach ITS sub-block (raster.hip).  A box is
-// enough there (tiny splats are nearly as big as their boxes); the per-pixel test decides as always.
-template <int QW, int QH>
-WS_HD uint64_t subblock_mask(float A, float C, float D, float cxl, float cyl, float cut) {
-    constexpr int SBW = 2 * QW, SBH = 2 * QH;
-    const float cutp = cut * 1.0001f + 1e-4f;
-    const float invD = fast_rcp(D);
-    const float xmax = fast_sqrt(cutp * C * invD) * 1.00001f + 2e-3f + 4e-6f * fabsf(cxl);
-    const float ymax = fast_sqrt(cutp * A * invD) * 1.00001f + 2e-3f + 4e-6f * fabsf(cyl);
-    const float clo = med3(ceilf((cxl - xmax - 3.5f) * 0.25f), 0.0f, (float)SBW);
-    const float chi = med3(floorf((cxl + xmax - 0.5f) * 0.25f), -1.0f, (float)(SBW - 1));
-    const float rlo = med3(ceilf((cyl - ymax - 3.5f) * 0.25f), 0.0f, (float)SBH);
-    const float rhi = med3(floorf((cyl + ymax - 0.5f) * 0.25f), -1.0f, (float)(SBH - 1));
-    if (!(clo <= chi) || !(rlo <= rhi)) return 0ull;  // (also false for NaN extents)
-    const uint32_t c0 = (uint32_t)clo, c1 = (uint32_t)chi, r0 = (uint32_t)rlo, r1 = (uint32_t)rhi;
-    const uint64_t row = (uint64_t)((2u << c1) - (1u << c0));
-    uint64_t m = 0ull;
-#pragma unroll
-    for (int r = 0; r < SBH; ++r)
-        if ((uint32_t)r >= r0 && (uint32_t)r <= r1) m |= row << (r * SBW);
-    return m;
-}
 
 // Coverage of the QW x QH quadrants (8x8 pixels each; pixel centres of quadrant column c span
 // [8c + 0.5, 8c + 7.5] in tile-local coordinates) by the kept ellipse
@@ -168,7 +141,6 @@ WS_HD Staged decode(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t
     const float B2 = 2.0f * (s.i00 * s.i01 + s.i10 * s.i11);
     const float dI = inv * SQRT_LOG2E_F;
     s.mask = quadrant_mask<QW, QH>(A, B2, C, dI * dI, cxl, cyl, cut);
-    s.sub = subblock_mask<QW, QH>(A, C, dI * dI, cxl, cyl, cut);
     s.alpha = half_bits(w4 >> 16);
     s.r = half_bits(w3);
     s.g = half_bits(w3 >> 16);

@@ -360,10 +360,8 @@ __device__ __forceinline__ void blend_composite(const BlendRec& r, float lx, flo
     }
 }
 
-// eight waves per SIMD = two 1024-thread workgroups per CU: the kernel sits at the 64-VGPR edge (four outer-scope values
-// are spilled once per tile, none in the walks)
 #ifndef WS_BLEND_MINWAVES
-#define WS_BLEND_MINWAVES 8
+#define WS_BLEND_MINWAVES 1
 #endif
 // entries staged per batch, at most (measured at 4x4: 256 -> blend +8 % on c2, +17 % on c3; 1024 does not leave LDS
 // for two workgroups per CU)
@@ -380,8 +378,6 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     constexpr int TW = 8 * QW, TH = 8 * QH;
     __shared__ float4 s_rec[2 * SLOTS];
     __shared__ uint32_t s_m[STAGE];  // quadrant bits of the staged record (0 = slot unused)
-    __shared__ uint2 s_sm[STAGE];    // 4x4-pixel sub-block bits of the staged record (bounding box, blend_stage.h)
-    __shared__ uint32_t s_fill[2][2];  // per batch parity: sum of sub-blocks / of quadrants the staged records reach
     // per wave: byte offsets of the staged records that reach its quadrant, near -> far, padded with the null record
     __shared__ __attribute__((aligned(16))) uint32_t s_list[NW][STAGE + 16];
     __shared__ uint2 s_range[16];   // [begin, end) of this workgroup's tiles in the sorted entry list
@@ -402,17 +398,9 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int qx = wave % QW, qy = wave / QW;
-    // lane -> pixel of the wave's 8x8 quadrant: four 16-lane groups, one 4x4 sub-block each (lane-group walk below)
-    const int sbi = lane >> 4;                                   // sub-block of the quadrant: (sbi & 1, sbi >> 1)
-    const int qpx = (sbi & 1) * 4 + (lane & 3), qpy = (sbi >> 1) * 4 + ((lane >> 2) & 3);
-    const float lx = (float)(qx * 8 + qpx) + 0.5f;  // tile-local pixel centre
-    const float ly = (float)(qy * 8 + qpy) + 0.5f;
+    const float lx = (float)(qx * 8 + (lane & 7)) + 0.5f;  // tile-local pixel centre
+    const float ly = (float)(qy * 8 + (lane >> 3)) + 0.5f;
     const uint32_t qbit = 1u << wave;
-    // bit positions of the wave's four sub-blocks in the 64-bit sub-block mask (row-major over 2 QW x 2 QH sub-blocks)
-    constexpr int SBW = 2 * QW;
-    const uint32_t sb_pos0 = (uint32_t)((qy * 2) * SBW + qx * 2);   // (0,0); (1,0) = +1; (0,1) = +SBW; (1,1) = +SBW + 1
-    constexpr int SUB_STRIDE = (STAGE + 16) / 2;                    // 16-bit entries per sub-block list (four per wave)
-    constexpr uint32_t SUB_CAP = SUB_STRIDE - 8;
     const bool stager = NT == STAGE || tid < STAGE;  // wave-uniform
     if ((uint32_t)tid < tpw) {  // the ranges of all my tiles up front: one round trip instead of one per tile
         const uint32_t slot = blk.w + (uint32_t)tid * wpb;
@@ -431,7 +419,6 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     if (tid == 0) {  // the null record: a' = 1e18, never inside the cut-off (visible after the first barrier)
         s_rec[STAGE] = make_float4(0.0f, 0.0f, 1.0e9f, 0.0f);
         s_rec[SLOTS + STAGE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        s_fill[0][0] = s_fill[0][1] = s_fill[1][0] = s_fill[1][1] = 0u;
     }
     __syncthreads();
     const float W = (float)p.width, H = (float)p.height;
@@ -455,8 +442,8 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     if (code != 0xFFFFFFFFu) {  // block-uniform
     const uint32_t tx = code & 0xFFFFu, ty = code >> 16;
     const uint32_t tile = ty * p.tiles_x + tx;
-    const uint32_t px = tx * TW + qx * 8 + qpx;
-    const uint32_t py = ty * TH + qy * 8 + qpy;
+    const uint32_t px = tx * TW + qx * 8 + (lane & 7);
+    const uint32_t py = ty * TH + qy * 8 + (lane >> 3);
     const bool inside = px < p.width && py < p.height;
     // Pixels outside the image start with T = 0: they accumulate nothing and count as saturated.  There is no
     // per-pixel "done" flag in the inner loop: a pixel below T_MIN keeps accumulating (its contributions are
@@ -465,7 +452,6 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     const float tile_x0 = (float)(tx * TW), tile_y0 = (float)(ty * TH);
 
     uint32_t hi = range.y;
-    uint32_t batch = 0u;
     // capture build only (p.debug_walked): records this wave walked, and the sum over batches of the most any wave
     // walked in the batch (the lock-step cost of the per-batch barriers)
     uint32_t dbg_walked = 0u, dbg_lockstep = 0u;
@@ -478,82 +464,23 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         const uint32_t hi_next = hi - nb;
         if (stager) {
             uint32_t mask = 0u;
-            uint64_t smask = 0ull;
             if ((uint32_t)tid < nb) {
                 const stage::Staged s = stage::decode<QW, QH>(raw.w0, raw.w1, raw.w2, raw.w3, raw.w4, W, H, tile_x0,
                                                               tile_y0, CUT_A2);
                 mask = s.mask;
-                smask = s.sub;
                 s_rec[tid] = make_float4(s.i00, s.i01, s.c0, s.i10);
                 s_rec[SLOTS + tid] = make_float4(s.i11, s.c1, __uint_as_float(raw.w3), __uint_as_float(raw.w4));
             }
             s_m[tid] = mask;
-            s_sm[tid] = make_uint2((uint32_t)smask, (uint32_t)(smask >> 32));
-            // how full are the quadrants the batch reaches?  (sub-blocks reached) / (4 x quadrants reached): pixel-sized
-            // splats fill a quarter of a quadrant or less -- then the lane-group walk below pays
-            if (mask) {  // (two LDS atomics per staged record; cheaper in registers than a wave reduction)
-                atomicAdd(&s_fill[batch & 1u][0], (uint32_t)__popcll(smask));
-                atomicAdd(&s_fill[batch & 1u][1], (uint32_t)__popc(mask));
-            }
             // the next batch's gathers fly while this batch is composited; wasted only when the tile saturates first
             if (hi_next > range.x) raw = blend_fetch_raw<STAGE>(p, range, hi_next, tid);
         }
         __syncthreads();
         const uint32_t dbg_before = dbg_walked;
-        // block-uniform choice of the walk for this batch: lane groups when the records fill at most 60 % of the quadrants
-        // they reach (s_fill was summed by the stagers before the barrier).  Pixel-sized splats (2 px radius: ~4 sub-blocks in
-        // ~2.25 quadrants, 0.44) take the lane-group walk, anything from ~8 px radius up the quadrant walk.
-        const uint32_t fill_sub = s_fill[batch & 1u][0], fill_quad = s_fill[batch & 1u][1];
-        if (tid == 0) s_fill[(batch + 1u) & 1u][0] = s_fill[(batch + 1u) & 1u][1] = 0u;  // (next batch adds after the closing barrier)
-        bool sub_walk = p.sub_walk && fill_sub * 5u <= fill_quad * 12u;   // sub / (4 quad) <= 0.6
         if (__ballot(T >= T_MIN) != 0ull) {  // a wave whose 64 pixels are saturated only keeps staging
-            const uint32_t rounds = (nb + 63u) >> 6;
-            uint32_t n = 0;
-            if (sub_walk) {
-                // ---- lane-group walk: each 16-lane group (one 4x4 sub-block of the quadrant) gets its OWN list of the
-                // staged records whose bounding box reaches the sub-block, near -> far, as 16-bit slot numbers; the four
-                // groups then composite four different records per step.  Same per-pixel arithmetic in the same order as
-                // the quadrant walk: only records that cannot pass a pixel's cut-off test are skipped.
-                uint16_t* sl_all = reinterpret_cast<uint16_t*>(my_list);
-                uint32_t ns[4] = {0u, 0u, 0u, 0u};
-                for (uint32_t r = 0; r < rounds; ++r) {
-                    const uint32_t slot = r * 64 + lane;
-                    const bool tq = (s_m[slot] & qbit) != 0u;
-                    const uint2 sm = s_sm[slot];
-                    const unsigned long long sm64 = ((unsigned long long)sm.y << 32) | sm.x;
-                    const uint32_t four = (uint32_t)((sm64 >> sb_pos0) & 3ull) | ((uint32_t)((sm64 >> (sb_pos0 + SBW)) & 3ull) << 2);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const bool t = tq && ((four >> g) & 1u);
-                        const unsigned long long bal = __ballot(t);
-                        const uint32_t pos = ns[g] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                        if (t && pos < SUB_CAP) sl_all[g * SUB_STRIDE + pos] = (uint16_t)slot;
-                        ns[g] += (uint32_t)__popcll(bal);
-                    }
-                }
-                const uint32_t steps = max(max(ns[0], ns[1]), max(ns[2], ns[3]));
-                if (lane < 4 && ns[lane & 3] <= SUB_CAP) sl_all[lane * SUB_STRIDE + ns[lane & 3]] = (uint16_t)STAGE;  // sentinel: the null record
-                if (steps > SUB_CAP) {
-                    sub_walk = false;  // a list ran over (cannot happen for the small splats this walk is chosen for): quadrant walk
-                } else if (steps > 0u) {
-                    const uint32_t n_mine = sbi == 0 ? ns[0] : (sbi == 1 ? ns[1] : (sbi == 2 ? ns[2] : ns[3]));
-                    const uint16_t* sl = sl_all + sbi * SUB_STRIDE;
-                    // a group whose list is exhausted keeps reading its sentinel (slot STAGE: the null record)
-                    BlendRec cur = blend_load_rec<SLOTS>(s_rec, (uint32_t)sl[0] * 16u);
-                    for (uint32_t i = 0; i < steps; ++i) {
-                        const uint32_t nxt_slot = (uint32_t)sl[min(i + 1u, n_mine)];
-                        const BlendRec nxt = blend_load_rec<SLOTS>(s_rec, nxt_slot * 16u);
-                        blend_composite(cur, lx, ly, T, cr, cg, cb);
-                        cur = nxt;
-                        if ((i & 3u) == 3u) {
-                            if ((CAPTURE && p.debug_walked)) dbg_walked += 4u;
-                            if (__ballot(T >= T_MIN) == 0ull) break;
-                        }
-                    }
-                }
-            }
-            if (!sub_walk) {
             // wave-private compaction: records whose kept ellipse reaches this quadrant, in near -> far order
+            uint32_t n = 0;
+            const uint32_t rounds = (nb + 63u) >> 6;
             for (uint32_t r = 0; r < rounds; ++r) {
                 const bool t = (s_m[r * 64 + lane] & qbit) != 0u;
                 const unsigned long long bal = __ballot(t);
@@ -587,9 +514,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
                     on = lp[g + 2u < n4 ? g + 2u : n4 - 1u];
                 }
             }
-            }
         }
-        ++batch;
         hi = hi_next;
         if ((CAPTURE && p.debug_walked) && lane == 0) atomicMax(&s_dbg_max, dbg_walked - dbg_before);
         const bool all_done = __syncthreads_and(T < T_MIN ? 1 : 0);
@@ -956,7 +881,7 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
 
 // host-side twin of the staging step (CPU unit test of the quadrant mask; not on any render path)
 int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, float tile_y0, uint32_t qw, uint32_t qh,
-                      float rec[10], uint32_t* mask, uint64_t* sub_mask) {
+                      float rec[10], uint32_t* mask) {
     stage::Staged s;
     if (qw == 2u && qh == 2u) s = stage::decode<2, 2>(w[0], w[1], w[2], w[3], w[4], W, H, tile_x0, tile_y0, CUT_A * stage::LOG2E_F);
     else if (qw == 4u && qh == 2u) s = stage::decode<4, 2>(w[0], w[1], w[2], w[3], w[4], W, H, tile_x0, tile_y0, CUT_A * stage::LOG2E_F);
@@ -965,7 +890,6 @@ int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, floa
     const float v[10] = {s.i00, s.i01, s.c0, s.i10, s.i11, s.c1, s.alpha, s.r, s.g, s.b};
     for (int i = 0; i < 10; ++i) rec[i] = v[i];
     *mask = s.mask;
-    if (sub_mask) *sub_mask = s.sub;
     return WS_OK;
 }
 

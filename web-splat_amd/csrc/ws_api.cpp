@@ -321,7 +321,6 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
     if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
-    ctx->blend_sub_walk = env_int("WS_BLEND_SUBWALK", 1) != 0;
     ctx->blend_lds_pad_kb = env_int("WS_BLEND_LDS_PAD_KB", 0);
     if (ctx->blend_lds_pad_kb < 0 || ctx->blend_lds_pad_kb > 96) ctx->blend_lds_pad_kb = 0;
     if (const char* shape = std::getenv("WS_TILE_SHAPE")) {  // tuning / A-B: quadrants per tile
@@ -349,13 +348,6 @@ int ws_debug_stage_splat(const uint32_t splat[5], float viewport_w, float viewpo
     if (!splat || !rec || !quadrant_mask) return fail(WS_ERR_INVALID, "ws_debug_stage_splat: null argument");
     return debug_stage_splat(splat, viewport_w, viewport_h, tile_x0, tile_y0, tile_w / QUAD, tile_h / QUAD, rec,
                              quadrant_mask);
-}
-
-int ws_debug_stage_splat_sub(const uint32_t splat[5], float viewport_w, float viewport_h, float tile_x0, float tile_y0,
-                             uint32_t tile_w, uint32_t tile_h, float rec[10], uint32_t* quadrant_mask, uint64_t* subblock_mask) {
-    if (!splat || !rec || !quadrant_mask || !subblock_mask) return fail(WS_ERR_INVALID, "ws_debug_stage_splat_sub: null argument");
-    return debug_stage_splat(splat, viewport_w, viewport_h, tile_x0, tile_y0, tile_w / QUAD, tile_h / QUAD, rec,
-                             quadrant_mask, subblock_mask);
 }
 
 int ws_sync(ws_context* ctx, void* stream) {
@@ -900,7 +892,6 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.format = (int)r->format;
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
     bp.lds_pad_kb = r->ctx->blend_lds_pad_kb;
-    bp.sub_walk = r->ctx->blend_sub_walk;
     bp.counters = r->counters;
     bp.sticky = r->sticky;
     bp.debug_consumed = r->capture ? r->debug_consumed : nullptr;

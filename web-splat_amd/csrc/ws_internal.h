@@ -257,7 +257,6 @@ struct BlendParams {
     int format;
     int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
     int lds_pad_kb;             // tuning: extra (unused) dynamic LDS per workgroup, limits workgroups per CU
-    int sub_walk;               // 1: batches of pixel-sized splats are composited by the lane-group walk (WS_BLEND_SUBWALK=0 disables)
     const FrameCounters* counters;  // this frame's counters: the error bits are folded into *sticky by the blend
     uint32_t* sticky;           // per-renderer error word that is NOT zeroed per frame (ws_renderer_errors)
     uint32_t* debug_consumed;   // nullptr, or [tiles]: entries of each tile's list the blend walked (capture mode)
@@ -266,7 +265,7 @@ struct BlendParams {
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
 int launch_empty(hipStream_t stream);
 int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, float tile_y0, uint32_t qw, uint32_t qh,
-                      float rec[10], uint32_t* mask, uint64_t* sub_mask = nullptr);
+                      float rec[10], uint32_t* mask);
 
 // ---- PLY row decode on the GPU (ply_decode.hip) -------------------------------------------------------
 int launch_ply_decode(const float* d_rows, uint32_t n, uint32_t sh_deg, uint4* planes, hipStream_t stream);
@@ -293,7 +292,6 @@ struct ws_context {
     int debug_cut = 0;        // WS_DEBUG_CUT (analysis): 0 = whole frame
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
-    int blend_sub_walk = 1;   // WS_BLEND_SUBWALK=0: never use the lane-group walk (A/B)
     uint32_t tile_qw = 4, tile_qh = 4;  // WS_TILE_SHAPE = 2x2 | 4x2 | 4x4 (default: 32x32-px binning tiles)
 };
 

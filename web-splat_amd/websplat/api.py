@@ -147,18 +147,6 @@ def stage_splat(words, viewport, tile_origin, tile_size=(16, 16)):
     return np.array(rec[:], dtype=np.float32), mask.value
 
 
-def stage_splat_sub(words, viewport, tile_origin, tile_size=(32, 32)):
-    """As stage_splat, plus the 4x4-pixel sub-block mask: (rec[10], quadrant mask, sub-block mask)."""
-    w = (C.c_uint32 * 5)(*[int(x) for x in words])
-    rec = (C.c_float * 10)()
-    mask = C.c_uint32()
-    sub = C.c_uint64()
-    check(lib.ws_debug_stage_splat_sub(w, float(viewport[0]), float(viewport[1]), float(tile_origin[0]),
-                                       float(tile_origin[1]), int(tile_size[0]), int(tile_size[1]), rec, C.byref(mask),
-                                       C.byref(sub)))
-    return np.array(rec[:], dtype=np.float32), mask.value, sub.value
-
-
 class Context:
     def __init__(self, device: int = 0):
         h = C.c_void_p()
