@@ -4,7 +4,7 @@ sys.path[:0] = [os.path.join(ROOT, "web-splat_amd"), os.path.join(ROOT, "tests")
 import numpy as np, torch
 import websplat as ws, bench
 ctx = ws.Context(0)
-gpc, views, (w, h) = bench.build_workload(ws, "c2", 64)
+gpc, views, (w, h), _ = bench.build_workload(ws, "c2", 64)
 pc = ws.PointCloud(ctx, gpc)
 K = 1000
 def run_python(ns, null_first=True):

@@ -6,7 +6,7 @@ sys.path[:0] = ["web-splat_amd", "tests", "."]
 import numpy as np, torch
 import websplat as ws, bench
 ctx = ws.Context(0)
-gpc, views, (w, h) = bench.build_workload(ws, sys.argv[1] if len(sys.argv) > 1 else "c2", 64)
+gpc, views, (w, h), _ = bench.build_workload(ws, sys.argv[1] if len(sys.argv) > 1 else "c2", 64)
 pc = ws.PointCloud(ctx, gpc)
 for ns in (1, 4):
     rs = [ws.GaussianRenderer(ctx, "rgba32float", 3, False) for _ in range(ns)]
