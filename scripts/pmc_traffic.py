@@ -28,10 +28,11 @@ def label_of(name):
         return "depth:k_dsort_hist"
     if "k_dsort_scatter" in name:
         return "depth:k_dsort_scatter"
-    m = re.search(r"k_sort_scatter<(?:false|true), (\d+), (?:false|true), (\d+)>", name)
-    if m:  # <LOOKBACK, KPT, RANGES, BITS>: the depth sort uses 8-bit digits, the tile-id sort 6..7 below 2^15 tiles
-        kpt, bits = int(m.group(1)), int(m.group(2))
-        which = "depth" if (bits == 8 and "true, 8>" not in name) or kpt == 4 else "tiles"
+    m = re.search(r"k_sort_scatter<(?:false|true), (\d+), (false|true), (\d+)(?:, (false|true))?>", name)
+    if m:  # <LOOKBACK, KPT, RANGES, BITS, CARRY>: the depth sort carries the tile rectangles (CARRY); the tile-id sort does not
+        carry = m.group(4) == "true"
+        kpt, bits = int(m.group(1)), int(m.group(3))
+        which = "depth" if carry or (bits == 8 and m.group(2) == "false" and kpt == 4) else "tiles"
         return f"{which}:k_sort_scatter"
     m = re.search(r"k_sort_tile_hist<(\d+)>", name)
     if m:
