@@ -322,3 +322,49 @@ def test_c3_full_image_vs_oracle(ws, ctx, oracle):
     """BASELINE config 3 at full size: 5 M Gaussians, 1920x1080 (the sort stress), image against the oracle."""
     _full_parity(ws, ctx, oracle, "c3", _scene_rows("c3"), [(0, synth.camera_c3(1920, 1080))], (1920, 1080))
     _SCENE_CACHE.clear()
+
+
+def test_frame_graph_replay_equals_launch_by_launch(ws, oracle, monkeypatch):
+    """prepare() on a real stream replays a captured frame graph (one graph launch + one kernel-argument update per
+    frame, a ring of executable graphs); twelve frames enqueued back to back on ONE stream -- three times the ring --
+    must give, view by view, the images of the launch-by-launch path (WS_GRAPH=0), and so must a second point cloud and
+    a second viewport on the same renderer (the graph is re-captured)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    cams = synth.orbit_cameras(12, 800, 600, 800.0, 800.0)
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("WS_GRAPH", mode)
+        c = ws.Context(0)
+        s = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0
+        try:
+            imgs = []
+            r = ws.GaussianRenderer(c, "rgba32float", 3, False)
+            for n, vp in ((200_000, (800, 600)), (120_000, (800, 600)), (120_000, (640, 360))):
+                sc = scenes.c2(ws, oracle, n=n, viewport=vp)
+                pc = ws.PointCloud(c, sc.gpc)
+                views = []
+                for cj in synth.orbit_cameras(12, vp[0], vp[1], float(vp[0]), float(vp[0])):
+                    cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, *vp)
+                    cam.fit_near_far(sc.gpc.aabb)
+                    views.append(ws.SplattingArgs(camera=cam, viewport=vp, max_sh_deg=3))
+                bufs = [c.malloc(vp[0] * vp[1] * 16) for _ in views]
+                for v, b in zip(views, bufs):                  # twelve frames, no sync in between
+                    r.prepare(pc, v, stream=s.value)
+                    r.render(pc, target_ptr=b, pitch=vp[0] * 16, stream=s.value)
+                c.sync(s.value)
+                assert r.errors()[0] == 0
+                imgs += [c.download(b, (vp[1], vp[0], 4), np.float32) for b in bufs]
+                for b in bufs:
+                    c.free(b)
+                pc.close()
+            r.close()
+            results[mode] = imgs
+        finally:
+            hip.hipStreamDestroy(s)
+            c.close()
+    assert len(results["1"]) == 36
+    for a, b in zip(results["1"], results["0"]):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(results["1"][0], results["1"][1])

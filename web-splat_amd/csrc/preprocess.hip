@@ -583,6 +583,7 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
         }
     }
     if (tid == 0) lb::st(b.block_status + bid, lb::pack(p.epoch, bid == 0 ? lb::FLAG_INCL : lb::FLAG_AGG, block_cnt));
+    if (tid == 0 && bid == 0) b.counters->epoch = p.epoch;  // for the later kernels of the frame (k_bin_prefix)
 
     // ---- back end, only for survivors --------------------------------------------------------------------
     SplatOut so[K1_ITEMS];
@@ -676,6 +677,10 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
 }
 
 }  // namespace
+
+const void* preprocess_kernel_func(bool compressed) {
+    return compressed ? reinterpret_cast<const void*>(&k_preprocess<true>) : reinterpret_cast<const void*>(&k_preprocess<false>);
+}
 
 uint32_t preprocess_blocks(uint32_t n) { return (n + K1_THREADS * K1_ITEMS - 1) / (K1_THREADS * K1_ITEMS); }
 

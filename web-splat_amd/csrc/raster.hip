@@ -73,14 +73,14 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
                                                            uint32_t* __restrict__ offsets,
                                                            uint32_t* __restrict__ emit_start,
                                                            uint64_t* __restrict__ status,
-                                                           FrameCounters* __restrict__ counters, uint32_t entry_cap,
-                                                           uint32_t epoch) {
+                                                           FrameCounters* __restrict__ counters, uint32_t entry_cap) {
     constexpr int BIN_ITEMS = BIN_THREADS * BIN_IPT;
     __shared__ uint32_t s_tmp[BIN_THREADS / 64];
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_base;
     const uint32_t v = counters->num_visible;
     if ((uint64_t)blockIdx.x * BIN_ITEMS >= v) return;  // surplus workgroups leave before drawing a ticket
+    const uint32_t epoch = counters->epoch;  // the frame's look-back epoch, left by K1
     const int tid = threadIdx.x;
     // Workgroup ids are handed out by an atomic ticket = START order: a workgroup only ever waits for workgroups that
     // already hold their slot.  (blockIdx order -- -DWS_BLOCKIDX_ORDER -- saves the ~11 ns the returning atomic costs
@@ -795,7 +795,7 @@ int launch_bin_prefix(const BinBuffers& b, hipStream_t stream) {
     const uint32_t blocks = bin_prefix_blocks(b.max_points);
     if (blocks == 0) return WS_OK;
     hipLaunchKernelGGL(k_bin_prefix<BIN_IPT>, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.rects_sorted, b.offsets,
-                       b.emit_start, b.block_status, b.counters, b.entry_cap, b.epoch);
+                       b.emit_start, b.block_status, b.counters, b.entry_cap);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }

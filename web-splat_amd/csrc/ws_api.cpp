@@ -123,6 +123,26 @@ struct ws_renderer {
     uint32_t epoch = 0;
     uint32_t* sticky = nullptr;      // device error word that survives the per-frame memset (ws_renderer_errors)
 
+    // The frame's launch sequence of prepare() (memset + 21 kernels), captured once per (point cloud, scratch) and replayed:
+    // only K1's arguments change from frame to frame (camera / settings uniforms, epoch).  A ring of executable graphs,
+    // because updating an executable graph's kernel arguments while an earlier launch of it has not run yet would change
+    // that earlier frame: slot i is reused only after the event recorded behind its last launch has completed.
+    static constexpr int GRAPH_RING = 4;
+    struct FrameGraph {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec[GRAPH_RING] = {};
+        hipEvent_t done[GRAPH_RING] = {};
+        bool used[GRAPH_RING] = {};
+        hipGraphNode_t k1_node = nullptr;
+        hipKernelNodeParams k1_params{};
+        const ws_pointcloud* pc = nullptr;
+        uint64_t generation = 0;   // scratch generation the graph was captured for
+        uint32_t next = 0;
+        bool valid = false;
+        uint32_t *sorted_idx = nullptr, *sorted_keys = nullptr, *rects_sorted = nullptr, *entries_sorted = nullptr;
+    } fg;
+    uint64_t scratch_generation = 0;
+
     // last prepared frame
     bool prepared = false;
     const ws_pointcloud* prepared_pc = nullptr;
@@ -171,7 +191,19 @@ static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, bool 
     return WS_OK;
 }
 
+static void renderer_free_graph(ws_renderer* r) {
+    ws_renderer::FrameGraph& g = r->fg;
+    for (int i = 0; i < ws_renderer::GRAPH_RING; ++i) {
+        if (g.exec[i]) (void)hipGraphExecDestroy(g.exec[i]);
+        if (g.done[i]) (void)hipEventDestroy(g.done[i]);
+    }
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+    g = ws_renderer::FrameGraph();
+}
+
 static void renderer_free_scratch(ws_renderer* r) {
+    renderer_free_graph(r);
+    ++r->scratch_generation;
     dfree(r->splats);
     dfree(r->keys_a);
     dfree(r->keys_b);
@@ -321,6 +353,7 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
     if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
+    ctx->use_graph = env_int("WS_GRAPH", 1);
     ctx->blend_lds_pad_kb = env_int("WS_BLEND_LDS_PAD_KB", 0);
     if (ctx->blend_lds_pad_kb < 0 || ctx->blend_lds_pad_kb > 96) ctx->blend_lds_pad_kb = 0;
     if (const char* shape = std::getenv("WS_TILE_SHAPE")) {  // tuning / A-B: quadrants per tile
@@ -678,75 +711,10 @@ int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries) {
     return WS_OK;
 }
 
-int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatting_args* args, void* stream_v) {
-    if (!r || !pc || !args) return fail(WS_ERR_INVALID, "ws_renderer_prepare: null argument");
-    if (pc->compressed != r->compressed)
-        return fail(WS_ERR_INVALID, "ws_renderer_prepare: renderer and point cloud disagree on `compressed`");
-    // a splat's tile rectangle is packed into 4 bytes (ws_internal.h): at most 256 binning tiles per axis = 8192 px with
-    // the default 32-px tile -- the default wgpu max_texture_dimension_2d of the reference's render targets
-    if (args->viewport[0] == 0 || args->viewport[1] == 0 ||
-        args->viewport[0] > RECT_MAX_TILES_PER_AXIS * QUAD * r->ctx->tile_qw ||
-        args->viewport[1] > RECT_MAX_TILES_PER_AXIS * QUAD * r->ctx->tile_qh)
-        return fail(WS_ERR_INVALID, "ws_renderer_prepare: bad viewport (at most 256 binning tiles per axis: 8192 px at 32-px tiles)");
-    if (args->max_sh_deg > 3) return fail(WS_ERR_UNSUPPORTED, "ws_renderer_prepare: max_sh_deg > 3");
-    if (!pc->compressed && args->max_sh_deg > pc->sh_deg) {
-        // the 96-B record always holds 16 coefficients (zeros above the file's degree): harmless, as in the reference
-    }
-    if (pc->compressed && args->max_sh_deg > r->sh_deg)
-        return fail(WS_ERR_INVALID, "ws_renderer_prepare: max_sh_deg exceeds the renderer's SH layout degree");
-    if (pc->compressed && pc->sh_deg > r->sh_deg)
-        return fail(WS_ERR_INVALID, "ws_renderer_prepare: compressed point cloud has a higher SH degree than the renderer was created for");
-    hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    r->prepared = false;
-    int rc = renderer_ensure_scratch(r, pc->num_points, args->viewport[0], args->viewport[1]);
-    if (rc) return rc;
-
-    K1Params kp;
-    std::memset(&kp, 0, sizeof kp);
-    build_camera_uniform(args->camera, args->viewport, &kp.cam);
-    if ((rc = ws_build_settings_uniform(args, pc, &kp.rs))) return rc;
-    kp.quant = pc->quant;
-    kp.num_points = pc->num_points;
-    // stride of the packed int8 SH records: the POINT CLOUD's degree (the records were laid out by its loader); a
-    // renderer created for another degree must not re-interpret them (WebGPU would clamp the reads, HIP would not)
-    kp.sh_deg_layout = (pc->sh_deg + 1) * (pc->sh_deg + 1);
-    kp.tiles_x = r->tiles_x;
-    kp.tiles_y = r->tiles_y;
-    kp.tile_w_log2 = r->ctx->tile_qw == 4 ? 5u : 4u;
-    kp.tile_h_log2 = r->ctx->tile_qh == 4 ? 5u : 4u;
-    kp.znear = -kp.cam.proj[3 * 4 + 2] / kp.cam.proj[2 * 4 + 2];
-    kp.zfar = -kp.cam.proj[3 * 4 + 2] / (kp.cam.proj[2 * 4 + 2] - 1.0f);
-    // fade-in (preprocess.wgsl:196-203): dd = 5 |centre - xyz| / extend <= 10 because the centroid lies inside the
-    // bbox and extend >= its radius; beyond walltime 11 s smoothstep(walltime - dd) is exactly 1 for every Gaussian.
-    // (the clip box only removes Gaussians, so the bound holds for user boxes too)
-    kp.fade_done = (kp.rs.walltime >= 11.0f && kp.rs.scene_extend > 0.0f && std::isfinite(kp.rs.scene_extend) &&
-                    !args->has_clipping_box) ? 1u : 0u;
-
-    K1Buffers kb;
-    kb.planes = pc->planes;
-    kb.gaussians_c = pc->gaussians_c;
-    kb.sh_bytes = pc->sh_bytes;
-    kb.covars = pc->covars;
-    kb.splats = r->splats;
-    kb.keys = r->keys_a;
-    kb.rects = r->rects_a;
-    kb.key_range = r->zero->key_range;
-    kb.src_index = r->capture ? r->src_index : nullptr;
-    kb.block_status = r->k1_status;
-    kb.counters = r->counters;
-
-    // look-back epoch of this frame (lookback.h); on wrap-around the status arrays are re-zeroed
-    if (++r->epoch == 0) {
-        WS_HIP(hipMemsetAsync(r->k1_status, 0, ((size_t)preprocess_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
-        WS_HIP(hipMemsetAsync(r->bin_status, 0, ((size_t)bin_prefix_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
-        WS_HIP(hipMemsetAsync(r->dsort.status, 0, depth_sort_group_words() * sizeof(uint64_t), stream));
-        if (r->ctx->sort_algo == 1) {
-            WS_HIP(hipMemsetAsync(r->sort_depth.status, 0, 4 * (size_t)r->sort_depth.tiles * RADIX * sizeof(uint64_t), stream));
-            WS_HIP(hipMemsetAsync(r->sort_tiles.status, 0, 4 * (size_t)r->sort_tiles.tiles * RADIX * sizeof(uint64_t), stream));
-        }
-        r->epoch = 1;
-    }
-    kp.epoch = r->epoch;
+// The frame's launch sequence behind prepare(): reset -> K1 -> depth sort -> binning -> tile-id sort.  Enqueued launch
+// by launch, or once under stream capture (ws_renderer_prepare replays the captured graph afterwards).
+static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params& kp, const K1Buffers& kb, hipStream_t stream) {
+    int rc;
     // GPURSSorter::record_reset_indirect_buffer (gpu_rs.rs:720-727): keys_size = 0, dispatch = 0 -- here ONE
     // memset clears the counters, every ticket, both sorts' digit histograms and the tile ranges
     WS_HIP(hipMemsetAsync(r->zero, 0, r->zero_bytes, stream));
@@ -818,7 +786,6 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     bb.max_points = pc->num_points;
     bb.tiles_x = r->tiles_x;
     bb.tiles_y = r->tiles_y;
-    bb.epoch = r->epoch;
     // the emit kernel cuts the entry list into the same 4096-entry tiles the radix sort uses, so it can hand
     // the sort the digit counts of its first pass for free
     const bool fused_hist = r->ctx->sort_algo != 1 && sort_tile_size(r->entry_cap) == (uint32_t)EMIT_TILE;
@@ -860,6 +827,147 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         WS_HIP(hipEventRecord(r->ev[3], stream));
         r->ev_prepare_valid = true;
     }
+    r->prepared = true;
+    r->prepared_pc = pc;
+    r->last_stream = stream;
+    return WS_OK;
+}
+
+int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatting_args* args, void* stream_v) {
+    if (!r || !pc || !args) return fail(WS_ERR_INVALID, "ws_renderer_prepare: null argument");
+    if (pc->compressed != r->compressed)
+        return fail(WS_ERR_INVALID, "ws_renderer_prepare: renderer and point cloud disagree on `compressed`");
+    // a splat's tile rectangle is packed into 4 bytes (ws_internal.h): at most 256 binning tiles per axis = 8192 px with
+    // the default 32-px tile -- the default wgpu max_texture_dimension_2d of the reference's render targets
+    if (args->viewport[0] == 0 || args->viewport[1] == 0 ||
+        args->viewport[0] > RECT_MAX_TILES_PER_AXIS * QUAD * r->ctx->tile_qw ||
+        args->viewport[1] > RECT_MAX_TILES_PER_AXIS * QUAD * r->ctx->tile_qh)
+        return fail(WS_ERR_INVALID, "ws_renderer_prepare: bad viewport (at most 256 binning tiles per axis: 8192 px at 32-px tiles)");
+    if (args->max_sh_deg > 3) return fail(WS_ERR_UNSUPPORTED, "ws_renderer_prepare: max_sh_deg > 3");
+    if (!pc->compressed && args->max_sh_deg > pc->sh_deg) {
+        // the 96-B record always holds 16 coefficients (zeros above the file's degree): harmless, as in the reference
+    }
+    if (pc->compressed && args->max_sh_deg > r->sh_deg)
+        return fail(WS_ERR_INVALID, "ws_renderer_prepare: max_sh_deg exceeds the renderer's SH layout degree");
+    if (pc->compressed && pc->sh_deg > r->sh_deg)
+        return fail(WS_ERR_INVALID, "ws_renderer_prepare: compressed point cloud has a higher SH degree than the renderer was created for");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    r->prepared = false;
+    int rc = renderer_ensure_scratch(r, pc->num_points, args->viewport[0], args->viewport[1]);
+    if (rc) return rc;
+
+    K1Params kp;
+    std::memset(&kp, 0, sizeof kp);
+    build_camera_uniform(args->camera, args->viewport, &kp.cam);
+    if ((rc = ws_build_settings_uniform(args, pc, &kp.rs))) return rc;
+    kp.quant = pc->quant;
+    kp.num_points = pc->num_points;
+    // stride of the packed int8 SH records: the POINT CLOUD's degree (the records were laid out by its loader); a
+    // renderer created for another degree must not re-interpret them (WebGPU would clamp the reads, HIP would not)
+    kp.sh_deg_layout = (pc->sh_deg + 1) * (pc->sh_deg + 1);
+    kp.tiles_x = r->tiles_x;
+    kp.tiles_y = r->tiles_y;
+    kp.tile_w_log2 = r->ctx->tile_qw == 4 ? 5u : 4u;
+    kp.tile_h_log2 = r->ctx->tile_qh == 4 ? 5u : 4u;
+    kp.znear = -kp.cam.proj[3 * 4 + 2] / kp.cam.proj[2 * 4 + 2];
+    kp.zfar = -kp.cam.proj[3 * 4 + 2] / (kp.cam.proj[2 * 4 + 2] - 1.0f);
+    // fade-in (preprocess.wgsl:196-203): dd = 5 |centre - xyz| / extend <= 10 because the centroid lies inside the
+    // bbox and extend >= its radius; beyond walltime 11 s smoothstep(walltime - dd) is exactly 1 for every Gaussian.
+    // (the clip box only removes Gaussians, so the bound holds for user boxes too)
+    kp.fade_done = (kp.rs.walltime >= 11.0f && kp.rs.scene_extend > 0.0f && std::isfinite(kp.rs.scene_extend) &&
+                    !args->has_clipping_box) ? 1u : 0u;
+
+    K1Buffers kb;
+    kb.planes = pc->planes;
+    kb.gaussians_c = pc->gaussians_c;
+    kb.sh_bytes = pc->sh_bytes;
+    kb.covars = pc->covars;
+    kb.splats = r->splats;
+    kb.keys = r->keys_a;
+    kb.rects = r->rects_a;
+    kb.key_range = r->zero->key_range;
+    kb.src_index = r->capture ? r->src_index : nullptr;
+    kb.block_status = r->k1_status;
+    kb.counters = r->counters;
+
+    // look-back epoch of this frame (lookback.h); on wrap-around the status arrays are re-zeroed
+    if (++r->epoch == 0) {
+        WS_HIP(hipMemsetAsync(r->k1_status, 0, ((size_t)preprocess_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
+        WS_HIP(hipMemsetAsync(r->bin_status, 0, ((size_t)bin_prefix_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
+        WS_HIP(hipMemsetAsync(r->dsort.status, 0, depth_sort_group_words() * sizeof(uint64_t), stream));
+        if (r->ctx->sort_algo == 1) {
+            WS_HIP(hipMemsetAsync(r->sort_depth.status, 0, 4 * (size_t)r->sort_depth.tiles * RADIX * sizeof(uint64_t), stream));
+            WS_HIP(hipMemsetAsync(r->sort_tiles.status, 0, 4 * (size_t)r->sort_tiles.tiles * RADIX * sizeof(uint64_t), stream));
+        }
+        r->epoch = 1;
+    }
+    kp.epoch = r->epoch;
+    const int cut_mode = r->ctx->debug_cut;
+    // A captured frame graph (one hipGraphLaunch + one kernel-argument update instead of 22 launches + a memset on the host)
+    // when the caller gave a real stream and no per-launch instrumentation is on.  The legacy NULL stream cannot be captured.
+    const bool use_graph = r->ctx->use_graph && stream != nullptr && !r->marks.active && !r->timers && !r->capture &&
+                           cut_mode == 0 && r->ctx->sort_algo == 0 && !r->ctx->depth_sort_adaptive;
+    if (!use_graph) return enqueue_frame(r, pc, kp, kb, stream);
+    ws_renderer::FrameGraph& g = r->fg;
+    if (!(g.valid && g.pc == pc && g.generation == r->scratch_generation)) {
+        renderer_free_graph(r);
+        WS_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_frame(r, pc, kp, kb, stream);
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(stream, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            r->prepared = false;
+            return rc;
+        }
+        if (ce != hipSuccess || !graph) return hip_fail(ce, "ws_renderer_prepare: stream capture");
+        g.graph = graph;
+        // K1's node: the one kernel node whose function is the preprocess kernel
+        size_t nn = 0;
+        WS_HIP(hipGraphGetNodes(graph, nullptr, &nn));
+        std::vector<hipGraphNode_t> nodes(nn);
+        WS_HIP(hipGraphGetNodes(graph, nodes.data(), &nn));
+        const void* k1_func = preprocess_kernel_func(pc->compressed);
+        for (size_t i = 0; i < nn && !g.k1_node; ++i) {
+            hipGraphNodeType ty;
+            if (hipGraphNodeGetType(nodes[i], &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
+            hipKernelNodeParams kn;
+            if (hipGraphKernelNodeGetParams(nodes[i], &kn) != hipSuccess) continue;
+            if (kn.func == k1_func) {
+                g.k1_node = nodes[i];
+                g.k1_params = kn;
+            }
+        }
+        if (!g.k1_node) {
+            renderer_free_graph(r);
+            return fail(WS_ERR_HIP, "ws_renderer_prepare: the preprocess kernel was not found in the captured frame graph");
+        }
+        for (int i = 0; i < ws_renderer::GRAPH_RING; ++i) {
+            WS_HIP(hipGraphInstantiate(&g.exec[i], graph, nullptr, nullptr, 0));
+            WS_HIP(hipEventCreateWithFlags(&g.done[i], hipEventDisableTiming));
+        }
+        g.pc = pc;
+        g.generation = r->scratch_generation;
+        g.sorted_idx = r->sorted_idx;
+        g.sorted_keys = r->sorted_keys;
+        g.rects_sorted = r->rects_sorted;
+        g.entries_sorted = r->entries_sorted;
+        g.valid = true;
+    }
+    const int slot = (int)(g.next++ % ws_renderer::GRAPH_RING);
+    if (g.used[slot]) WS_HIP(hipEventSynchronize(g.done[slot]));  // an earlier launch of this executable graph must have run
+    void* k1_args[2] = {const_cast<K1Params*>(&kp), const_cast<K1Buffers*>(&kb)};
+    hipKernelNodeParams np = g.k1_params;
+    np.kernelParams = k1_args;
+    np.extra = nullptr;
+    WS_HIP(hipGraphExecKernelNodeSetParams(g.exec[slot], g.k1_node, &np));
+    WS_HIP(hipGraphLaunch(g.exec[slot], stream));
+    WS_HIP(hipEventRecord(g.done[slot], stream));
+    g.used[slot] = true;
+    r->sorted_idx = g.sorted_idx;
+    r->sorted_keys = g.sorted_keys;
+    r->rects_sorted = g.rects_sorted;
+    r->entries_sorted = g.entries_sorted;
     r->prepared = true;
     r->prepared_pc = pc;
     r->last_stream = stream;

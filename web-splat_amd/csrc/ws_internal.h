@@ -43,7 +43,9 @@ struct FrameCounters {
     uint32_t sort_ticket[8]; // per-pass tile dispensers: [0..3] depth sort, [4..7] tile sort
     uint32_t bin_ticket;     // block dispenser of the binning prefix kernel
     uint32_t entries_needed; // D before clamping to the capacity (what a retry has to allocate)
-    uint32_t _pad[2];
+    uint32_t epoch;          // look-back epoch of the frame, written by K1 (the only kernel whose arguments change per
+                             // frame: later kernels read it here, so that a captured frame graph replays with ONE update)
+    uint32_t _pad[1];
 };
 static_assert(sizeof(FrameCounters) == 64, "FrameCounters layout");
 
@@ -217,6 +219,7 @@ struct K1Buffers {
     uint32_t* key_range;         // FrameZero::key_range
 };
 int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, hipStream_t stream);
+const void* preprocess_kernel_func(bool compressed);  // host-side kernel symbol (identifies K1's node in a captured graph)
 uint32_t preprocess_blocks(uint32_t n);
 
 // ---- binning + blend ----------------------------------------------------------------------------
@@ -239,7 +242,6 @@ struct BinBuffers {
     FrameCounters* counters;
     uint32_t max_points;         // N (upper bound of V)
     uint32_t tiles_x, tiles_y;
-    uint32_t epoch;
 };
 int launch_bin_prefix(const BinBuffers& b, hipStream_t stream);
 int launch_bin_emit(const BinBuffers& b, hipStream_t stream);
@@ -292,6 +294,7 @@ struct ws_context {
     int debug_cut = 0;        // WS_DEBUG_CUT (analysis): 0 = whole frame
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
+    int use_graph = 1;        // WS_GRAPH=0: enqueue every frame launch by launch instead of replaying the captured frame graph
     uint32_t tile_qw = 4, tile_qh = 4;  // WS_TILE_SHAPE = 2x2 | 4x2 | 4x4 (default: 32x32-px binning tiles)
 };
 
