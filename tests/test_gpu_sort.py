@@ -8,23 +8,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[1, 0, "adaptive", "twolevel"], ids=["onesweep", "reduce_scan", "depth3pass", "depth2level"])
+@pytest.fixture(scope="module", params=[1, 0, "depth"], ids=["onesweep", "reduce_scan", "depth3pass"])
 def sort_ctx(ws, request):
-    """Four paths to the same contract: the generic sorter's one-sweep and reduce-then-scan cross-tile prefixes, and
-    the depth-sort specialisations behind ws_sorter_sort_depth -- three range-adaptive digit passes, and the two-level
-    form (one partition pass on the top bits + bucket-local LDS sorts)."""
-    depth = request.param in ("adaptive", "twolevel")
-    old = {k: os.environ.get(k) for k in ("WS_SORT_ALGO", "WS_DEPTH_SORT")}
-    os.environ["WS_SORT_ALGO"] = "0" if depth else str(request.param)
-    if depth:
-        os.environ["WS_DEPTH_SORT"] = request.param
+    """Three paths to the same contract: the generic sorter's one-sweep and reduce-then-scan cross-tile prefixes, and
+    the renderer's range-adaptive three-pass depth sort (ws_sorter_sort_depth)."""
+    old = os.environ.get("WS_SORT_ALGO")
+    os.environ["WS_SORT_ALGO"] = str(request.param) if request.param != "depth" else "0"
     c = ws.Context(0)
-    c.depth_mode = depth
-    for k, v in old.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    c.depth_mode = request.param == "depth"
+    if old is None:
+        del os.environ["WS_SORT_ALGO"]
+    else:
+        os.environ["WS_SORT_ALGO"] = old
     yield c
     c.close()
 
@@ -120,52 +115,10 @@ def test_sort_large_sortedness(ws, sort_ctx):
     assert np.all(p[1:][ties] > p[:-1][ties])
 
 
-@pytest.fixture(scope="module", params=["adaptive", "twolevel"])
-def depth_ctx(ws, request):
-    old = os.environ.get("WS_DEPTH_SORT")
-    os.environ["WS_DEPTH_SORT"] = request.param
-    c = ws.Context(0)
-    if old is None:
-        del os.environ["WS_DEPTH_SORT"]
-    else:
-        os.environ["WS_DEPTH_SORT"] = old
-    yield c
-    c.close()
-
-
-@pytest.mark.parametrize("shape", ["one_hot_bucket", "two_hot_buckets", "hot_and_duplicates", "staircase"])
-def test_depth_sort_oversize_buckets(ws, depth_ctx, oracle, shape):
-    """Key distributions that put far more than an LDS-sortable bucket into one top digit of the two-level sort (a depth
-    range 2^-10 of the frame's with a hundred thousand distinct keys): the in-global-memory path of k_dsort_local."""
-    rng = np.random.default_rng(42)
-    n = 400_000
-    keys = rng.integers(0, 1 << 30, size=n, dtype=np.uint64).astype(np.uint32)       # nbits = 30: 2^20-wide top digits
-    if shape == "one_hot_bucket":
-        keys[:150_000] = (0x12300000 + rng.integers(0, 1 << 13, size=150_000)).astype(np.uint32)
-    elif shape == "two_hot_buckets":
-        keys[:90_000] = (0x05500000 + rng.integers(0, 1 << 19, size=90_000)).astype(np.uint32)
-        keys[90_000:200_000] = (0x3A100000 + rng.integers(0, 1 << 9, size=110_000)).astype(np.uint32)
-    elif shape == "hot_and_duplicates":
-        keys[:200_000] = (0x20000000 + rng.integers(0, 40, size=200_000) * 977).astype(np.uint32)
-    else:
-        keys[:300_000] = (0x10000000 + (np.arange(300_000) // 7) * 3).astype(np.uint32)[::-1]
-    rng.shuffle(keys)
-    sorter = ws.GPURSSorter(depth_ctx, n)
-    try:
-        aux_in = (np.arange(n, dtype=np.uint32) * np.uint32(40503)) ^ np.uint32(0xA5A5A5A5)
-        k, p, ax = sorter.sort_host(keys, np.arange(n, dtype=np.uint32), depth=True, aux=aux_in)
-    finally:
-        sorter.close()
-    ok, op = oracle.sort_pairs(keys, np.arange(n, dtype=np.uint32))
-    assert np.array_equal(k, ok) and np.array_equal(p, op) and np.array_equal(ax, aux_in[op])
-
-
 @pytest.mark.parametrize("nbits", [0, 1, 5, 12, 13, 20, 26, 27, 28, 30, 31, 32])
-def test_depth_sort_digit_width_follows_the_key_range(ws, depth_ctx, oracle, nbits):
-    """The depth sorts size their digits by bit_length(kmax - kmin): every width from 4 to 11 bits (three-pass form), every
-    split between the partition pass and the bucket sorts (two-level form), ranges that start anywhere (kmin is
-    subtracted), including the full 32 bits and a single value."""
-    ctx = depth_ctx
+def test_depth_sort_digit_width_follows_the_key_range(ws, ctx, oracle, nbits):
+    """The depth sort sizes its three digit passes by bit_length(kmax - kmin): every width from 4 to 11 bits, ranges that
+    start anywhere (kmin is subtracted), including the full 32 bits and a single value."""
     n = 300_001
     rng = np.random.default_rng(1000 + nbits)
     span = (1 << nbits) - 1 if nbits else 0

@@ -483,16 +483,6 @@ __device__ __forceinline__ DSortPlan dsort_plan(const uint32_t* __restrict__ key
     p.kmin = ~kmin_inv;
     const uint32_t range = kmax >= p.kmin ? kmax - p.kmin : 0u;  // (no keys at all: 0)
     const uint32_t nbits = range ? 32u - (uint32_t)__clz((int)range) : 0u;
-    if (pass == DSORT_TOP_PASS) {
-        // two-level sort: ONE partition pass on the top DSORT_TOP_BITS bits of key - kmin; the low `shift` bits are
-        // sorted bucket by bucket in LDS afterwards (k_dsort_local)
-        const uint32_t w = nbits < (uint32_t)DSORT_TOP_BITS ? (nbits < 4u ? 4u : nbits) : (uint32_t)DSORT_TOP_BITS;
-        p.w = w;
-        p.shift = nbits > w ? nbits - w : 0u;
-        p.mask = (1u << w) - 1u;
-        p.nb = 1u << w;
-        return p;
-    }
     uint32_t w = (nbits + (uint32_t)DSORT_PASSES - 1u) / (uint32_t)DSORT_PASSES;
     if (w < 4u) w = 4u;
     p.w = w;
@@ -502,17 +492,13 @@ __device__ __forceinline__ DSortPlan dsort_plan(const uint32_t* __restrict__ key
     return p;
 }
 
-// tiles are grouped for the cross-tile prefix: about one group per 16 tiles (a 16-wave workgroup counts its tiles in one
-// round), at least 32 and at most DSORT_MAX_GROUPS groups of `gt` consecutive tiles: few groups keep the look-back to
-// one or two windows on small inputs, many groups keep the chip busy on large ones
+// tiles are grouped for the cross-tile prefix: at most DSORT_MAX_GROUPS groups of `gt` consecutive tiles
 __device__ __forceinline__ uint32_t dsort_group_tiles(uint32_t ntiles) {
-    uint32_t groups = ntiles / 16u;
-    groups = groups < 32u ? 32u : (groups > (uint32_t)DSORT_MAX_GROUPS ? (uint32_t)DSORT_MAX_GROUPS : groups);
-    const uint32_t gt = (ntiles + groups - 1u) / groups;
+    const uint32_t gt = (ntiles + (uint32_t)DSORT_MAX_GROUPS - 1u) / (uint32_t)DSORT_MAX_GROUPS;
     return gt ? gt : 1u;
 }
 
-constexpr int DSORT_LB_WINDOW = 32;  // predecessor rows per look-back round trip
+constexpr int DSORT_LB_WINDOW = 16;  // predecessor rows per look-back round trip
 
 // ---- k_dsort_hist: per-tile digit counts + the whole cross-tile prefix, one launch ------------------------------
 // One 1024-thread workgroup = one GROUP of gt consecutive tiles (group ids from an atomic ticket: a workgroup only ever
@@ -559,12 +545,10 @@ __global__ __launch_bounds__(DH_THREADS) void k_dsort_hist(const uint32_t* __res
                                                           uint32_t* __restrict__ group_off,  // [groups][nb] of this pass
                                                           uint64_t* __restrict__ status,     // [groups][nb] of this pass
                                                           uint32_t* __restrict__ totals,     // [nb] of this pass: first output position of every digit
-                                                          uint32_t* __restrict__ ticket, uint32_t epoch_arg,
-                                                          const uint32_t* __restrict__ d_epoch,  // non-null: the epoch lives in device memory (renderer: left there by K1)
+                                                          uint32_t* __restrict__ ticket, uint32_t epoch,
                                                           uint32_t* __restrict__ error_word) {
     constexpr int TILE_N = SORT_THREADS * KPT;
-    constexpr int QPL = TILE_N / 256;
-    const uint32_t epoch = d_epoch ? *d_epoch : epoch_arg;                      // 16-byte key quads per lane and tile
+    constexpr int QPL = TILE_N / 256;                      // 16-byte key quads per lane and tile
     constexpr int MAX_DPT = DSORT_MAX_BINS / DH_THREADS;   // digits per thread in phase 2 (2 at 2048 bins)
     __shared__ uint32_t s_cnt[DH_WAVES][DSORT_MAX_BINS / 2];  // wave-private, two 16-bit counters per word (a tile has < 65536 keys)
     __shared__ uint32_t s_group;
@@ -867,241 +851,6 @@ __global__ __launch_bounds__(SORT_THREADS, WS_DSORT_MINWAVES) void k_dsort_scatt
     }
 }
 
-// ---- k_dsort_local: level two of the two-level depth sort -------------------------------------------------------------
-// After ONE stable partition pass on the top bits of key - kmin (k_dsort_hist + k_dsort_scatter with the DSORT_TOP_PASS
-// plan) the pairs are ordered by their top digit; what remains is to sort the low `shift` bits inside every digit -- local
-// work.  Digits are grouped into BUCKETS by their position: digit b belongs to bucket floor(first position of b /
-// DL_TARGET), so a bucket holds fewer than DL_TARGET pairs plus its last digit's, and every workgroup finds its bucket's
-// digits from the scanned digit totals alone (no plan kernel).  A bucket of up to DL_CAP pairs is sorted entirely in LDS:
-// stable LSD passes of 8 bits over (key - kmin - first key of the bucket), 16 waves, ballot ranking as in the scatter
-// kernels, keys and a 16-bit permutation ping-pong between two LDS buffers; payload and companion are gathered through the
-// permutation at the end.  A larger bucket -- a digit holding more than DL_CAP - DL_TARGET pairs: a depth range 2^-10 of
-// the frame's with thousands of splats -- is sorted by the same workgroup in global memory (correct for any input, slow,
-// never seen on the scenes measured).  With shift == 0 the partition pass has sorted everything: the buckets are copied.
-constexpr int DL_THREADS = 1024;
-constexpr int DL_WAVES = DL_THREADS / 64;
-constexpr int DL_KPT = 4;
-constexpr int DL_CAP = DL_THREADS * DL_KPT;   // 4096 pairs per LDS-sorted bucket
-constexpr uint32_t DL_TARGET = 2048u;
-
-// stable rank of this thread's DL_KPT elements (position order = (wave, j, lane)) by an 8-bit digit: position of each
-// element among the chunk's elements in digit-major order; s_cnt = [DL_WAVES][128] packed 16-bit counters, s_dig[256]
-// receives the first position of every digit.  All DL_THREADS threads call this (barriers inside).
-__device__ __forceinline__ void dl_rank(const uint32_t (&d)[DL_KPT], uint32_t (&pos)[DL_KPT], uint32_t* s_cnt /*[DL_WAVES*128]*/,
-                                        uint32_t* s_dig /*[256]*/, uint32_t* s_tmp /*[DL_WAVES]*/, uint32_t* digit_count) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < DL_WAVES * 128; i += DL_THREADS) s_cnt[i] = 0u;
-    __syncthreads();
-    const uint32_t lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xFFFFFFFFu;
-    const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
-    uint32_t info[DL_KPT];
-#pragma unroll
-    for (int j = 0; j < DL_KPT; ++j) {
-        uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
-#pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const uint32_t B = (uint32_t)(-(int32_t)((d[j] >> bit) & 1u));
-            const unsigned long long bal = __ballot(B != 0u);
-            mlo &= ~((uint32_t)bal ^ B);
-            mhi &= ~((uint32_t)(bal >> 32) ^ B);
-        }
-        const uint32_t below = (uint32_t)__popc(mlo & lt_lo) + (uint32_t)__popc(mhi & lt_hi);
-        const uint32_t leader = mlo ? (uint32_t)(__ffs((int)mlo) - 1) : 32u + (uint32_t)(__ffs((int)mhi) - 1);
-        const uint32_t cnt = (below == 0u) ? (uint32_t)(__popc(mlo) + __popc(mhi)) : 0u;
-        info[j] = below | (leader << 8) | (cnt << 16);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    uint32_t prev[DL_KPT];
-#pragma unroll
-    for (int j = 0; j < DL_KPT; ++j) {
-        prev[j] = 0u;
-        if (info[j] >> 16) {
-            const uint32_t sft = (d[j] & 1u) * 16u;
-            const uint32_t old = atomicAdd(&s_cnt[((uint32_t)wave * 256u + d[j]) >> 1], (info[j] >> 16) << sft);
-            prev[j] = (old >> sft) & 0xFFFFu;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < DL_KPT; ++j) pos[j] = __shfl(prev[j], (int)((info[j] >> 8) & 63u), 64) + (info[j] & 63u);
-    __syncthreads();
-    uint16_t* wh = reinterpret_cast<uint16_t*>(s_cnt);  // [DL_WAVES][256]
-    uint32_t tile_cnt = 0u;
-    if (tid < 256) {
-#pragma unroll
-        for (int w = 0; w < DL_WAVES; ++w) {
-            const uint32_t c = wh[w * 256 + tid];
-            wh[w * 256 + tid] = (uint16_t)tile_cnt;
-            tile_cnt += c;
-        }
-        if (digit_count) digit_count[tid] = tile_cnt;
-    }
-    const uint32_t ex = block_exclusive_scan_1024(tile_cnt, s_tmp, nullptr);
-    if (tid < 256) s_dig[tid] = ex;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < DL_KPT; ++j) pos[j] += s_dig[d[j]] + (uint32_t)wh[wave * 256 + d[j]];
-    __syncthreads();
-}
-
-template <bool CARRY>
-__global__ __launch_bounds__(DL_THREADS) void k_dsort_local(uint32_t* __restrict__ keys_a, uint32_t* __restrict__ vals_a,
-                                                           uint32_t* __restrict__ aux_a, uint32_t* __restrict__ keys_b,
-                                                           uint32_t* __restrict__ vals_b, uint32_t* __restrict__ aux_b,
-                                                           const uint32_t* __restrict__ d_count, uint32_t n,
-                                                           const uint32_t* __restrict__ key_range,
-                                                           const uint32_t* __restrict__ totals) {
-    // (keys_b, vals_b, aux_b) hold the partitioned pairs; the sorted result goes to (keys_a, vals_a, aux_a)
-    __shared__ uint32_t s_key[2][DL_CAP];
-    __shared__ uint16_t s_perm[2][DL_CAP];
-    __shared__ uint32_t s_cnt[DL_WAVES * 128];
-    __shared__ uint32_t s_dig[256];
-    __shared__ uint32_t s_run[256];
-    __shared__ uint32_t s_tmp[DL_WAVES];
-    __shared__ uint32_t s_b0, s_b1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t count = device_count(d_count, n);
-    if (count == 0u) return;
-    const DSortPlan pl = dsort_plan(key_range, DSORT_TOP_PASS);
-    const uint32_t nb = pl.nb, s = pl.shift;
-    const uint32_t nbuckets = (count + DL_TARGET - 1u) / DL_TARGET;
-    for (uint32_t k = blockIdx.x; k < nbuckets; k += gridDim.x) {
-        if (tid == 0) {
-            s_b0 = 0xFFFFFFFFu;
-            s_b1 = 0u;
-        }
-        __syncthreads();
-        // the digits of bucket k: non-empty digits whose first position lies in [k, k + 1) * DL_TARGET
-        for (uint32_t b = tid; b < nb; b += DL_THREADS) {
-            const uint32_t c0 = totals[b];
-            const uint32_t c1 = b + 1u < nb ? totals[b + 1u] : count;
-            if (c1 > c0 && c0 / DL_TARGET == k) {
-                atomicMin(&s_b0, b);
-                atomicMax(&s_b1, b);
-            }
-        }
-        __syncthreads();
-        const uint32_t b0 = s_b0, b1 = s_b1;
-        __syncthreads();
-        if (b0 == 0xFFFFFFFFu) continue;  // no digit starts here (a long digit of an earlier bucket covers the range)
-        const uint32_t start = totals[b0];
-        const uint32_t end = b1 + 1u < nb ? totals[b1 + 1u] : count;
-        const uint32_t len = end - start;
-        const uint32_t base_nk = b0 << s;  // (b0 << s fits: b0 < 2^w and w + s <= 32; for w + s == 32 the shift keeps the low bits)
-        if (s == 0u) {  // the partition pass sorted everything
-            for (uint32_t i = tid; i < len; i += DL_THREADS) {
-                keys_a[start + i] = keys_b[start + i];
-                vals_a[start + i] = vals_b[start + i];
-                if (CARRY) aux_a[start + i] = aux_b[start + i];
-            }
-            continue;
-        }
-        const uint32_t span = ((b1 - b0 + 1u) << s) - 1u;           // largest local key
-        const uint32_t bits = 32u - (uint32_t)__clz((int)(span | 1u));
-        const uint32_t passes = (bits + 7u) / 8u;
-        if (len <= (uint32_t)DL_CAP) {
-            // ---- LDS sort ----------------------------------------------------------------------------------------
-            const uint32_t wbase = (uint32_t)wave * (64u * DL_KPT) + (uint32_t)lane;  // position order = (wave, j, lane)
-            uint32_t lk[DL_KPT], pm[DL_KPT];
-#pragma unroll
-            for (int j = 0; j < DL_KPT; ++j) {
-                const uint32_t i = wbase + j * 64u;
-                lk[j] = i < len ? keys_b[start + i] - pl.kmin - base_nk : 0xFFFFFFFFu;  // padding sorts last in every pass
-                pm[j] = i;
-            }
-            uint32_t cur = 0u;
-            for (uint32_t p = 0; p < passes; ++p) {
-                uint32_t d[DL_KPT], pos[DL_KPT];
-#pragma unroll
-                for (int j = 0; j < DL_KPT; ++j) d[j] = (lk[j] >> (8u * p)) & 255u;
-                dl_rank(d, pos, s_cnt, s_dig, s_tmp, nullptr);
-#pragma unroll
-                for (int j = 0; j < DL_KPT; ++j) {
-                    s_key[cur][pos[j]] = lk[j];
-                    s_perm[cur][pos[j]] = (uint16_t)pm[j];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < DL_KPT; ++j) {
-                    const uint32_t i = wbase + j * 64u;
-                    lk[j] = s_key[cur][i];
-                    pm[j] = s_perm[cur][i];
-                }
-                cur ^= 1u;
-                __syncthreads();
-            }
-#pragma unroll
-            for (int j = 0; j < DL_KPT; ++j) {
-                const uint32_t i = wbase + j * 64u;
-                if (i < len) {
-                    keys_a[start + i] = lk[j] + base_nk + pl.kmin;
-                    vals_a[start + i] = vals_b[start + pm[j]];
-                    if (CARRY) aux_a[start + i] = aux_b[start + pm[j]];
-                }
-            }
-            continue;
-        }
-        // ---- oversize bucket: the same stable LSD passes, one workgroup, in global memory ---------------------------
-        uint32_t *sk = keys_b, *sv = vals_b, *sa = aux_b, *dk = keys_a, *dv = vals_a, *da = aux_a;
-        for (uint32_t p = 0; p < passes; ++p) {
-            const uint32_t sh = 8u * p;
-            if (tid < 256) s_run[tid] = 0u;
-            __syncthreads();
-            for (uint32_t i = tid; i < len; i += DL_THREADS)
-                atomicAdd(&s_run[((sk[start + i] - pl.kmin - base_nk) >> sh) & 255u], 1u);
-            __syncthreads();
-            const uint32_t ex = block_exclusive_scan_1024(tid < 256 ? s_run[tid] : 0u, s_tmp, nullptr);
-            __syncthreads();
-            if (tid < 256) s_run[tid] = ex;  // first output position of every digit, advanced chunk by chunk
-            __syncthreads();
-            for (uint32_t c0 = 0; c0 < len; c0 += (uint32_t)DL_CAP) {
-                const uint32_t wbase = c0 + (uint32_t)wave * (64u * DL_KPT) + (uint32_t)lane;
-                uint32_t kk[DL_KPT], d[DL_KPT], pos[DL_KPT];
-#pragma unroll
-                for (int j = 0; j < DL_KPT; ++j) {
-                    const uint32_t i = wbase + j * 64u;
-                    kk[j] = i < len ? sk[start + i] : 0u;
-                    d[j] = i < len ? ((kk[j] - pl.kmin - base_nk) >> sh) & 255u : 255u;  // padding ranks last in the chunk
-                }
-                dl_rank(d, pos, s_cnt, s_dig, s_tmp, reinterpret_cast<uint32_t*>(s_key[0]));  // s_key[0][0..255] = chunk digit counts
-#pragma unroll
-                for (int j = 0; j < DL_KPT; ++j) {
-                    const uint32_t i = wbase + j * 64u;
-                    if (i < len) {
-                        const uint32_t o = start + s_run[d[j]] + (pos[j] - s_dig[d[j]]);
-                        dk[o] = kk[j];
-                        dv[o] = sv[start + i];
-                        if (CARRY) da[o] = sa[start + i];
-                    }
-                }
-                __syncthreads();
-                if (tid < 256) {
-                    uint32_t c = s_key[0][tid];
-                    if (tid == 255) {  // padding of the last, partial chunk was counted as digit 255
-                        const uint32_t valid = (len - c0) < (uint32_t)DL_CAP ? (len - c0) : (uint32_t)DL_CAP;
-                        c -= (uint32_t)DL_CAP - valid;
-                    }
-                    s_run[tid] += c;
-                }
-                __syncthreads();
-            }
-            uint32_t* t;
-            t = sk; sk = dk; dk = t;
-            t = sv; sv = dv; dv = t;
-            t = sa; sa = da; da = t;
-            __threadfence();  // (slow path) the next pass re-reads addresses this CU may still hold in its L1
-            __syncthreads();
-        }
-        if (sk != keys_a) {  // an odd number of passes left the result in the partition buffers
-            for (uint32_t i = tid; i < len; i += DL_THREADS) {
-                keys_a[start + i] = keys_b[start + i];
-                vals_a[start + i] = vals_b[start + i];
-                if (CARRY) aux_a[start + i] = aux_b[start + i];
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // key range of arbitrary input (stand-alone sorter in depth mode): the same table K1 fills
 __global__ __launch_bounds__(SORT_THREADS) void k_key_minmax(const uint32_t* __restrict__ keys,
                                                             const uint32_t* __restrict__ d_count, uint32_t n,
@@ -1172,7 +921,7 @@ int run_depth_sort(const DepthSortScratch& sc, uint32_t* keys, uint32_t* vals, u
     for (int p = 0; p < DSORT_PASSES; ++p) {
         hipLaunchKernelGGL(k_dsort_hist<KPT>, dim3(DSORT_MAX_GROUPS), dim3(DH_THREADS), 0, stream, kin, d_count, n, p,
                            sc.key_range, sc.tile_off, sc.group_off + p * gw, sc.status + p * gw,
-                           sc.totals + (size_t)p * DSORT_MAX_BINS, sc.tickets + p, epoch, sc.d_epoch, sc.error);
+                           sc.totals + (size_t)p * DSORT_MAX_BINS, sc.tickets + p, epoch, sc.error);
         km_mark(km, "depth:k_dsort_hist");
         const int iota = (implicit_iota && p == 0) ? 1 : 0;
         if (aux)
@@ -1241,50 +990,6 @@ int launch_gather_u32(const uint32_t* src, const uint32_t* idx, const uint32_t* 
     hipLaunchKernelGGL(k_gather_u32, dim3(blocks), dim3(SORT_THREADS), 0, stream, src, idx, d_count, n, out);
     WS_HIP(hipGetLastError());
     return WS_OK;
-}
-
-// Two-level depth sort: one stable partition pass on the top bits (A -> B), then bucket-local LDS sorts (B -> A):
-// three launches.  The sorted pairs end in the CALLER's arrays (keys, vals, aux).
-template <int KPT>
-static int run_depth_sort_two_level(const DepthSortScratch& sc, uint32_t* keys, uint32_t* vals, uint32_t* aux,
-                                    const uint32_t* d_count, uint32_t n, bool implicit_iota, uint32_t epoch, hipStream_t stream,
-                                    KernelMarks* km) {
-    constexpr uint32_t TILE_N = SORT_THREADS * KPT;
-    const uint32_t tiles = sort_grid((n + TILE_N - 1) / TILE_N);
-    hipLaunchKernelGGL(k_dsort_hist<KPT>, dim3(DSORT_MAX_GROUPS), dim3(DH_THREADS), 0, stream, keys, d_count, n, DSORT_TOP_PASS,
-                       sc.key_range, sc.tile_off, sc.group_off, sc.status, sc.totals, sc.tickets, epoch, sc.d_epoch, sc.error);
-    km_mark(km, "depth:k_dsort_hist");
-    const int iota = implicit_iota ? 1 : 0;
-    uint32_t local_grid = (n + DL_TARGET - 1u) / DL_TARGET;
-    if (local_grid > 2048u) local_grid = 2048u;
-    if (aux) {
-        hipLaunchKernelGGL((k_dsort_scatter<KPT, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, keys, vals, aux, sc.keys_alt,
-                           sc.vals_alt, sc.aux_alt, d_count, n, DSORT_TOP_PASS, iota, sc.key_range, sc.tile_off, sc.group_off,
-                           sc.totals);
-        km_mark(km, "depth:k_dsort_scatter");
-        hipLaunchKernelGGL(k_dsort_local<true>, dim3(local_grid), dim3(DL_THREADS), 0, stream, keys, vals, aux, sc.keys_alt,
-                           sc.vals_alt, sc.aux_alt, d_count, n, sc.key_range, sc.totals);
-    } else {
-        hipLaunchKernelGGL((k_dsort_scatter<KPT, false>), dim3(tiles), dim3(SORT_THREADS), 0, stream, keys, vals,
-                           (const uint32_t*)nullptr, sc.keys_alt, sc.vals_alt, (uint32_t*)nullptr, d_count, n, DSORT_TOP_PASS, iota,
-                           sc.key_range, sc.tile_off, sc.group_off, sc.totals);
-        km_mark(km, "depth:k_dsort_scatter");
-        hipLaunchKernelGGL(k_dsort_local<false>, dim3(local_grid), dim3(DL_THREADS), 0, stream, keys, vals, (uint32_t*)nullptr,
-                           sc.keys_alt, sc.vals_alt, (uint32_t*)nullptr, d_count, n, sc.key_range, sc.totals);
-    }
-    km_mark(km, "depth:k_dsort_local");
-    WS_HIP(hipGetLastError());
-    return WS_OK;
-}
-
-int launch_depth_sort_two_level(const DepthSortScratch& sc, uint32_t* keys, uint32_t* vals, uint32_t* aux, const uint32_t* d_count,
-                                uint32_t n, bool implicit_iota, uint32_t epoch, hipStream_t stream, KernelMarks* km) {
-    if (n == 0) return WS_OK;
-    if (n > sc.cap) return fail(WS_ERR_INVALID, "depth sort: n exceeds the scratch capacity");
-    if (aux && !sc.aux_alt) return fail(WS_ERR_INVALID, "depth sort: companion values without a companion scratch buffer");
-    if (sort_tile_size(n) == SORT_TILE)
-        return run_depth_sort_two_level<SORT_KPT>(sc, keys, vals, aux, d_count, n, implicit_iota, epoch, stream, km);
-    return run_depth_sort_two_level<SORT_KPT_SMALL>(sc, keys, vals, aux, d_count, n, implicit_iota, epoch, stream, km);
 }
 
 int launch_key_minmax(const uint32_t* keys, const uint32_t* d_count, uint32_t n, uint32_t* key_range, hipStream_t stream) {

@@ -27,10 +27,6 @@ int hip_fail(hipError_t e, const char* what) {
     return e == hipErrorOutOfMemory ? WS_ERR_OOM : WS_ERR_HIP;
 }
 
-#ifndef WS_DEPTH_SORT_DEFAULT
-#define WS_DEPTH_SORT_DEFAULT 0
-#endif
-
 static int env_int(const char* name, int dflt) {
     const char* v = std::getenv(name);
     return (v && *v) ? std::atoi(v) : dflt;
@@ -318,7 +314,6 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
         ds.key_range = r->zero->key_range;
         ds.tickets = r->counters->sort_ticket;  // [0..2]; the tile sort uses [4..7]
         ds.error = &r->counters->overflow;
-        ds.d_epoch = &r->counters->epoch;
     }
     r->cap_points = n;
     r->vw = vw;
@@ -352,14 +347,8 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->device = hip_device;
     WS_HIP(hipGetDeviceProperties(&ctx->props, hip_device));
     ctx->sort_algo = env_int("WS_SORT_ALGO", 0);
-    ctx->depth_sort_mode = WS_DEPTH_SORT_DEFAULT;
-    if (const char* ds = std::getenv("WS_DEPTH_SORT")) {
-        if (std::strcmp(ds, "classic") == 0) ctx->depth_sort_mode = 0;
-        else if (std::strcmp(ds, "adaptive") == 0) ctx->depth_sort_mode = 1;
-        else if (std::strcmp(ds, "twolevel") == 0) ctx->depth_sort_mode = 2;
-        else { delete ctx; return fail(WS_ERR_INVALID, "WS_DEPTH_SORT must be classic, adaptive or twolevel"); }
-    }
-    if (ctx->sort_algo == 1) ctx->depth_sort_mode = 0;  // the one-sweep cross-check path is a generic-sorter path
+    if (const char* ds = std::getenv("WS_DEPTH_SORT")) ctx->depth_sort_adaptive = std::strcmp(ds, "adaptive") == 0;
+    if (ctx->sort_algo == 1) ctx->depth_sort_adaptive = false;  // the one-sweep cross-check path is a generic-sorter path
     ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
     ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
@@ -750,14 +739,7 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     // depth sort: V (key, store index) pairs, values start as iota (preprocess.wgsl:274), the packed tile rectangle
     // rides along as a companion value.  Default: the generic 4 x 8-bit sorter (GPURSSorter's shape);
     // WS_DEPTH_SORT=adaptive: three range-adaptive digit passes (launch_depth_sort; measured: no faster).
-    if (r->ctx->depth_sort_mode == 2) {
-        if ((rc = launch_depth_sort_two_level(r->dsort, r->keys_a, r->vals_a, r->rects_a, &r->counters->num_visible,
-                                              pc->num_points, true, r->epoch, stream, km)))
-            return rc;
-        r->sorted_idx = r->vals_a;    // partition A -> B, bucket sorts B -> A
-        r->sorted_keys = r->keys_a;
-        r->rects_sorted = r->rects_a;
-    } else if (r->ctx->depth_sort_mode == 0) {
+    if (!r->ctx->depth_sort_adaptive) {
         const bool carry = r->ctx->sort_algo != 1;  // (the one-sweep cross-check path gathers the rectangles afterwards)
         uint32_t *sk = nullptr, *sv = nullptr;
         if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
@@ -924,7 +906,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     // A captured frame graph (one hipGraphLaunch + one kernel-argument update instead of 22 launches + a memset on the host)
     // when the caller gave a real stream and no per-launch instrumentation is on.  The legacy NULL stream cannot be captured.
     const bool use_graph = r->ctx->use_graph && stream != nullptr && !r->marks.active && !r->timers && !r->capture &&
-                           cut_mode == 0 && r->ctx->sort_algo == 0;
+                           cut_mode == 0 && r->ctx->sort_algo == 0 && !r->ctx->depth_sort_adaptive;
     if (!use_graph) return enqueue_frame(r, pc, kp, kb, stream);
     ws_renderer::FrameGraph& g = r->fg;
     if (!(g.valid && g.pc == pc && g.generation == r->scratch_generation)) {
@@ -1277,8 +1259,6 @@ int ws_sorter_sort_depth(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, ui
     if (n == 0) return WS_OK;
     int rc = launch_key_minmax(d_keys, d_count, n, s->zero->key_range, stream);
     if (rc) return rc;
-    if (s->ctx->depth_sort_mode == 2)  // two-level form: the result lands in the caller's arrays
-        return launch_depth_sort_two_level(s->ds, d_keys, d_payload, d_aux, d_count, n, false, s->epoch, stream, nullptr);
     rc = launch_depth_sort(s->ds, d_keys, d_payload, d_aux, d_count, n, false, s->epoch, stream, nullptr);
     if (rc) return rc;
     // three passes leave the result in the scratch buffers: bring the sorted prefix home (elements past the

@@ -177,8 +177,6 @@ constexpr int DSORT_PASSES = 3;
 constexpr int DSORT_MAX_BITS = 11;
 constexpr int DSORT_MAX_BINS = 1 << DSORT_MAX_BITS;
 constexpr int DSORT_MAX_GROUPS = 128;
-constexpr int DSORT_TOP_PASS = 100;   // pass id of the two-level sort's partition pass: the TOP bits of key - kmin
-constexpr int DSORT_TOP_BITS = 10;
 struct DepthSortScratch {
     uint32_t* keys_alt = nullptr;   // [cap] ping-pong partners
     uint32_t* vals_alt = nullptr;
@@ -190,7 +188,6 @@ struct DepthSortScratch {
     uint32_t* tickets = nullptr;    // [passes] group dispensers, zero on entry
     const uint32_t* key_range = nullptr;    // [KEY_RANGE_SLOTS][KEY_RANGE_STRIDE]: {max(key), max(~key)} per slot (FrameZero)
     uint32_t* error = nullptr;      // OR-ed with 8 if a look-back spin times out
-    const uint32_t* d_epoch = nullptr;  // non-null: the look-back epoch is read from device memory (FrameCounters::epoch)
     uint32_t cap = 0, tiles_cap = 0;
 };
 size_t depth_sort_tile_off_words(uint32_t cap);     // allocation sizes for capacity `cap`
@@ -205,11 +202,6 @@ int launch_gather_u32(const uint32_t* src, const uint32_t* idx, const uint32_t* 
                       hipStream_t stream);
 int launch_copy_counted(const uint32_t* s0, uint32_t* d0, const uint32_t* s1, uint32_t* d1, const uint32_t* s2, uint32_t* d2,
                         const uint32_t* d_count, uint32_t n, hipStream_t stream);
-// Two-level form: one stable partition pass on the top DSORT_TOP_BITS bits of key - kmin (into the scratch partners),
-// then every bucket of ~2048 pairs is sorted on the remaining bits entirely in LDS (k_dsort_local) back into the
-// caller's arrays: three launches, 44 instead of 112 bytes moved per pair.
-int launch_depth_sort_two_level(const DepthSortScratch& sc, uint32_t* keys, uint32_t* vals, uint32_t* aux, const uint32_t* d_count,
-                                uint32_t n, bool implicit_iota, uint32_t epoch, hipStream_t stream, KernelMarks* km = nullptr);
 int launch_key_minmax(const uint32_t* keys, const uint32_t* d_count, uint32_t n, uint32_t* key_range, hipStream_t stream);
 
 // ---- preprocess ---------------------------------------------------------------------------------
@@ -297,8 +289,7 @@ struct ws_context {
     int device = 0;
     hipDeviceProp_t props;
     int sort_algo = 0;    // 0 = tile histograms -> column scan -> scatter (default), 1 = one-sweep (look-back)
-    int depth_sort_mode = 0;  // WS_DEPTH_SORT: 0 classic (4 x 8 bit), 1 adaptive (three range-adaptive passes), 2 twolevel
-                              // (one partition pass on the top bits + bucket-local LDS sorts)
+    bool depth_sort_adaptive = false;  // WS_DEPTH_SORT=adaptive: three range-adaptive digit passes (sort.hip; cross-check)
     int blend_variant = 0;
     int debug_cut = 0;        // WS_DEBUG_CUT (analysis): 0 = whole frame
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
