@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/wgsl_*.npz: outputs of the reference's OWN shader source, executed by oracle/wgsl_exec.py.
+
+Run in the build container (the reference checkout is not on the GPU box and nothing at test time reads it):
+
+    python tests/golden/gen_wgsl_golden.py            # all cases
+    python tests/golden/gen_wgsl_golden.py k1_default # one case
+
+The shader text is read from $WEBSPLAT_REFERENCE/src/shaders (default /root/reference) at generation time and is NOT
+stored: the fixtures hold only the seeded input buffers (the bytes a wgpu binding would see) and the output buffers the
+shader wrote.  Bindings and the MAX_SH_DEG prefix follow renderer.rs:379-392 (build_shader) and :394-420 (bind groups).
+
+  wgsl_k1_<case>.npz    preprocess.wgsl `preprocess`            -> points_2d, sort_depths, keys_size, dispatch_x (+ the
+                        invocation that drew each store index)
+  wgsl_k1c_<case>.npz   preprocess_compressed.wgsl `preprocess` -> the same
+  wgsl_k6_fragments.npz gaussian.wgsl `vs_main` (4 vertices per instance) and `fs_main` at pixel centres; the
+                        screen_pos a fragment receives is the rasteriser's linear interpolation of the four vertices'
+                        values, restated here in float64 and rounded to f32 (the one step no shader text covers).
+
+Inputs come from the repository's synthetic scene generators and the oracle's host math (uniform structs as bytes);
+the interpreter decodes them with WGSL's own layout rules, so a layout disagreement shows up as a value mismatch.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "web-splat_amd")]
+import wgsl_exec as W  # noqa: E402
+
+REF = os.environ.get("WEBSPLAT_REFERENCE", "/root/reference")
+
+
+def shader(name, max_sh_deg=None):
+    src = open(os.path.join(REF, "src", "shaders", name)).read()
+    if max_sh_deg is not None:  # renderer.rs:379-392
+        src = "\n        const MAX_SH_DEG:u32 = %du;\n        %s" % (max_sh_deg, src)
+    return src
+
+
+def struct_bytes(s):
+    import ctypes
+    return bytes(ctypes.string_at(ctypes.byref(s), ctypes.sizeof(s)))
+
+
+def run_preprocess(src, bindings, n):
+    """Binds the buffers, dispatches ceil(n / 256) workgroups (renderer.rs:411-413), returns the written buffers."""
+    m = W.Module(src)
+    out = {}
+    for name, data in bindings.items():
+        out[name] = m.bind(name, data)
+    splat_size = m.struct_size("Splat")
+    out["points_2d"] = m.bind("points_2d", bytearray(splat_size * n))
+    out["sort_depths"] = m.bind("sort_depths", bytearray(4 * n))
+    out["sort_indices"] = m.bind("sort_indices", bytearray(4 * n))
+    out["sort_infos"] = m.bind("sort_infos", bytearray(m.struct_size("SortInfos")))
+    out["sort_dispatch"] = m.bind("sort_dispatch", bytearray(m.struct_size("DispatchIndirect")))
+    src_index = []
+
+    def watch(gid):  # which invocation drew which store index (keys_size is SortInfos' first word)
+        if int.from_bytes(out["sort_infos"][0:4], "little") > len(src_index):
+            src_index.append(gid)
+    m.dispatch("preprocess", (n + 255) // 256, watch)
+    v = int(np.frombuffer(out["sort_infos"], dtype=np.uint32)[0])
+    assert v == len(src_index)
+    idx = np.frombuffer(out["sort_indices"], dtype=np.uint32)[:v]
+    assert np.array_equal(idx, np.arange(v, dtype=np.uint32))
+    return dict(num_visible=np.uint32(v), src_index=np.array(src_index, dtype=np.uint32),
+                splats=np.frombuffer(out["points_2d"], dtype=np.uint8)[:v * splat_size].reshape(v, splat_size).copy(),
+                keys=np.frombuffer(out["sort_depths"], dtype=np.uint32)[:v].copy(),
+                dispatch_x=np.frombuffer(out["sort_dispatch"], dtype=np.uint32)[0])
+
+
+# ---- K1 -------------------------------------------------------------------------------------------------------------
+def k1_case(name):
+    import oracle_lib as oracle
+    import websplat as ws
+    import wgsl_cases
+    sc = wgsl_cases.k1_scene(ws, oracle, name)
+    n, sh_deg = sc.gpc.num_points, sc.sh_deg
+    # the uniforms as the ORACLE's host math builds them (camera.rs / renderer.rs restated in ws_oracle.c)
+    cam = sc.args.camera
+    ocam = oracle.make_camera(cam.position, cam.rotation, cam.fovx, cam.fovy, cam.znear, cam.zfar, cam.fov2view_ratio)
+    cu = oracle.camera_uniform(ocam, *sc.viewport)
+    a = sc.args
+    rs = oracle.settings_uniform(oracle.make_aabb(sc.gpc.aabb.min, sc.gpc.aabb.max), sc.gpc.center,
+                                 gaussian_scaling=a.gaussian_scaling, max_sh_deg=a.max_sh_deg,
+                                 mip_splatting=a.mip_splatting, kernel_size=a.kernel_size,
+                                 clipping_box=a.clipping_box, walltime=a.walltime, scene_extend=a.scene_extend,
+                                 pc_mip=sc.gpc.mip_splatting, pc_kernel_size=sc.gpc.kernel_size)
+    g = np.ascontiguousarray(sc.gpc.gaussians).view(np.uint8).reshape(n, -1)
+    sh = np.ascontiguousarray(sc.gpc.sh_coefs).view(np.uint8).reshape(n, -1)
+    cu_b, rs_b = struct_bytes(cu), struct_bytes(rs)
+    res = run_preprocess(shader("preprocess.wgsl", sh_deg),
+                         dict(camera=cu_b, render_settings=rs_b, gaussians=g.tobytes(), sh_coefs=sh.tobytes()), n)
+    res.update(gaussians=g, sh_coefs=sh, camera_uniform=np.frombuffer(cu_b, dtype=np.uint8),
+               settings_uniform=np.frombuffer(rs_b, dtype=np.uint8), sh_deg=np.uint32(sh_deg),
+               viewport=np.array(sc.viewport, dtype=np.uint32))
+    return res
+
+
+# ---- K1c ------------------------------------------------------------------------------------------------------------
+def k1c_case(name):
+    import oracle_lib as oracle
+    import websplat as ws
+    import wgsl_cases
+    gpc, cam, viewport, sh_deg = wgsl_cases.k1c_inputs(ws, name)
+    n = gpc.num_points
+    ocam = oracle.make_camera(cam.position, cam.rotation, cam.fovx, cam.fovy, cam.znear, cam.zfar, cam.fov2view_ratio)
+    cu = oracle.camera_uniform(ocam, *viewport)
+    rs = oracle.settings_uniform(oracle.make_aabb(gpc.aabb.min, gpc.aabb.max), gpc.center, max_sh_deg=sh_deg,
+                                 pc_mip=gpc.mip_splatting, pc_kernel_size=gpc.kernel_size)
+    q = gpc.quantization
+    oq = oracle.make_quantization({k: (getattr(q, k).zero_point, getattr(q, k).scale)
+                                   for k in ("color_dc", "color_rest", "opacity", "scaling_factor")})
+    g = np.ascontiguousarray(gpc.gaussians).view(np.uint8).reshape(n, -1)
+    shb = np.ascontiguousarray(gpc.sh_coefs).view(np.uint8).reshape(-1)
+    cov = np.ascontiguousarray(gpc.covars).view(np.uint8).reshape(-1)
+    pad = (-len(shb)) % 4 + 4  # the shader reads whole u32 words, one past the last coefficient's word
+    cu_b, rs_b, q_b = struct_bytes(cu), struct_bytes(rs), struct_bytes(oq)
+    res = run_preprocess(shader("preprocess_compressed.wgsl", sh_deg),
+                         dict(camera=cu_b, render_settings=rs_b, vertices=g.tobytes(),
+                              sh_coefs=shb.tobytes() + bytes(pad), geometries=cov.tobytes(), quantization=q_b), n)
+    res.update(gaussians=g, sh_coefs=shb, covars=cov, camera_uniform=np.frombuffer(cu_b, dtype=np.uint8),
+               settings_uniform=np.frombuffer(rs_b, dtype=np.uint8), quantization=np.frombuffer(q_b, dtype=np.uint8),
+               sh_deg=np.uint32(sh_deg), viewport=np.array(viewport, dtype=np.uint32))
+    return res
+
+
+# ---- K6: vertex + fragment functions ----------------------------------------------------------------------------------
+def k6_fragments():
+    """For S splats of the k1_default fixture and the pixel centres of a window around each: vs_main's four vertices,
+    the interpolated screen_pos at the pixel, fs_main's premultiplied output (or discard)."""
+    k1 = np.load(os.path.join(HERE, "wgsl_k1_default.npz"))
+    w, h = (int(x) for x in k1["viewport"])
+    splats = k1["splats"]
+    rng = np.random.default_rng(5)
+    pick = np.sort(rng.choice(len(splats), size=48, replace=False))
+    m = W.Module(shader("gaussian.wgsl"))
+    m.bind("points_2d", splats.tobytes())
+    m.bind("indices", np.arange(len(splats), dtype=np.uint32).tobytes())
+    rec_splat, rec_px, rec_pos, rec_out, rec_keep, verts = [], [], [], [], [], []
+    for s in pick:
+        vo = [m.invoke("vs_main", [W.u32(k), W.u32(int(s))]) for k in range(4)]
+        P = np.array([[float(c) for c in v.f["position"].c[:2]] for v in vo], dtype=np.float64)   # NDC of the 4 vertices
+        Q = np.array([[float(c) for c in v.f["screen_pos"].c] for v in vo], dtype=np.float64)     # their screen_pos
+        verts.append(np.concatenate([P, Q], axis=1))
+        # affine map NDC -> screen_pos through vertices 0 (+,+), 1 (-,+), 2 (+,-): a triangle strip of two triangles
+        # that share it (the quad is a parallelogram), i.e. what the rasteriser's interpolation evaluates
+        A = np.stack([P[1] - P[0], P[2] - P[0]], axis=1)
+        if abs(np.linalg.det(A)) < 1e-30:
+            continue
+        Ainv = np.linalg.inv(A)
+        dQ = np.stack([Q[1] - Q[0], Q[2] - Q[0]], axis=1)
+        # pixel window: the quad's bounding box in pixels, thinned to at most ~60 pixels, plus everything within one
+        # pixel of the cut-off circle is kept by the thinning (the interesting ones)
+        px = (P[:, 0] * 0.5 + 0.5) * w
+        py = (0.5 - P[:, 1] * 0.5) * h
+        x0, x1 = int(np.floor(px.min())) - 1, int(np.ceil(px.max())) + 1
+        y0, y1 = int(np.floor(py.min())) - 1, int(np.ceil(py.max())) + 1
+        xs = np.arange(max(x0, 0), min(x1, w - 1) + 1)
+        ys = np.arange(max(y0, 0), min(y1, h - 1) + 1)
+        if len(xs) == 0 or len(ys) == 0:
+            continue
+        stride = max(1, int(np.sqrt(len(xs) * len(ys) / 60.0)))
+        color = vo[0].f["color"]
+        for y in ys[::stride]:
+            for x in xs[::stride]:
+                ndc = np.array([(x + 0.5) / w * 2.0 - 1.0, 1.0 - (y + 0.5) / h * 2.0])
+                st = Ainv @ (ndc - P[0])
+                sp = Q[0] + dQ @ st
+                spv = W.Vec([W.F32(sp[0]), W.F32(sp[1])])
+                frag = W.StructVal("VertexOutput", dict(position=W.Vec([W.F32(x + 0.5), W.F32(y + 0.5), W.F32(0), W.F32(1)]),
+                                                        screen_pos=spv, color=color))
+                try:
+                    o = m.invoke("fs_main", [frag])
+                    rec_out.append([float(c) for c in o.c])
+                    rec_keep.append(1)
+                except W.Discard:
+                    rec_out.append([0.0] * 4)
+                    rec_keep.append(0)
+                rec_splat.append(int(s))
+                rec_px.append((x, y))
+                rec_pos.append((float(spv.c[0]), float(spv.c[1])))
+    return dict(viewport=np.array([w, h], dtype=np.uint32), splats=splats, picked=pick.astype(np.uint32),
+                vertices=np.array(verts, dtype=np.float32), frag_splat=np.array(rec_splat, dtype=np.uint32),
+                frag_pixel=np.array(rec_px, dtype=np.uint32), frag_screen_pos=np.array(rec_pos, dtype=np.float32),
+                frag_out=np.array(rec_out, dtype=np.float32), frag_keep=np.array(rec_keep, dtype=np.uint8))
+
+
+import wgsl_cases  # noqa: E402
+
+CASES = {}
+for c in wgsl_cases.K1_CASES:
+    CASES["k1_" + c] = (lambda c=c: k1_case(c))
+for c in wgsl_cases.K1C_CASES:
+    CASES["k1c_" + c] = (lambda c=c: k1c_case(c))
+CASES["k6_fragments"] = k6_fragments
+
+
+def main():
+    want = sys.argv[1:] or list(CASES)
+    for name in want:
+        t0 = time.time()
+        res = CASES[name]()
+        path = os.path.join(HERE, "wgsl_%s.npz" % name)
+        np.savez_compressed(path, **res)
+        extra = "V = %d" % int(res["num_visible"]) if "num_visible" in res else "%d fragments" % len(res["frag_keep"])
+        print("%-16s %s  %.1f s  %d bytes" % (name, extra, time.time() - t0, os.path.getsize(path)))
+
+
+if __name__ == "__main__":
+    main()
