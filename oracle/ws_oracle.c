@@ -1,8 +1,11 @@
 /*
  * ws_oracle.c -- CPU restatement of web-splat's render hot path.
  *
- * TEST INFRASTRUCTURE ONLY (see ws_oracle.h).  PARITY STATUS: parity unpinned
- * except for the sort contract (gpu_rs.rs:295-331 known-answer vector).
+ * TEST INFRASTRUCTURE ONLY (see ws_oracle.h).  PARITY STATUS (details in ws_oracle.h):
+ * the sort is pinned by the reference's known-answer vector (gpu_rs.rs:295-331); K1, K1c
+ * and the K6 fragment function are pinned by golden vectors produced by executing the
+ * reference's WGSL source text (tests/golden/wgsl_*.npz); parity unpinned for the Rust
+ * host math, the rasteriser interpolation / blend state and the loaders.
  *
  * Every function cites the reference file:line (relative to /root/reference) it
  * restates.  Arithmetic is f32 in the WGSL/Rust expression order; build with

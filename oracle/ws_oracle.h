@@ -4,14 +4,21 @@
  * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *
- * PARITY STATUS: **parity unpinned** for K1 / K1c / K6.  The reference
- * (KeKsBoTer/web-splat) ships no golden vectors, fixtures or tests for those
- * stages and cannot be built here (Rust + WGSL through wgpu/naga; no cargo, no
- * Vulkan ICD).  The only known-answer check the reference holds is
- * GPURSSorter::test_sort (src/gpu_rs.rs:295-331: 8192 reversed f32 keys), which
- * pins the sort contract; the oracle is checked against it in
- * tests/test_oracle.py.  Everything else is a line-by-line restatement of the
- * WGSL/Rust sources cited at each function.
+ * PARITY STATUS.  The reference (KeKsBoTer/web-splat) ships no golden vectors,
+ * fixtures or tests for K1 / K1c / K6 and cannot be built here (Rust + WGSL
+ * through wgpu/naga; no cargo, no Vulkan ICD), so there is no oracle/_ref.
+ *   PINNED to the reference's own source:
+ *   - the sort contract, by GPURSSorter::test_sort (src/gpu_rs.rs:295-331: 8192
+ *     reversed f32 keys), tests/test_oracle.py;
+ *   - wso_preprocess (K1), wso_preprocess_compressed (K1c) and the fragment
+ *     function inside wso_render (K6), by tests/golden/wgsl_*.npz: the outputs of
+ *     preprocess.wgsl / preprocess_compressed.wgsl / gaussian.wgsl executed FROM
+ *     THEIR SOURCE TEXT by the WGSL-subset interpreter oracle/wgsl_exec.py in the
+ *     build container (generator: tests/golden/gen_wgsl_golden.py).  K1 agrees
+ *     bit for bit on all ten cases (tests/test_wgsl_golden.py).
+ *   parity unpinned (line-by-line restatement only): the Rust host math
+ *   (camera.rs, cgmath, renderer.rs uniforms), the rasteriser's interpolation and
+ *   the blend state of the draw (renderer.rs:65), the loaders (ws_oracle_io.py).
  */
 #ifndef WS_ORACLE_H
 #define WS_ORACLE_H
