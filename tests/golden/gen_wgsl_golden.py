@@ -13,6 +13,7 @@ shader wrote.  Bindings and the MAX_SH_DEG prefix follow renderer.rs:379-392 (bu
   wgsl_k1_<case>.npz    preprocess.wgsl `preprocess`            -> points_2d, sort_depths, keys_size, dispatch_x (+ the
                         invocation that drew each store index)
   wgsl_k1c_<case>.npz   preprocess_compressed.wgsl `preprocess` -> the same
+  wgsl_frame.npz        K1 + stable sort + the instanced draw with the pipeline's blend state: a whole 320x240 frame
   wgsl_k6_fragments.npz gaussian.wgsl `vs_main` (4 vertices per instance) and `fs_main` at pixel centres; the
                         screen_pos a fragment receives is the rasteriser's linear interpolation of the four vertices'
                         values, restated here in float64 and rounded to f32 (the one step no shader text covers).
@@ -191,6 +192,57 @@ def k6_fragments():
                 frag_out=np.array(rec_out, dtype=np.float32), frag_keep=np.array(rec_keep, dtype=np.uint8))
 
 
+# ---- a whole frame: K1 -> stable sort by key -> instanced draw with premultiplied "over" ----------------------------------
+def frame():
+    """preprocess.wgsl, then the draw of renderer.rs:240-283: instances in ascending key order (stable: equal keys keep
+    their store order, gpu_rs.rs), vs_main / fs_main from source for every pixel centre inside an instance's quad, and
+    the pipeline's blend state PREMULTIPLIED_ALPHA_BLENDING (renderer.rs:65: dst = src + dst * (1 - src.a), f32 here)
+    on a transparent target.  The kept disc (radius sqrt(2 CUTOFF) in screen_pos units) lies strictly inside the quad
+    (half-width CUTOFF), so the rasteriser's edge rules never decide a pixel."""
+    res = k1_case("frame")
+    w, h = (int(x) for x in res["viewport"])
+    splats, keys = res["splats"], res["keys"]
+    order = np.argsort(keys, kind="stable").astype(np.uint32)
+    m = W.Module(shader("gaussian.wgsl"))
+    m.bind("points_2d", splats.tobytes())
+    m.bind("indices", order.tobytes())
+    img = np.zeros((h, w, 4), dtype=np.float32)
+    one = np.float32(1.0)
+    nfrag = 0
+    for inst in range(len(order)):
+        vo = [m.invoke("vs_main", [W.u32(k), W.u32(inst)]) for k in range(4)]
+        P = np.array([[float(c) for c in v.f["position"].c[:2]] for v in vo], dtype=np.float64)
+        Q = np.array([[float(c) for c in v.f["screen_pos"].c] for v in vo], dtype=np.float64)
+        A = np.stack([P[1] - P[0], P[2] - P[0]], axis=1)
+        if abs(np.linalg.det(A)) < 1e-30:
+            continue
+        Ainv = np.linalg.inv(A)
+        dQ = np.stack([Q[1] - Q[0], Q[2] - Q[0]], axis=1)
+        px = (P[:, 0] * 0.5 + 0.5) * w
+        py = (0.5 - P[:, 1] * 0.5) * h
+        xs = range(max(int(np.floor(px.min())), 0), min(int(np.ceil(px.max())), w - 1) + 1)
+        ys = range(max(int(np.floor(py.min())), 0), min(int(np.ceil(py.max())), h - 1) + 1)
+        color = vo[0].f["color"]
+        for y in ys:
+            for x in xs:
+                ndc = np.array([(x + 0.5) / w * 2.0 - 1.0, 1.0 - (y + 0.5) / h * 2.0])
+                st = Ainv @ (ndc - P[0])
+                if st[0] < 0 or st[0] > 1 or st[1] < 0 or st[1] > 1:
+                    continue  # outside the quad
+                sp = Q[0] + dQ @ st
+                frag = W.StructVal("VertexOutput", dict(position=W.Vec([W.F32(x + 0.5), W.F32(y + 0.5), W.F32(0), W.F32(1)]),
+                                                        screen_pos=W.Vec([W.F32(sp[0]), W.F32(sp[1])]), color=color))
+                try:
+                    o = m.invoke("fs_main", [frag])
+                except W.Discard:
+                    continue
+                src = np.array([c for c in o.c], dtype=np.float32)
+                img[y, x] = src + img[y, x] * (one - src[3])
+                nfrag += 1
+    res.update(order=order, image=img, fragments=np.uint32(nfrag))
+    return res
+
+
 import wgsl_cases  # noqa: E402
 
 CASES = {}
@@ -199,6 +251,7 @@ for c in wgsl_cases.K1_CASES:
 for c in wgsl_cases.K1C_CASES:
     CASES["k1c_" + c] = (lambda c=c: k1c_case(c))
 CASES["k6_fragments"] = k6_fragments
+CASES["frame"] = frame
 
 
 def main():
@@ -208,7 +261,9 @@ def main():
         res = CASES[name]()
         path = os.path.join(HERE, "wgsl_%s.npz" % name)
         np.savez_compressed(path, **res)
-        extra = "V = %d" % int(res["num_visible"]) if "num_visible" in res else "%d fragments" % len(res["frag_keep"])
+        extra = ("V = %d" % int(res["num_visible"]) if "num_visible" in res else "") + \
+                (" %d fragments" % (int(res["fragments"]) if "fragments" in res else len(res["frag_keep"]))
+                 if ("fragments" in res or "frag_keep" in res) else "")
         print("%-16s %s  %.1f s  %d bytes" % (name, extra, time.time() - t0, os.path.getsize(path)))
 
 

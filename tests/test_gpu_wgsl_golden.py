@@ -127,3 +127,27 @@ def test_fragments_equal_the_reference_shader(ws, ctx, oracle):
     finally:
         r.close()
     assert checked > 800, checked
+
+
+def test_frame_equals_the_reference_shaders(ws, ctx, oracle):
+    """The whole HIP frame (K1 -> depth sort -> binning -> tile sort -> blend) against the frame the reference's shaders
+    draw when executed from source (tests/golden/wgsl_frame.npz): the stated image tolerance, boundary pixels proven."""
+    z = load("frame")
+    sc = wgsl_cases.k1_scene(ws, oracle, "frame")
+    w, h = sc.viewport
+    pc = ws.PointCloud(ctx, sc.gpc)
+    r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    try:
+        assert _bytes(sc.args.camera.uniform(sc.viewport)) == z["camera_uniform"].tobytes()
+        assert _bytes(pc.settings_uniform(sc.args)) == z["settings_uniform"].tobytes()
+        r.prepare(pc, sc.args)
+        r.render(pc)
+        img = r.download_target()
+        assert r.frame_stats()["num_visible"] == int(z["num_visible"])
+        proof = lambda: scenes.BoundaryProof(z["splats"], z["order"], w, h)  # noqa: E731
+        ok, msg, mx, mean, nb = scenes.image_close(img, z["image"], proof=proof)
+        assert ok, msg
+        assert mean < 2e-5, mean
+    finally:
+        r.close()
+        pc.close()

@@ -15,6 +15,8 @@ K1C_CASES = ("deg3", "deg2", "deg0")
 
 def k1_scene(ws, oracle, name):
     n, viewport, seed, sh_deg, kw = 700, (640, 480), 50, 3, {}
+    if name == "frame":  # the whole-frame fixture: the default scene on a quarter of the pixels
+        return scenes.c1(ws, oracle, n=n, viewport=(320, 240), seed=seed, sh_deg=3, max_sh_deg=3)
     if name.startswith("sh"):
         sh_deg = int(name[2])
         seed = 60 + sh_deg
