@@ -110,6 +110,17 @@ def build_workload(ws, name, n_views):
     elif name != "bonsai":
         raise SystemExit(f"unknown workload {name} (one of {', '.join(WORKLOADS)})")
     if rows is not None:
+        if os.environ.get("WS_BENCH_SCENE_ORDER") == "morton":
+            # A/B only (never the default, never the reported configuration): the synthetic scenes are generated in
+            # random order; this stores them along a 3-D Morton curve instead, as a trained scene roughly is
+            p = rows[:, :3].astype(np.float64)
+            q = ((p - p.min(0)) / np.maximum(p.max(0) - p.min(0), 1e-12) * 1023.0).astype(np.uint64)
+            code = np.zeros(len(rows), dtype=np.uint64)
+            for bit in range(10):
+                for axis in range(3):
+                    code |= ((q[:, axis] >> np.uint64(bit)) & np.uint64(1)) << np.uint64(3 * bit + axis)
+            rows = rows[np.argsort(code, kind="stable")]
+            note = (note + "; " if note else "") + "scene stored in Morton order (A/B)"
         gpc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
     args = []
     for cj in cams:
