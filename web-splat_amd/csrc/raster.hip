@@ -297,25 +297,34 @@ __device__ __forceinline__ void store_pixel(const BlendParams& p, uint32_t px, u
 }
 
 // raw words of one staged entry: the 20-B Splat record (pointcloud.rs:352-358)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 struct RawSplat {
-    uint32_t w0, w1, w2, w3, w4;
+    u32x4_t a;    // words 0..3: kept as ONE 128-bit value from the load to the decode (see blend_fetch_raw)
+    uint32_t w4;
 };
-// Unconditional gather of this thread's entry of the batch that ends at `hi` (slot 0 = nearest).  The address
-// is clamped into the tile's range, so the loads never depend on a branch and can be issued a whole batch ahead.
+// This thread's entry of the batch that ends at `hi` (slot 0 = nearest): its Splat index.  The address is clamped into
+// the tile's (non-empty) range, so the load never depends on a branch and can be issued batches ahead.
 template <int STAGE>
-__device__ __forceinline__ RawSplat blend_fetch_raw(const BlendParams& p, uint2 range, uint32_t hi, int tid) {
+__device__ __forceinline__ uint32_t blend_entry_idx(const BlendParams& p, uint2 range, uint32_t hi, int tid) {
     const uint32_t h = hi > range.x ? hi : range.x + 1u;
     const uint32_t nb = (h - range.x) < (uint32_t)STAGE ? (h - range.x) : (uint32_t)STAGE;
     const uint32_t off = (uint32_t)tid < nb ? (uint32_t)tid : nb - 1u;
-    const uint32_t idx = p.entry_vals[h - 1u - off];
-    const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx * 20);
+    return p.entry_vals[h - 1u - off];
+}
+// The 20-B Splat record.  One dwordx4 + one dword, and the four words stay a single 128-bit value until the decode: as
+// five scalars the compiler parked three of them in other registers right behind the load (s_waitcnt vmcnt + v_mov: the
+// gather of the next batch never overlapped the walk of the current one); five separate dword loads fix that too but cost
+// 2.5x the address lookups of a random gather (measured: blend +35 % on hd1m, +29 % on c3).
+__device__ __forceinline__ RawSplat blend_gather(const BlendParams& p, uint32_t idx) {
+    const char* sp = reinterpret_cast<const char*>(p.splats) + (size_t)idx * 20;
     RawSplat r;
-    r.w0 = sp[0];
-    r.w1 = sp[1];
-    r.w2 = sp[2];
-    r.w3 = sp[3];
-    r.w4 = sp[4];
+    __builtin_memcpy(&r.a, sp, 16);
+    __builtin_memcpy(&r.w4, sp + 16, 4);
     return r;
+}
+template <int STAGE>
+__device__ __forceinline__ RawSplat blend_fetch_raw(const BlendParams& p, uint2 range, uint32_t hi, int tid) {
+    return blend_gather(p, blend_entry_idx<STAGE>(p, range, hi, tid));
 }
 
 // LDS layout of a staged batch: two planes of 16-B records with the SAME slot stride, so one byte offset
@@ -379,7 +388,10 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     __shared__ float4 s_rec[2 * SLOTS];
     __shared__ uint32_t s_m[STAGE];  // quadrant bits of the staged record (0 = slot unused)
     // per wave: byte offsets of the staged records that reach its quadrant, near -> far, padded with the null record
-    __shared__ __attribute__((aligned(16))) uint32_t s_list[NW][STAGE + 16];
+    // (a wave compacts and walks a staged batch in sub-rounds of at most LCAP records, so the lists stay small when the
+    // batch is large: -DWS_BLEND_STAGE_MAX=1024 halves the per-batch barriers and still leaves LDS for two workgroups)
+    constexpr int LCAP = STAGE < 512 ? STAGE : 512;
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[NW][LCAP + 16];
     __shared__ uint2 s_range[16];   // [begin, end) of this workgroup's tiles in the sorted entry list
     __shared__ uint32_t s_txy[16];  // tx | ty << 16, or 0xFFFFFFFF for a slot outside the image
     __shared__ uint32_t s_dbg_max;  // capture mode: most records any wave walked in the current batch
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     if (!blk.valid) return;  // block-uniform
     const uint32_t tpw = 1u << tpw_log2, wpb = shape.tpb() >> tpw_log2;
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (wave-uniform: lives in an SGPR)
     const int qx = wave % QW, qy = wave / QW;
     const float lx = (float)(qx * 8 + (lane & 7)) + 0.5f;  // tile-local pixel centre
     const float ly = (float)(qy * 8 + (lane >> 3)) + 0.5f;
@@ -424,7 +436,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     const float W = (float)p.width, H = (float)p.height;
     uint32_t* my_list = s_list[wave];
 
-    RawSplat raw = {0u, 0u, 0u, 0u, 0u};
+    RawSplat raw = {{0u, 0u, 0u, 0u}, 0u};
     if (stager) {
         const uint2 r0 = s_range[0];
         if (r0.y > r0.x) raw = blend_fetch_raw<STAGE>(p, r0, r0.y, tid);  // (an empty tile must not touch the entry list)
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     const uint2 range = s_range[k];
     // the first batch of the NEXT tile (entry index -> Splat record: two dependent round trips) flies while this
     // tile is composited
-    RawSplat raw_next_tile = {0u, 0u, 0u, 0u, 0u};
+    RawSplat raw_next_tile = {{0u, 0u, 0u, 0u}, 0u};
     if (MULTI && stager && k + 1u < tpw) {
         const uint2 rn = s_range[k + 1u];
         if (rn.y > rn.x) raw_next_tile = blend_fetch_raw<STAGE>(p, rn, rn.y, tid);
@@ -452,6 +464,11 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     const float tile_x0 = (float)(tx * TW), tile_y0 = (float)(ty * TH);
 
     uint32_t hi = range.y;
+    // Two-deep pipeline of the staging loads: while batch b is composited, the Splat records of batch b+1 (their indices
+    // arrived during batch b-1) and the entry indices of batch b+2 are in flight.
+    uint32_t idx_next = 0u;
+    if (stager && range.y > range.x)
+        idx_next = blend_entry_idx<STAGE>(p, range, range.y - range.x > (uint32_t)STAGE ? range.y - (uint32_t)STAGE : range.x, tid);
     // capture build only (p.debug_walked): records this wave walked, and the sum over batches of the most any wave
     // walked in the batch (the lock-step cost of the per-batch barriers)
     uint32_t dbg_walked = 0u, dbg_lockstep = 0u;
@@ -465,27 +482,34 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         if (stager) {
             uint32_t mask = 0u;
             if ((uint32_t)tid < nb) {
-                const stage::Staged s = stage::decode<QW, QH>(raw.w0, raw.w1, raw.w2, raw.w3, raw.w4, W, H, tile_x0,
+                const stage::Staged s = stage::decode<QW, QH>(raw.a.x, raw.a.y, raw.a.z, raw.a.w, raw.w4, W, H, tile_x0,
                                                               tile_y0, CUT_A2);
                 mask = s.mask;
                 s_rec[tid] = make_float4(s.i00, s.i01, s.c0, s.i10);
-                s_rec[SLOTS + tid] = make_float4(s.i11, s.c1, __uint_as_float(raw.w3), __uint_as_float(raw.w4));
+                s_rec[SLOTS + tid] = make_float4(s.i11, s.c1, __uint_as_float(raw.a.w), __uint_as_float(raw.w4));
             }
             s_m[tid] = mask;
-            // the next batch's gathers fly while this batch is composited; wasted only when the tile saturates first
-            if (hi_next > range.x) raw = blend_fetch_raw<STAGE>(p, range, hi_next, tid);
+            // the next batch's gathers fly while this batch is composited; wasted only when the tile saturates first.
+            // UNCONDITIONAL (the address is clamped into the tile's range): under `if (hi_next > range.x)` the compiler
+            // merged the loaded words with the old ones at the join -- s_waitcnt vmcnt directly behind the loads and three
+            // v_mov, i.e. the "prefetch" waited for its own data before the barrier, one exposed round trip per batch
+            raw = blend_gather(p, idx_next);
+            idx_next = blend_entry_idx<STAGE>(p, range, hi_next - range.x > (uint32_t)STAGE ? hi_next - (uint32_t)STAGE : range.x, tid);
         }
         __syncthreads();
         const uint32_t dbg_before = dbg_walked;
-        if (__ballot(T >= T_MIN) != 0ull) {  // a wave whose 64 pixels are saturated only keeps staging
+        // a wave whose 64 pixels are saturated only keeps staging
+        for (uint32_t sub = 0; sub < nb && __ballot(T >= T_MIN) != 0ull; sub += (uint32_t)LCAP) {
             // wave-private compaction: records whose kept ellipse reaches this quadrant, in near -> far order
+            const uint32_t nsub = (nb - sub) < (uint32_t)LCAP ? (nb - sub) : (uint32_t)LCAP;
             uint32_t n = 0;
-            const uint32_t rounds = (nb + 63u) >> 6;
+            const uint32_t rounds = (nsub + 63u) >> 6;
             for (uint32_t r = 0; r < rounds; ++r) {
-                const bool t = (s_m[r * 64 + lane] & qbit) != 0u;
+                const uint32_t slot = sub + r * 64 + lane;
+                const bool t = slot < nb && (s_m[slot] & qbit) != 0u;
                 const unsigned long long bal = __ballot(t);
                 const uint32_t pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                if (t) my_list[pos] = (uint32_t)(r * 64 + lane) * 16u;
+                if (t) my_list[pos] = slot * 16u;
                 n += (uint32_t)__popcll(bal);
             }
             if (n > 0u) {
@@ -532,10 +556,14 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         if (wave == 0) p.debug_walked[(size_t)tile * 17u + 16u] = dbg_lockstep;
     }
 
-    if (inside) {
-        // begin_render_pass(clear = background) then "over": dst = src + dst * (1 - src.a), all four channels
-        store_pixel<FORMAT>(p, px, py, cr + p.background[0] * T, cg + p.background[1] * T, cb + p.background[2] * T,
-                            (1.0f - T) + p.background[3] * T);
+    {
+        // (the pixel coordinates are rebuilt from lx / ly instead of staying live across the walk: two registers)
+        const uint32_t sx = tx * TW + (uint32_t)lx, sy = ty * TH + (uint32_t)ly;
+        if (sx < p.width && sy < p.height) {
+            // begin_render_pass(clear = background) then "over": dst = src + dst * (1 - src.a), all four channels
+            store_pixel<FORMAT>(p, sx, sy, cr + p.background[0] * T, cg + p.background[1] * T, cb + p.background[2] * T,
+                                (1.0f - T) + p.background[3] * T);
+        }
     }
     }  // tile inside the image
     if (!MULTI) break;
