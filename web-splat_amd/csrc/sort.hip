@@ -121,11 +121,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __re
 }
 
 // ---- algo 0: digit counts of every tile, transposed: tile_sums[digit * tiles_cap + tile] ---------------
-template <int KPT>
+template <int KPT, bool KEY16>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ d_count, uint32_t n,
                                                                 int shift, uint32_t mask, uint32_t* __restrict__ tile_sums,
-                                                                uint32_t tiles_cap, int key16) {
+                                                                uint32_t tiles_cap) {
     constexpr int TILE_N = SORT_THREADS * KPT;
     __shared__ uint32_t sh[RADIX * HIST_COPIES];
     const uint32_t count = device_count(d_count, n);
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t*
         for (int j = 0; j < KPT; ++j) {
             const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
             const uint32_t q = pos < count ? pos : count - 1u;
-            k[j] = key16 ? (uint32_t)reinterpret_cast<const uint16_t*>(keys)[q] : keys[q];
+            k[j] = KEY16 ? (uint32_t)reinterpret_cast<const uint16_t*>(keys)[q] : keys[q];
         }
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
@@ -196,7 +196,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* 
 // passes, e.g. 6 + 6 for 3750 tiles: fewer ballots per key, shorter scans, longer write runs).
 // CARRY: a 4-byte companion value (aux_in -> aux_out) travels with the payload: the depth sort carries the splat's packed
 // tile rectangle, so that the binning prefix reads it in draw order instead of gathering it (raster.hip).
-template <bool LOOKBACK, int KPT, bool RANGES, int BITS, bool CARRY = false>
+// KEY16: the key arrays hold uint16_t (tile ids below 65535): 2 B less per entry.  A template parameter, not an argument:
+// with both load forms behind a run-time flag the compiler shared registers between them and put a full s_waitcnt vmcnt
+// between the second and third key load of every thread -- two exposed round trips per tile instead of one.
+template <bool LOOKBACK, int KPT, bool RANGES, int BITS, bool CARRY = false, bool KEY16 = false>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out,
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     uint32_t* __restrict__ ticket,         // tile dispenser, zero on entry                  (LOOKBACK)
     const uint32_t* __restrict__ tile_off, // [256][tiles_cap] exclusive offsets per digit   (!LOOKBACK)
     uint32_t tiles_cap, uint32_t epoch, uint32_t* __restrict__ error_word, uint2* __restrict__ ranges,
-    uint32_t nranges, int key16) {  // key16: the key arrays hold uint16_t (tile ids below 65535): 2 B less per entry
+    uint32_t nranges) {
     constexpr int TILE_N = SORT_THREADS * KPT;
     constexpr uint32_t DMASK = (1u << BITS) - 1u;
     static_assert(!LOOKBACK || BITS == RADIX_BITS, "the one-sweep path uses 8-bit digits");
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const uint32_t pos = wave_base + j * 64;
-        key[j] = pos < count ? (key16 ? (uint32_t)reinterpret_cast<const uint16_t*>(keys_in)[pos] : keys_in[pos])
+        key[j] = pos < count ? (KEY16 ? (uint32_t)reinterpret_cast<const uint16_t*>(keys_in)[pos] : keys_in[pos])
                              : 0xFFFFFFFFu;
     }
 #pragma unroll
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             vals_out[gpos] = vv;
             if (CARRY) aux_out[gpos] = s_aux[lp];
             if (!RANGES) {
-                if (key16) reinterpret_cast<uint16_t*>(keys_out)[gpos] = (uint16_t)kk;
+                if (KEY16) reinterpret_cast<uint16_t*>(keys_out)[gpos] = (uint16_t)kk;
                 else keys_out[gpos] = kk;
             } else if (kk < nranges) {
                 const uint32_t prev_k = lp > 0u ? s_keys[lp - 1u] : ~kk;
@@ -407,40 +410,40 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     }
 }
 
-template <int KPT, int BITS>
+template <int KPT, int BITS, bool KEY16>
 int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t* ain,
                     uint32_t* aout,
                     const uint32_t* d_count, uint32_t n, int begin_bit, int npass, bool implicit_iota,
                     bool first_tile_hist_ready, uint32_t epoch, hipStream_t stream, uint32_t** fk, uint32_t** fv,
-                    KernelMarks* km, const char* const* names, uint2* ranges, uint32_t nranges, bool key16) {
+                    KernelMarks* km, const char* const* names, uint2* ranges, uint32_t nranges) {
     constexpr uint32_t TILE_N = SORT_THREADS * KPT;
     const uint32_t tiles = sort_grid((n + TILE_N - 1) / TILE_N);
     for (int p = 0; p < npass; ++p) {
         const int shift = begin_bit + p * BITS;
         const int iota = (implicit_iota && p == 0) ? 1 : 0;
         if (!(p == 0 && first_tile_hist_ready)) {
-            hipLaunchKernelGGL(k_sort_tile_hist<KPT>, dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift,
-                               (1u << BITS) - 1u, sc.tile_sums, sc.tiles_cap, key16 ? 1 : 0);
+            hipLaunchKernelGGL((k_sort_tile_hist<KPT, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift,
+                               (1u << BITS) - 1u, sc.tile_sums, sc.tiles_cap);
             km_mark(km, names[0]);
         }
         hipLaunchKernelGGL(k_sort_col_scan, dim3(1u << BITS), dim3(SORT_THREADS), 0, stream, d_count, n, TILE_N,
                            sc.tile_sums, sc.tiles_cap, sc.hist + p * RADIX);
         km_mark(km, names[1]);
         if (ranges && p == npass - 1)
-            hipLaunchKernelGGL((k_sort_scatter<false, KPT, true, BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
+            hipLaunchKernelGGL((k_sort_scatter<false, KPT, true, BITS, false, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota,
                                sc.hist + p * RADIX, (uint64_t*)nullptr, (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch,
-                               (uint32_t*)nullptr, ranges, nranges, key16 ? 1 : 0);
+                               (uint32_t*)nullptr, ranges, nranges);
         else if (ain)
             hipLaunchKernelGGL((k_sort_scatter<false, KPT, false, BITS, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
                                vin, kout, vout, ain, aout, d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr,
                                (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr, (uint2*)nullptr,
-                               0u, key16 ? 1 : 0);
+                               0u);
         else
-            hipLaunchKernelGGL((k_sort_scatter<false, KPT, false, BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
+            hipLaunchKernelGGL((k_sort_scatter<false, KPT, false, BITS, false, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota,
                                sc.hist + p * RADIX, (uint64_t*)nullptr, (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch,
-                               (uint32_t*)nullptr, (uint2*)nullptr, 0u, key16 ? 1 : 0);
+                               (uint32_t*)nullptr, (uint2*)nullptr, 0u);
         km_mark(km, names[2]);
         WS_HIP(hipGetLastError());
         uint32_t* tk = kin;
@@ -1022,6 +1025,7 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
     if (algo == 1 && aux) return fail(WS_ERR_INVALID, "sort: companion values are a feature of the scan path");
     if (aux && (ranges || !aux_alt)) return fail(WS_ERR_INVALID, "sort: companion values need a scratch partner and no range recording");
     if (key16 && end_bit > 16) return fail(WS_ERR_INVALID, "sort: 16-bit keys with more than 16 key bits");
+    if (key16 && aux) return fail(WS_ERR_INVALID, "sort: companion values travel with 32-bit keys only");
     if (digit_bits < 6 || digit_bits > RADIX_BITS) return fail(WS_ERR_INVALID, "sort: digit width must be 6, 7 or 8 bits");
     if (begin_bit < 0 || end_bit > 32 || begin_bit >= end_bit)
         return fail(WS_ERR_INVALID, "sort: bit range must be non-empty and within [0,32]");
@@ -1038,9 +1042,12 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
         int rc;
         const bool big = sort_tile_size(n) == SORT_TILE;
 #define WS_RUN_SCAN(KPT_, BITS_)                                                                                       \
-    rc = run_passes_scan<KPT_, BITS_>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass, implicit_iota, \
-                                      first_tile_hist_ready, epoch, stream, &kin, &vin, km, names, ranges, nranges, \
-                                      key16)
+    rc = key16 ? run_passes_scan<KPT_, BITS_, true>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass,   \
+                                                    implicit_iota, first_tile_hist_ready, epoch, stream, &kin, &vin, km,   \
+                                                    names, ranges, nranges)                                                \
+               : run_passes_scan<KPT_, BITS_, false>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass,  \
+                                                     implicit_iota, first_tile_hist_ready, epoch, stream, &kin, &vin, km,  \
+                                                     names, ranges, nranges)
         if (digit_bits == 8) {
             if (big) WS_RUN_SCAN(SORT_KPT, 8); else WS_RUN_SCAN(SORT_KPT_SMALL, 8);
         } else if (digit_bits == 7) {
@@ -1066,12 +1073,12 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                 hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, true, RADIX_BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
                                    vin, kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota, sc.hist + p * RADIX,
                                    sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
-                                   0u, epoch, sc.error, ranges, nranges, 0);
+                                   0u, epoch, sc.error, ranges, nranges);
             else
                 hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, false, RADIX_BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
                                    vin, kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota, sc.hist + p * RADIX,
                                    sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
-                                   0u, epoch, sc.error, (uint2*)nullptr, 0u, 0);
+                                   0u, epoch, sc.error, (uint2*)nullptr, 0u);
             km_mark(km, names[2]);
             WS_HIP(hipGetLastError());
             uint32_t* tk = kin;
