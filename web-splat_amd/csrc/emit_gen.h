@@ -94,6 +94,19 @@ __device__ __forceinline__ Slice slice_setup(const Source& src, uint32_t slice, 
     return sl;
 }
 
+// Tile id of the k-th tile (row-major inside the rectangle) of the packed rectangle r.
+__device__ __forceinline__ uint32_t tile_of(uint32_t r, uint32_t k, uint32_t tiles_x) {
+    const uint32_t x0 = r & 0xFFu, y0 = (r >> 8) & 0xFFu;  // x0 | y0 << 8 | (w - 1) << 16 | (h - 1) << 24
+    const uint32_t w = ((r >> 16) & 0xFFu) + 1u;
+    // k / w without the integer-division sequence: k < 2^16 (a rectangle has at most 256 x 256 tiles), far inside the
+    // range where the float path with one correction step is exact
+    uint32_t q = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
+    uint32_t rem = k - q * w;
+    if ((int32_t)rem < 0) { q -= 1u; rem += w; }
+    if (rem >= w) { q += 1u; rem -= w; }
+    return (y0 + q) * tiles_x + (x0 + rem);
+}
+
 // Entry el (0 <= el < sl.ne) of the slice: tile id and splat (store index).
 __device__ __forceinline__ void entry(const Source& src, const Slice& sl, const uint32_t* s_off, const uint32_t* s_own,
                                       uint32_t el, uint32_t* key, uint32_t* val) {
@@ -112,18 +125,7 @@ __device__ __forceinline__ void entry(const Source& src, const Slice& sl, const 
         }
     }
     const uint32_t pos = sl.s_lo + lo;
-    const uint32_t r = src.rects_sorted[pos];  // x0 | y0 << 8 | (w - 1) << 16 | (h - 1) << 24
-    const uint32_t x0 = r & 0xFFu, y0 = (r >> 8) & 0xFFu;
-    const uint32_t w = ((r >> 16) & 0xFFu) + 1u;
-    const uint32_t k = e - (sl.in_lds ? s_off[lo] : sl.goff[lo]);
-    // k / w without the integer-division sequence: k < 2^24 always (a rectangle has at most 2^16 x 2^16 tiles
-    // but the entry capacity is below 2^30 and rows are at most 65535 wide; one correction step covers rounding)
-    uint32_t q = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
-    uint32_t rem = k - q * w;
-    if ((int32_t)rem < 0) { q -= 1u; rem += w; }
-    if (rem >= w) { q += 1u; rem -= w; }
-    if (k >= (1u << 23)) { q = k / w; rem = k % w; }  // exactness of the float path ends at 2^23
-    *key = (y0 + q) * src.tiles_x + (x0 + rem);
+    *key = tile_of(src.rects_sorted[pos], e - (sl.in_lds ? s_off[lo] : sl.goff[lo]), src.tiles_x);
     *val = src.sorted_idx[pos];
 }
 

@@ -188,14 +188,44 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
     for (uint32_t slice = blockIdx.x; (uint64_t)slice * EMIT_TILE < d; slice += gridDim.x) {
         for (int k = tid; k < RADIX * EMIT_COPIES; k += BIN_THREADS) s_hist[k] = 0u;
         const emit::Slice sl = emit::slice_setup(src, slice, d, v, s_off, s_own, s_wmax);
-        for (uint32_t el = tid; el < sl.ne; el += BIN_THREADS) {
-            uint32_t key, val;
-            emit::entry(src, sl, s_off, s_own, el, &key, &val);
-            const uint32_t e = sl.e0 + el;
-            if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
-            else entry_keys[e] = key;
-            entry_vals[e] = val;
-            atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
+        if (sl.in_lds) {  // (block-uniform) the usual case
+            // All EPT entries of a thread at once: owners from LDS, then their rectangle and index gathers in flight
+            // together.  (Entry by entry, each one waited for its two dependent loads before the next one's were issued:
+            // 16 serial round trips per thread -- the whole duration of this kernel.)
+            uint32_t lo[emit::EPT], rect[emit::EPT], val[emit::EPT];
+#pragma unroll
+            for (int j = 0; j < emit::EPT; ++j) {
+                const uint32_t el = (uint32_t)tid + (uint32_t)j * BIN_THREADS;
+                lo[j] = el < sl.ne ? s_own[emit::pad(el)] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < emit::EPT; ++j) {
+                const uint32_t pos = sl.s_lo + lo[j];
+                rect[j] = src.rects_sorted[pos];
+                val[j] = src.sorted_idx[pos];
+            }
+#pragma unroll
+            for (int j = 0; j < emit::EPT; ++j) {
+                const uint32_t el = (uint32_t)tid + (uint32_t)j * BIN_THREADS;
+                if (el < sl.ne) {
+                    const uint32_t e = sl.e0 + el;
+                    const uint32_t key = emit::tile_of(rect[j], e - s_off[lo[j]], src.tiles_x);
+                    if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
+                    else entry_keys[e] = key;
+                    entry_vals[e] = val[j];
+                    atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
+                }
+            }
+        } else {
+            for (uint32_t el = tid; el < sl.ne; el += BIN_THREADS) {
+                uint32_t key, val;
+                emit::entry(src, sl, s_off, s_own, el, &key, &val);
+                const uint32_t e = sl.e0 + el;
+                if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
+                else entry_keys[e] = key;
+                entry_vals[e] = val;
+                atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
+            }
         }
         if (tile_hist) {  // digit counts of sort tile `slice` for the tile-id sort's first pass ([digit][tile])
             __syncthreads();
