@@ -415,12 +415,17 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     constexpr int STAGE = NT < WS_BLEND_STAGE_MAX ? NT : WS_BLEND_STAGE_MAX;   // entries staged per batch
     constexpr int SLOTS = STAGE + 1;
     constexpr int TW = 8 * QW, TH = 8 * QH;
-    __shared__ float4 s_rec[2 * SLOTS];
-    __shared__ uint32_t s_m[STAGE];  // quadrant bits of the staged record (0 = slot unused)
-    // per wave: byte offsets of the staged records that reach its quadrant, near -> far, padded with the null record
     // (a wave compacts and walks a staged batch in sub-rounds of at most LCAP records, so the lists stay small when the
     // batch is large: -DWS_BLEND_STAGE_MAX=1024 halves the per-batch barriers and still leaves LDS for two workgroups)
     constexpr int LCAP = STAGE < 512 ? STAGE : 512;
+
+    __shared__ float4 s_rec[2 * SLOTS];
+    // quadrant bits of the staged records (0 = slot unused), 16 bits each, TRANSPOSED per sub-round of LCAP slots: the
+    // masks of slots lane, lane + 64, lane + 128, ... sit side by side, so a wave's compaction reads all of them with one
+    // or two wide LDS loads instead of one dependent load per 64 records
+    __shared__ __attribute__((aligned(16))) uint16_t s_m[STAGE];
+    static_assert(LCAP % 256 == 0, "sub-round layout of the quadrant masks: four 16-bit masks per 64-bit piece");
+    // per wave: byte offsets of the staged records that reach its quadrant, near -> far, padded with the null record
     __shared__ __attribute__((aligned(16))) uint32_t s_list[NW][LCAP + 16];
     __shared__ uint2 s_range[16];   // [begin, end) of this workgroup's tiles in the sorted entry list
     __shared__ uint32_t s_txy[16];  // tx | ty << 16, or 0xFFFFFFFF for a slot outside the image
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
                 s_rec[tid] = make_float4(s.i00, s.i01, s.c0, s.i10);
                 s_rec[SLOTS + tid] = make_float4(s.i11, s.c1, __uint_as_float(raw.a.w), __uint_as_float(raw.w4));
             }
-            s_m[tid] = mask;
+            s_m[((uint32_t)tid / LCAP) * LCAP + ((uint32_t)tid & 63u) * (LCAP / 64) + (((uint32_t)tid % LCAP) >> 6)] = (uint16_t)mask;
             // the next batch's gathers fly while this batch is composited; wasted only when the tile saturates first.
             // UNCONDITIONAL (the address is clamped into the tile's range): under `if (hi_next > range.x)` the compiler
             // merged the loaded words with the old ones at the join -- s_waitcnt vmcnt directly behind the loads and three
@@ -531,16 +536,25 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         // a wave whose 64 pixels are saturated only keeps staging
         for (uint32_t sub = 0; sub < nb && __ballot(T >= T_MIN) != 0ull; sub += (uint32_t)LCAP) {
             // wave-private compaction: records whose kept ellipse reaches this quadrant, in near -> far order
-            const uint32_t nsub = (nb - sub) < (uint32_t)LCAP ? (nb - sub) : (uint32_t)LCAP;
+            // (the masks of the sub-round's slots lane, lane + 64, ... in 64-bit pieces -- slots past nb hold 0)
+            const uint2* mp = reinterpret_cast<const uint2*>(s_m + sub + (uint32_t)lane * (LCAP / 64));
             uint32_t n = 0;
-            const uint32_t rounds = (nsub + 63u) >> 6;
-            for (uint32_t r = 0; r < rounds; ++r) {
-                const uint32_t slot = sub + r * 64 + lane;
-                const bool t = slot < nb && (s_m[slot] & qbit) != 0u;
-                const unsigned long long bal = __ballot(t);
-                const uint32_t pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                if (t) my_list[pos] = slot * 16u;
-                n += (uint32_t)__popcll(bal);
+            uint32_t slot16 = (sub + (uint32_t)lane) * 16u;  // byte offset of the record of round 0
+            asm volatile("" : "+v"(slot16));  // (recomputed here: hoisted out of the tile loop, the eight offsets of the
+                                              // unrolled rounds would hold eight registers for the whole kernel)
+#pragma unroll
+            for (int h = 0; h < LCAP / 256; ++h) {
+                const uint2 mm = mp[h];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = h * 4 + q;
+                    const uint32_t word = (q & 2) ? mm.y : mm.x;
+                    const bool t = (word & (qbit << ((q & 1) * 16))) != 0u;
+                    const unsigned long long bal = __ballot(t);
+                    const uint32_t pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    if (t) my_list[pos] = slot16 + (uint32_t)r * 1024u;
+                    n += (uint32_t)__popcll(bal);
+                }
             }
             if (n > 0u) {
                 if (lane < 4 && ((n + (uint32_t)lane) >> 2) == (n >> 2) && (n & 3u)) my_list[n + lane] = (uint32_t)STAGE * 16u;  // pad to x4
