@@ -266,7 +266,8 @@ def test_ply_file_roundtrip(ws, ctx, oracle, tmp_path):
                                  {"WS_TILE_SHAPE": "4x4", "WS_BLEND_VARIANT": "1", "WS_SORT_ALGO": "1"},
                                  {"WS_TILE_SHAPE": "4x4", "WS_BLEND_TPW_LOG2": "1"},
                                  {"WS_TILE_SHAPE": "4x2", "WS_BLEND_TPW_LOG2": "2"},
-                                 {"WS_DEPTH_SORT": "adaptive"}, {"WS_DEPTH_SORT": "adaptive", "WS_TILE_SHAPE": "2x2"}])
+                                 {"WS_DEPTH_SORT": "adaptive"}, {"WS_DEPTH_SORT": "adaptive", "WS_TILE_SHAPE": "2x2"},
+                                 {"WS_BLEND_SPLIT": "1"}])
 def test_cross_check_paths(ws, oracle, env, monkeypatch):
     """The alternative implementations kept as cross-checks (one-sweep look-back sort, range-adaptive three-pass depth
     sort, wave-per-quadrant blend) and

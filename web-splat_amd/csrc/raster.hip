@@ -457,7 +457,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         uint32_t code = 0xFFFFFFFFu;
         if (tx < p.tiles_x && ty < p.tiles_y) {
             code = tx | (ty << 16);
-            range = p.tile_ranges[ty * p.tiles_x + tx];
+            range = p.tile_ranges[(ty >> p.range_row_shift) * p.tiles_x + tx];
             range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
         }
         s_range[tid] = range;

@@ -354,6 +354,7 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
     if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
     ctx->use_graph = env_int("WS_GRAPH", 1);
+    ctx->blend_split = env_int("WS_BLEND_SPLIT", 0);
     ctx->blend_lds_pad_kb = env_int("WS_BLEND_LDS_PAD_KB", 0);
     if (ctx->blend_lds_pad_kb < 0 || ctx->blend_lds_pad_kb > 96) ctx->blend_lds_pad_kb = 0;
     if (const char* shape = std::getenv("WS_TILE_SHAPE")) {  // tuning / A-B: quadrants per tile
@@ -1000,6 +1001,12 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.format = (int)r->format;
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
     bp.lds_pad_kb = r->ctx->blend_lds_pad_kb;
+    bp.range_row_shift = 0;
+    if (r->ctx->blend_split && bp.qw == 4 && bp.qh == 4 && !r->capture) {  // A/B: two 512-thread workgroups per binning tile
+        bp.qh = 2;
+        bp.tiles_y = (r->vh + 15u) / 16u;
+        bp.range_row_shift = 1;
+    }
     bp.counters = r->counters;
     bp.sticky = r->sticky;
     bp.debug_consumed = r->capture ? r->debug_consumed : nullptr;

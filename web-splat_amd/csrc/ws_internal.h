@@ -259,6 +259,8 @@ struct BlendParams {
     int format;
     int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
     int lds_pad_kb;             // tuning: extra (unused) dynamic LDS per workgroup, limits workgroups per CU
+    uint32_t range_row_shift;   // 0, or 1 = "split" mode: tiles_y counts HALF binning tiles (32x16 px, 8 waves) and the list of
+                                //   blend tile (tx, ty) is the binning tile's (tx, ty >> 1): two workgroups share one list
     const FrameCounters* counters;  // this frame's counters: the error bits are folded into *sticky by the blend
     uint32_t* sticky;           // per-renderer error word that is NOT zeroed per frame (ws_renderer_errors)
     uint32_t* debug_consumed;   // nullptr, or [tiles]: entries of each tile's list the blend walked (capture mode)
@@ -294,6 +296,7 @@ struct ws_context {
     int debug_cut = 0;        // WS_DEBUG_CUT (analysis): 0 = whole frame
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
+    int blend_split = 0;      // WS_BLEND_SPLIT=1 (A/B): 4x4 binning tiles composited by two 4x2 workgroups each
     int use_graph = 1;        // WS_GRAPH=0: enqueue every frame launch by launch instead of replaying the captured frame graph
     uint32_t tile_qw = 4, tile_qh = 4;  // WS_TILE_SHAPE = 2x2 | 4x2 | 4x4 (default: 32x32-px binning tiles)
 };
