@@ -1,0 +1,44 @@
+"""One configuration of scripts/sweep.py with progress output: python scripts/sweep_one.py N W H [streams...]"""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "web-splat_amd"), os.path.join(ROOT, "tests"), ROOT]
+import numpy as np, torch
+import websplat as ws
+from websplat import synth
+n, w, h = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+streams = [int(x) for x in sys.argv[4:]] or [4, 1]
+ctx = ws.Context(0)
+gpc = ws.GenericGaussianPointCloud.from_ply_rows(synth.scene_c2(n=n, seed=1), 3)
+pc = ws.PointCloud(ctx, gpc)
+f = 1200.0 * w / 1200.0
+views = []
+for cj in synth.orbit_cameras(16, w, h, f, f):
+    cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, w, h)
+    cam.fit_near_far(gpc.aabb)
+    views.append(ws.SplattingArgs(camera=cam, viewport=(w, h), max_sh_deg=3))
+for ns in streams:
+    rs = [ws.GaussianRenderer(ctx, "rgba32float", 3, False) for _ in range(ns)]
+    tg = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(ns)]
+    keep = [torch.cuda.Stream() for _ in range(ns)]
+    st = [torch.cuda.current_stream().cuda_stream] + [s_.cuda_stream for s_ in keep[1:]]
+    if os.environ.get("NONNULL"):
+        st = [s_.cuda_stream for s_ in keep]
+    print("streams", ns, "stream handles", st, flush=True)
+    for i in range(64):
+        k = i % ns
+        rs[k].prepare(pc, views[i % 16], stream=st[k]); rs[k].render(pc, target_ptr=tg[k].data_ptr(), stream=st[k])
+        mix = os.environ.get("MIX")
+        if mix:
+            torch.cuda.synchronize()
+            if mix == "torchcpu": torch.zeros(4, device="cuda").cpu()
+            if mix == "ctxdl":
+                if i == 0: dbuf = ctx.malloc(64)
+                ctx.download(dbuf, (4,), np.float32)
+            if mix == "target": rs[k].download_target() if False else ctx.download(tg[k].data_ptr(), (4,), np.float32)
+            print("frame", i, "mix ok", flush=True)
+        if os.environ.get("SYNC_EACH"):
+            torch.cuda.synchronize(); print("frame", i, "ok", rs[k].frame_stats() if os.environ.get("SYNC_EACH") == "1" else "", flush=True)
+    torch.cuda.synchronize()
+    print("streams", ns, "done", rs[0].frame_stats(), rs[0].errors(), flush=True)
+    for r in rs: r.close()

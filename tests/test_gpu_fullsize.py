@@ -368,3 +368,57 @@ def test_frame_graph_replay_equals_launch_by_launch(ws, oracle, monkeypatch):
     for a, b in zip(results["1"], results["0"]):
         assert np.array_equal(a, b)
     assert not np.array_equal(results["1"][0], results["1"][1])
+
+
+def test_read_backs_and_null_stream_work_between_frames(ws, oracle):
+    """Frames on real streams with everything a caller may do in between -- frame_stats(), errors(), download_frame(),
+    a NULL-stream hipMemcpy (Context.download), a second renderer enqueueing on the legacy stream -- for three times the
+    depth of any internal ring: every image equals the one a fresh renderer draws for that view.  (scripts/sweep.py found
+    that exactly this pattern crashed the captured-frame-graph path on ROCm 7.2, which is why that path is opt-in; the
+    library's own read-backs keep off the NULL stream.)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    c = ws.Context(0)
+    streams = [C.c_void_p() for _ in range(2)]
+    for s in streams:
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0
+    try:
+        vp = (800, 600)
+        sc = scenes.c2(ws, oracle, n=250_000, viewport=vp)
+        pc = ws.PointCloud(c, sc.gpc)
+        views = []
+        for cj in synth.orbit_cameras(14, vp[0], vp[1], float(vp[0]), float(vp[0])):
+            cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, *vp)
+            cam.fit_near_far(sc.gpc.aabb)
+            views.append(ws.SplattingArgs(camera=cam, viewport=vp, max_sh_deg=3))
+        ref = ws.GaussianRenderer(c, "rgba32float", 3, False)
+        want = []
+        for v in views:
+            ref.prepare(pc, v)
+            ref.render(pc)
+            want.append(ref.download_target())
+        rs = [ws.GaussianRenderer(c, "rgba32float", 3, False) for _ in range(3)]   # two on streams, one on the NULL stream
+        bufs = [c.malloc(vp[0] * vp[1] * 16) for _ in rs]
+        small = c.malloc(64)
+        for i, v in enumerate(views):
+            k = i % 3
+            st = streams[k].value if k < 2 else None
+            rs[k].prepare(pc, v, stream=st)
+            rs[k].render(pc, target_ptr=bufs[k], pitch=vp[0] * 16, stream=st)
+            stats = rs[k].frame_stats()
+            assert stats["overflow"] == 0 and stats["num_visible"] > 100_000
+            assert rs[k].errors()[0] == 0
+            c.download(small, (4,), np.float32)                      # NULL-stream copy
+            if i % 4 == 1:
+                rs[k].enable_capture(False)
+            got = c.download(bufs[k], (vp[1], vp[0], 4), np.float32)
+            assert np.array_equal(got, want[i]), i
+        for r in rs + [ref]:
+            r.close()
+        for b in bufs + [small]:
+            c.free(b)
+        pc.close()
+    finally:
+        for s in streams:
+            hip.hipStreamDestroy(s)
+        c.close()

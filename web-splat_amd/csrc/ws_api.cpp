@@ -39,6 +39,17 @@ static int dmalloc(T** p, size_t count) {
     WS_HIP(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
     return WS_OK;
 }
+// Device -> host read-back ORDERED ON THE RENDERER'S OWN STREAM (then waited for): the library never touches the legacy
+// NULL stream for a frame's data.  (Besides the device-wide implicit synchronisation a NULL-stream copy brings, a
+// hipMemcpy on the NULL stream between two launches of a captured frame graph made the next launch of an already
+// used executable graph fault on ROCm 7.2 -- found by scripts/sweep.py, which reads frame_stats() between frames.)
+static int copy_d2h(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return WS_OK;
+    WS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+    WS_HIP(hipStreamSynchronize(stream));
+    return WS_OK;
+}
+
 template <typename T>
 static void dfree(T*& p) {
     if (p) (void)hipFree(p);
@@ -353,7 +364,7 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
     if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
-    ctx->use_graph = env_int("WS_GRAPH", 1);
+    ctx->use_graph = env_int("WS_GRAPH", 0);
     ctx->blend_split = env_int("WS_BLEND_SPLIT", 0);
     ctx->blend_lds_pad_kb = env_int("WS_BLEND_LDS_PAD_KB", 0);
     if (ctx->blend_lds_pad_kb < 0 || ctx->blend_lds_pad_kb > 96) ctx->blend_lds_pad_kb = 0;
@@ -1035,7 +1046,7 @@ int ws_renderer_frame_stats(ws_renderer* r, ws_frame_stats* out) {
     if (!r->prepared) return fail(WS_ERR_STATE, "ws_renderer_frame_stats: no prepared frame");
     WS_HIP(hipStreamSynchronize(r->last_stream));
     FrameCounters fc;
-    WS_HIP(hipMemcpy(&fc, r->counters, sizeof fc, hipMemcpyDeviceToHost));
+    { int rc_ = copy_d2h(&fc, r->counters, sizeof fc, r->last_stream); if (rc_) return rc_; }
     out->num_visible = fc.num_visible;
     out->num_tile_entries = fc.num_entries;
     out->tile_entries_capacity = r->entry_cap;
@@ -1049,9 +1060,12 @@ int ws_renderer_errors(ws_renderer* r, uint32_t* bits, uint32_t* entries_needed,
     if (entries_needed) *entries_needed = 0;
     if (!r->prepared) return WS_OK;  // nothing rendered yet
     WS_HIP(hipStreamSynchronize(r->last_stream));
-    WS_HIP(hipMemcpy(bits, r->sticky, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (entries_needed) WS_HIP(hipMemcpy(entries_needed, &r->counters->entries_needed, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (reset && *bits) WS_HIP(hipMemset(r->sticky, 0, sizeof(uint32_t)));
+    { int rc_ = copy_d2h(bits, r->sticky, sizeof(uint32_t), r->last_stream); if (rc_) return rc_; }
+    if (entries_needed) { int rc_ = copy_d2h(entries_needed, &r->counters->entries_needed, sizeof(uint32_t), r->last_stream); if (rc_) return rc_; }
+    if (reset && *bits) {
+        WS_HIP(hipMemsetAsync(r->sticky, 0, sizeof(uint32_t), r->last_stream));
+        WS_HIP(hipStreamSynchronize(r->last_stream));
+    }
     return WS_OK;
 }
 
@@ -1107,10 +1121,10 @@ int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t*
     WS_HIP(hipStreamSynchronize(r->last_stream));
     if (list_len) {
         std::vector<uint2> rg(nt);
-        WS_HIP(hipMemcpy(rg.data(), r->tile_ranges, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost));
+        { int rc_ = copy_d2h(rg.data(), r->tile_ranges, (size_t)nt * sizeof(uint2), r->last_stream); if (rc_) return rc_; }
         for (uint32_t i = 0; i < nt; ++i) list_len[i] = rg[i].y ? rg[i].y - (0xFFFFFFFFu - rg[i].x) : 0u;
     }
-    if (consumed) WS_HIP(hipMemcpy(consumed, r->debug_consumed, (size_t)nt * 4, hipMemcpyDeviceToHost));
+    if (consumed) { int rc_ = copy_d2h(consumed, r->debug_consumed, (size_t)nt * 4, r->last_stream); if (rc_) return rc_; }
     return WS_OK;
 }
 
@@ -1121,7 +1135,7 @@ int ws_renderer_download_wave_stats(ws_renderer* r, uint32_t tile_capacity, uint
     const uint32_t nt = r->tiles_x * r->tiles_y;
     if (tile_capacity < nt) return fail(WS_ERR_INVALID, "ws_renderer_download_wave_stats: capacity smaller than the tile count");
     WS_HIP(hipStreamSynchronize(r->last_stream));
-    WS_HIP(hipMemcpy(walked, r->debug_walked, (size_t)nt * 17 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    { int rc_ = copy_d2h(walked, r->debug_walked, (size_t)nt * 17 * sizeof(uint32_t), r->last_stream); if (rc_) return rc_; }
     return WS_OK;
 }
 
@@ -1138,14 +1152,14 @@ int ws_renderer_download_tile_lists(ws_renderer* r, uint32_t tile_capacity, uint
         return fail(WS_ERR_INVALID, "ws_renderer_download_tile_lists: entry capacity too small");
     if (begin || end) {
         std::vector<uint2> rg(nt);
-        WS_HIP(hipMemcpy(rg.data(), r->tile_ranges, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost));
+        { int rc_ = copy_d2h(rg.data(), r->tile_ranges, (size_t)nt * sizeof(uint2), r->last_stream); if (rc_) return rc_; }
         for (uint32_t i = 0; i < nt; ++i) {
             if (begin) begin[i] = rg[i].y ? 0xFFFFFFFFu - rg[i].x : 0u;
             if (end) end[i] = rg[i].y;
         }
     }
     if (entries && st.num_tile_entries)
-        WS_HIP(hipMemcpy(entries, r->entries_sorted, (size_t)st.num_tile_entries * 4, hipMemcpyDeviceToHost));
+        { int rc_ = copy_d2h(entries, r->entries_sorted, (size_t)st.num_tile_entries * 4, r->last_stream); if (rc_) return rc_; }
     return WS_OK;
 }
 
@@ -1162,15 +1176,15 @@ int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, 
     if (src_index && !r->capture)
         return fail(WS_ERR_STATE, "ws_renderer_download_frame: src_index needs ws_renderer_enable_capture before prepare");
     if (v == 0) return WS_OK;
-    if (splats) WS_HIP(hipMemcpy(splats, r->splats, (size_t)v * 20, hipMemcpyDeviceToHost));
-    if (src_index) WS_HIP(hipMemcpy(src_index, r->src_index, (size_t)v * 4, hipMemcpyDeviceToHost));
-    if (sorted) WS_HIP(hipMemcpy(sorted, r->sorted_idx, (size_t)v * 4, hipMemcpyDeviceToHost));
+    if (splats) { int rc_ = copy_d2h(splats, r->splats, (size_t)v * 20, r->last_stream); if (rc_) return rc_; }
+    if (src_index) { int rc_ = copy_d2h(src_index, r->src_index, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
+    if (sorted) { int rc_ = copy_d2h(sorted, r->sorted_idx, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
     if (keys) {
         // the sort permutes the keys in place; un-permute them with the sorted indices so that the caller
         // gets keys in STORE order (what preprocess wrote)
         std::vector<uint32_t> ks(v), idx(v);
-        WS_HIP(hipMemcpy(ks.data(), r->sorted_keys, (size_t)v * 4, hipMemcpyDeviceToHost));
-        WS_HIP(hipMemcpy(idx.data(), r->sorted_idx, (size_t)v * 4, hipMemcpyDeviceToHost));
+        { int rc_ = copy_d2h(ks.data(), r->sorted_keys, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
+        { int rc_ = copy_d2h(idx.data(), r->sorted_idx, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
         for (uint32_t i = 0; i < v; ++i)
             if (idx[i] < v) keys[idx[i]] = ks[i];
     }

@@ -297,7 +297,9 @@ struct ws_context {
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
     int blend_split = 0;      // WS_BLEND_SPLIT=1 (A/B): 4x4 binning tiles composited by two 4x2 workgroups each
-    int use_graph = 1;        // WS_GRAPH=0: enqueue every frame launch by launch instead of replaying the captured frame graph
+    int use_graph = 0;        // WS_GRAPH=1: prepare() on a real stream replays a captured frame graph instead of enqueueing 22
+                              //   launches (opt-in: on ROCm 7.2 legacy-NULL-stream work between two launches of a used
+                              //   executable graph makes the next launch fault)
     uint32_t tile_qw = 4, tile_qh = 4;  // WS_TILE_SHAPE = 2x2 | 4x2 | 4x4 (default: 32x32-px binning tiles)
 };
 
