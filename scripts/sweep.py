@@ -10,6 +10,9 @@ from websplat import synth
 
 ctx = ws.Context(0)
 out = []
+# four real streams, created ONCE: a renderer on the legacy NULL stream serialises against the others (the round-1 sweeps
+# had one), and streams taken from torch's pool again and again end up sharing hardware queues in some cells
+STREAMS = [torch.cuda.Stream() for _ in range(4)]
 for n in (250_000, 500_000, 1_000_000, 2_000_000, 5_000_000):
     gpc = ws.GenericGaussianPointCloud.from_ply_rows(synth.scene_c2(n=n, seed=1), 3)
     pc = ws.PointCloud(ctx, gpc)
@@ -24,7 +27,7 @@ for n in (250_000, 500_000, 1_000_000, 2_000_000, 5_000_000):
         for ns in (4, 1):
             rs = [ws.GaussianRenderer(ctx, "rgba32float", 3, False) for _ in range(ns)]
             tg = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(ns)]
-            st = [torch.cuda.current_stream().cuda_stream] + [torch.cuda.Stream().cuda_stream for _ in range(ns - 1)]
+            st = [s_.cuda_stream for s_ in STREAMS[:ns]]
             def frame(i):
                 k = i % ns
                 rs[k].prepare(pc, views[i % 16], stream=st[k]); rs[k].render(pc, target_ptr=tg[k].data_ptr(), stream=st[k])

@@ -25,7 +25,9 @@ for ns in streams:
     if os.environ.get("NONNULL"):
         st = [s_.cuda_stream for s_ in keep]
     print("streams", ns, "stream handles", st, flush=True)
-    for i in range(64):
+    nframes = int(os.environ.get("FRAMES", "64"))
+    torch.cuda.synchronize(); t_start = time.perf_counter()
+    for i in range(nframes):
         k = i % ns
         rs[k].prepare(pc, views[i % 16], stream=st[k]); rs[k].render(pc, target_ptr=tg[k].data_ptr(), stream=st[k])
         mix = os.environ.get("MIX")
@@ -40,5 +42,6 @@ for ns in streams:
         if os.environ.get("SYNC_EACH"):
             torch.cuda.synchronize(); print("frame", i, "ok", rs[k].frame_stats() if os.environ.get("SYNC_EACH") == "1" else "", flush=True)
     torch.cuda.synchronize()
+    print("streams %d: %.0f frames/s" % (ns, nframes / (time.perf_counter() - t_start)), flush=True)
     print("streams", ns, "done", rs[0].frame_stats(), rs[0].errors(), flush=True)
     for r in rs: r.close()

@@ -267,7 +267,7 @@ def test_ply_file_roundtrip(ws, ctx, oracle, tmp_path):
                                  {"WS_TILE_SHAPE": "4x4", "WS_BLEND_TPW_LOG2": "1"},
                                  {"WS_TILE_SHAPE": "4x2", "WS_BLEND_TPW_LOG2": "2"},
                                  {"WS_DEPTH_SORT": "adaptive"}, {"WS_DEPTH_SORT": "adaptive", "WS_TILE_SHAPE": "2x2"},
-                                 {"WS_BLEND_SPLIT": "1"}])
+                                 {"WS_BLEND_SPLIT": "1"}, {"WS_BLEND_SPLIT": "0"}])
 def test_cross_check_paths(ws, oracle, env, monkeypatch):
     """The alternative implementations kept as cross-checks (one-sweep look-back sort, range-adaptive three-pass depth
     sort, wave-per-quadrant blend) and
@@ -457,7 +457,9 @@ def test_wave_stats_capture(ws, ctx, oracle):
         r.prepare(pc, sc.args)
         r.render(pc)
         img_cap = r.download_target()
-        assert np.array_equal(img_plain, img_cap)
+        # (capture mode always composites whole 32x32 binning tiles; without it a viewport this small is drawn by two
+        # 32x16 workgroups per tile, whose tile-local coordinates round the affine map differently in the last bits)
+        assert np.abs(img_plain - img_cap).max() <= 4e-6
         st = r.wave_stats().astype(np.int64)
         ts = r.tile_stats(with_consumed=True)
         tw, th = ctx.tile_size()

@@ -365,7 +365,8 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
     if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
     ctx->use_graph = env_int("WS_GRAPH", 0);
-    ctx->blend_split = env_int("WS_BLEND_SPLIT", 0);
+    ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
+    ctx->num_cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
     ctx->blend_lds_pad_kb = env_int("WS_BLEND_LDS_PAD_KB", 0);
     if (ctx->blend_lds_pad_kb < 0 || ctx->blend_lds_pad_kb > 96) ctx->blend_lds_pad_kb = 0;
     if (const char* shape = std::getenv("WS_TILE_SHAPE")) {  // tuning / A-B: quadrants per tile
@@ -1013,7 +1014,13 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
     bp.lds_pad_kb = r->ctx->blend_lds_pad_kb;
     bp.range_row_shift = 0;
-    if (r->ctx->blend_split && bp.qw == 4 && bp.qh == 4 && !r->capture) {  // A/B: two 512-thread workgroups per binning tile
+    // Two 512-thread workgroups (32x16 halves) per 32x32 binning tile, both reading the tile's list.  Automatic: when the
+    // frame has fewer binning tiles than the chip holds 1024-thread blend workgroups (two per CU) -- small viewports --
+    // the halves fill the chip and balance the long tiles (800x600, 0.5 M Gaussians: +24 % frames/s); above that the
+    // doubled staging costs more with frames in flight than the finer synchronisation saves.
+    const bool split = r->ctx->blend_split >= 0 ? r->ctx->blend_split != 0
+                                                 : (r->tiles_x * r->tiles_y < 2u * (uint32_t)r->ctx->num_cus);
+    if (split && bp.qw == 4 && bp.qh == 4 && !r->capture && r->ctx->blend_variant == 0) {
         bp.qh = 2;
         bp.tiles_y = (r->vh + 15u) / 16u;
         bp.range_row_shift = 1;

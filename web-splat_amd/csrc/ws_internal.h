@@ -296,7 +296,8 @@ struct ws_context {
     int debug_cut = 0;        // WS_DEBUG_CUT (analysis): 0 = whole frame
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
-    int blend_split = 0;      // WS_BLEND_SPLIT=1 (A/B): 4x4 binning tiles composited by two 4x2 workgroups each
+    int blend_split = -1;     // WS_BLEND_SPLIT: 4x4 binning tiles composited by two 4x2 workgroups each; -1 = when tiles < 2 x CUs
+    int num_cus = 256;
     int use_graph = 0;        // WS_GRAPH=1: prepare() on a real stream replays a captured frame graph instead of enqueueing 22
                               //   launches (opt-in: on ROCm 7.2 legacy-NULL-stream work between two launches of a used
                               //   executable graph makes the next launch fault)
