@@ -43,7 +43,7 @@ def test_k1_equals_the_reference_shader(ws, ctx, oracle, case):
         o = z["splats"].copy()
         oh = o.view(np.uint16).reshape(-1, 10)
         undefined = ((oh[:, :4] & 0x7FFF) > 0x7C00).any(axis=1)   # normalize((0,0)): indeterminate in WGSL
-        assert undefined.any() == (case == "fade_in")
+        assert undefined.any() == (case in ("fade_in", "extremes"))
         if undefined.any():
             assert frame["num_visible"] == len(z["keys"])
             gh = frame["splats"].view(np.uint16).reshape(-1, 10)

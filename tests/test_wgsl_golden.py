@@ -151,7 +151,7 @@ def test_oracle_k1_equals_the_reference_shader(oracle, case):
     # interpreter gives NaN axes; it happens exactly where the screen covariance is isotropic (fade-in not started:
     # covariance = the dilation kernel alone).  The oracle and the library define the direction as (1, 0) there.
     undefined = ((o[:, :4] & 0x7FFF) > 0x7C00).any(axis=1)
-    assert undefined.sum() == (int((undefined).sum()) if case == "fade_in" else 0)
+    assert undefined.any() == (case in ("fade_in", "extremes"))   # (extremes: splats far below a pixel, covariance = the kernel)
     assert np.array_equal(g[~undefined], o[~undefined])
     assert np.array_equal(g[undefined][:, 4:], o[undefined][:, 4:])
     if undefined.any():

@@ -9,7 +9,7 @@ import numpy as np
 import scenes
 from websplat import synth
 
-K1_CASES = ("default", "sh0", "sh1", "sh2", "mip_on", "kernel_0p1", "scaling_0p5", "fade_in", "clip_box", "inside")
+K1_CASES = ("default", "sh0", "sh1", "sh2", "mip_on", "kernel_0p1", "scaling_0p5", "fade_in", "clip_box", "inside", "extremes")
 K1C_CASES = ("deg3", "deg2", "deg0")
 
 
@@ -34,6 +34,18 @@ def k1_scene(ws, oracle, name):
         rows = synth.scene_c2(n=n, seed=seed)
         cj = synth.look_at_camera(0, [0.3, -0.2, -1.0], [0.2, 0.1, 0.5], 400, 300, 350.0, 350.0)
         return scenes.Scene(ws, oracle, rows, 3, cj, (400, 300))
+    elif name == "extremes":
+        # the rarely taken branches: scales from 1e-6 to 3 (lambda2 clamped at 0.1, f16 overflow of the axes to inf for
+        # splats the camera almost touches), mip-splatting with det_0 <= 1e-6 (coef = 0), opacities at both ends,
+        # Gaussians on the near plane and just outside the 1.2 w cull bounds; camera 0.3 from the cloud's edge
+        rng = np.random.default_rng(99)
+        rows = synth.scene_c1(n=n, seed=98)
+        ncol = rows.shape[1]
+        rows[:, ncol - 7:ncol - 4] = rng.uniform(np.log(1e-6), np.log(3.0), size=(n, 3)).astype(np.float32)   # log scales
+        rows[:, ncol - 8] = rng.choice(np.array([-30.0, -8.0, 0.0, 8.0, 30.0], dtype=np.float32), size=n)      # opacity logits
+        rows[: n // 4, :3] *= np.float32(0.02)                                                                  # a knot at the centre
+        cj = synth.look_at_camera(0, [0.0, 0.1, -1.3], [0.0, 0.0, 0.0], 400, 300, 300.0, 300.0)
+        return scenes.Scene(ws, oracle, rows, 3, cj, (400, 300), mip_splatting=True, kernel_size=0.05)
     elif name != "default":
         raise KeyError("unknown K1 case " + name)
     return scenes.c1(ws, oracle, n=n, viewport=viewport, seed=seed, sh_deg=sh_deg, max_sh_deg=sh_deg, **kw)
