@@ -185,8 +185,21 @@ def test_oracle_k1c_matches_the_reference_shader(oracle, case):
     o = z["splats"].view(np.uint16).reshape(-1, 10)
     assert np.array_equal(g[:, 4:9], o[:, 4:9])                 # centre, r, g, b: no exp() upstream
     d = scenes.half_ulp_diff(g, o)
-    assert d[:, 9].max() <= 1                                    # opacity (mip-splatting off: exact; kept as a bound)
-    assert (d[:, :4] > 0).mean() < 0.05 and d[:, :4].max() <= 2, (float((d[:, :4] > 0).mean()), int(d[:, :4].max()))
+    assert d[:, 9].max() <= 1                                    # opacity (one ulp of the mip-splatting coefficient)
+    # the axes through the screen covariance they encode, (v1 v1^T + v2 v2^T) / 2: the eigenvector direction
+    # normalize((off, lambda1 - d1)) is ill-conditioned for nearly isotropic splats, so the ulp of exp() may turn the axes
+    # by several f16 ulps while the Gaussian they describe is unchanged (same criterion as tests/test_gpu_preprocess.py)
+    assert (d[:, :4] > 0).mean() < 0.05
+
+    def cov(hh):
+        f = hh[:, :4].view(np.float16).astype(np.float64)
+        w, h = (float(x) for x in z["viewport"])
+        v1 = np.stack([f[:, 0] * w, f[:, 1] * h], -1)
+        v2 = np.stack([f[:, 2] * w, f[:, 3] * h], -1)
+        return 0.5 * (v1[:, :, None] * v1[:, None, :] + v2[:, :, None] * v2[:, None, :])
+    cg, co = cov(np.ascontiguousarray(g)), cov(np.ascontiguousarray(o))
+    rel = np.abs(cg - co).max(axis=(1, 2)) / np.maximum(np.abs(co).max(axis=(1, 2)), 1e-12)
+    assert rel.max() <= 2.0 ** -8, float(rel.max())
 
 
 # ---- K6 ----------------------------------------------------------------------------------------------------------------

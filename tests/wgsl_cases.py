@@ -10,7 +10,7 @@ import scenes
 from websplat import synth
 
 K1_CASES = ("default", "sh0", "sh1", "sh2", "mip_on", "kernel_0p1", "scaling_0p5", "fade_in", "clip_box", "inside", "extremes")
-K1C_CASES = ("deg3", "deg2", "deg0")
+K1C_CASES = ("deg3", "deg2", "deg0", "deg1_mip")
 
 
 def k1_scene(ws, oracle, name):
@@ -53,9 +53,12 @@ def k1_scene(ws, oracle, name):
 
 def k1c_inputs(ws, name):
     """-> (host point cloud read back through the library's .npz reader, camera, viewport, sh_deg)"""
-    sh_deg = {"deg3": 3, "deg2": 2, "deg0": 0}[name]
+    sh_deg = {"deg3": 3, "deg2": 2, "deg0": 0, "deg1_mip": 1}[name]
     a = synth.c3dgs_arrays(n=500, n_geometry=96, n_sh=80, seed=70 + sh_deg, sh_deg=sh_deg, extent=1.0)
     a["scaling_factor_zero_point"] = np.array(330, dtype=np.int32)
+    if name == "deg1_mip":  # the file's own metadata (io/npz.rs:29-56): mip-splatting on, kernel size 0.1
+        a["mip_splatting"] = np.array(1, dtype=np.int32)
+        a["kernel_size"] = np.array(0.1, dtype=np.float32)
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "c.npz")
         synth.write_npz(path, a)
