@@ -8,7 +8,8 @@ source rather than to a reading of it.  Nothing in the product path imports this
 
 What is implemented is the W3C WGSL semantics of exactly what those shaders use:
   * declarations: const, struct (with @align), var<uniform|storage>, fn; attributes are parsed and ignored otherwise;
-  * statements: let / var / assignment / compound assignment / if-else / return / discard / call statements;
+  * statements: let / var / assignment / compound assignment / ++ / -- / if-else / for / while / loop / break / continue /
+    return / discard / call statements;
   * types: f32 u32 i32 bool, vecN<T>, matCxR<f32>, array<T,N>, array<T>, atomic<T>, structs;
   * the memory layout rules (align / size / stride, section "Memory Layout") used to decode the bound buffers from raw bytes
     and to encode stores, so that the host-side uniform structs are checked against the shader's own declaration;
@@ -18,7 +19,11 @@ What is implemented is the W3C WGSL semantics of exactly what those shaders use:
     smoothstep clamp min max abs sqrt exp log floor select bitcast atomicAdd atomicLoad atomicStore arrayLength and the
     value constructors.  length = sqrt(x*x + y*y [+ z*z]) summed left to right, normalize = v / length(v),
     smoothstep = t*t*(3 - 2t): the spec's definitions, without fused operations.
-Invocations run one after the other in global-invocation order, so atomicAdd hands out consecutive values in that order.
+dispatch(): invocations run one after the other in global-invocation order, so atomicAdd hands out consecutive values in
+that order.  dispatch_workgroups(): for entry points whose invocations cooperate -- var<workgroup> / var<private>,
+workgroupBarrier(): workgroups in workgroup-id order, the invocations of one as threads that meet at the barriers, atomics
+serialised, WebGPU's robust buffer access on request (out-of-bounds loads give zero, stores are dropped).  What it does NOT
+model is subgroup lock-step: code that reads a neighbour lane's store without a barrier needs subgroup size 1.
 """
 import re
 import struct
@@ -102,6 +107,14 @@ class Discard(Exception):
 class _Return(Exception):
     def __init__(self, v):
         self.v = v
+
+
+class _Break(Exception):
+    pass
+
+
+class _Continue(Exception):
+    pass
 
 
 def is_abstract(v):
@@ -388,7 +401,9 @@ class Parser:
         if self.at("<"):
             self.eat("<")
             while True:
-                if self.peek()[0] == "id" and (self.peek()[1] in TEMPLATED or self.peek(1)[1] in (",", ">", ">>")):
+                if name == "array" and args:          # array<T, N>: the element count is an expression
+                    args.append(("expr", self.add()))
+                elif self.peek()[0] == "id" and (self.peek()[1] in TEMPLATED or self.peek(1)[1] in (",", ">", ">>")):
                     args.append(self.type_())
                 else:
                     args.append(("expr", self.add()))
@@ -520,6 +535,46 @@ class Parser:
             return ("if", cond, then, els)
         if tok == "{":
             return ("block", self.block())
+        if tok in ("break", "continue"):
+            self.eat()
+            self.eat(";")
+            return (tok,)
+        if tok == "while":
+            self.eat()
+            cond = self.expr()
+            return ("loop", None, cond, None, self.block())
+        if tok == "loop":
+            self.eat()
+            return ("loop", None, None, None, self.block())
+        if tok == "for":
+            self.eat()
+            self.eat("(")
+            init = None if self.at(";") else self.statement()      # (consumes its own ';')
+            if init is None:
+                self.eat(";")
+            cond = None if self.at(";") else self.expr()
+            self.eat(";")
+            step = None if self.at(")") else self.simple_statement()
+            self.eat(")")
+            return ("loop", init, cond, step, self.block())
+        st = self.simple_statement()
+        self.eat(";")
+        return st
+
+    def simple_statement(self):
+        """assignment / compound assignment / increment / call, without the trailing ';' (also a for-loop's step)."""
+        lhs = self.expr()
+        if self.at("++") or self.at("--"):
+            op = self.eat()
+            return ("assign", "+=" if op == "++" else "-=", lhs, ("num", 1))
+        if self.at(";") or self.at(")"):
+            return ("expr", lhs)
+        op = self.eat()
+        if op not in ("=", "+=", "-=", "*=", "/=", "%=", "&=", "|=", "^=", "<<=", ">>="):
+            raise SyntaxError("unexpected %r in statement" % op)
+        return ("assign", op, lhs, self.expr())
+
+    def _unused_statement_tail(self):
         lhs = self.expr()
         if self.at(";"):
             self.eat(";")
@@ -768,6 +823,8 @@ class Ref:
             stride = round_up(a, s)
             n = (len(self.buf) - self.off) // stride if len(args) == 1 else int(self.layout.m.const_eval(args[1][1]))
             if not 0 <= i < n:
+                if self.layout.m.robust:
+                    return OobRef(self.layout, args[0])
                 raise IndexError("buffer index %d out of range (%d)" % (i, n))
             return Ref(self.layout, self.buf, args[0], self.off + stride * i)
         raise TypeError("indexing a reference to " + name)
@@ -775,6 +832,29 @@ class Ref:
     def array_length(self):
         a, s = self.layout.align_size(self.ty[2][0])
         return (len(self.buf) - self.off) // round_up(a, s)
+
+
+class OobRef:
+    """Out-of-bounds element under WebGPU's robust buffer access: loads give zero, stores are dropped."""
+
+    def __init__(self, layout, ty):
+        self.layout, self.ty = layout, ty
+
+    def load(self):
+        return self.layout.m.zero(self.ty if self.ty[1] != "atomic" else self.ty[2][0])
+
+    def store(self, v):
+        pass
+
+    def member(self, name):
+        _, _, members = self.layout.struct_layout(self.ty[1])
+        for fname, fty, _ in members:
+            if fname == name:
+                return OobRef(self.layout, fty)
+        raise KeyError(name)
+
+    def index(self, i):
+        return OobRef(self.layout, self.ty[2][0])
 
 
 class LocalRef:
@@ -798,6 +878,12 @@ class Module:
         self.consts = {}
         self.vars = {}        # name -> (type, address space list)
         self.bindings = {}    # name -> bytearray
+        self.wg = {}          # var<workgroup>: name -> value shared by the invocations of the running workgroup
+        import threading
+        self.tls = threading.local()   # .private: var<private> of the invocation this thread runs
+        self.robust = False   # WebGPU robust buffer access: out-of-bounds loads give 0, stores are dropped
+        self.barrier = None   # callable run by workgroupBarrier() (set by dispatch_workgroups)
+        self.atomic_lock = None
         self.layout = Layout(self)
         for d in self.decls:
             if d[0] == "struct":
@@ -837,6 +923,8 @@ class Module:
             return i32(0)
         if name == "bool":
             return False
+        if name == "atomic":
+            return self.zero(args[0])
         if name in ("vec2", "vec3", "vec4"):
             return Vec([self.zero(args[0]) for _ in range(int(name[3]))])
         if name.startswith("mat"):
@@ -928,12 +1016,29 @@ class Module:
                     def set_(v, scope=scope, name=name):
                         scope[name] = v
                     return LocalRef(get, set_)
+            priv = getattr(self.tls, "private", None)
+            if priv is not None and name in priv:
+                def getp(priv=priv, name=name):
+                    return priv[name]
+
+                def setp(v, priv=priv, name=name):
+                    priv[name] = v
+                return LocalRef(getp, setp)
+            if name in self.wg:
+                def getw(name=name):
+                    return self.wg[name]
+
+                def setw(v, name=name):
+                    self.wg[name] = v
+                return LocalRef(getw, setw)
             if name in self.bindings:
                 return Ref(self.layout, self.bindings[name], self.vars[name][0], 0)
             raise NameError(name)
         if kind == "member":
             base = self.ref(e[1], env)
             name = e[2]
+            if isinstance(base, OobRef):
+                return base.member(name)
             if isinstance(base, Ref):
                 if base.ty[1] in self.structs:
                     return base.member(name)
@@ -962,6 +1067,8 @@ class Module:
         if kind == "index":
             base = self.ref(e[1], env)
             idx = int(self.eval(e[2], env))
+            if isinstance(base, OobRef):
+                return base.index(idx)
             if isinstance(base, Ref):
                 if base.ty[1] == "array":
                     return base.index(idx)
@@ -1025,6 +1132,11 @@ class Module:
                     return scope[name]
             if name in self.consts:
                 return self.consts[name]
+            priv = getattr(self.tls, "private", None)
+            if priv is not None and name in priv:
+                return priv[name]
+            if name in self.wg:
+                return self.wg[name]
             if name in self.bindings:
                 return Ref(self.layout, self.bindings[name], self.vars[name][0], 0).load()
             raise NameError(name)
@@ -1187,14 +1299,26 @@ class Module:
                 return scalar_binop("*", scalar_binop("*", t, t),
                                     scalar_binop("-", F32(3.0), scalar_binop("*", F32(2.0), t)))
             return cw(ss, a[0], a[1], a[2])
-        if name == "atomicAdd":
-            old = a[0].load()
-            a[0].store(scalar_binop("+", old, concretize_like(a[1], old)))
-            return old
-        if name == "atomicLoad":
-            return a[0].load()
-        if name == "atomicStore":
-            a[0].store(a[1])
+        if name in ("atomicAdd", "atomicLoad", "atomicStore"):
+            lock = self.atomic_lock
+            if lock is not None:
+                lock.acquire()
+            try:
+                if name == "atomicLoad":
+                    return a[0].load()
+                if name == "atomicStore":
+                    a[0].store(concretize_like(a[1], a[0].load()))
+                    return None
+                old = a[0].load()
+                a[0].store(scalar_binop("+", old, concretize_like(a[1], old)))
+                return old
+            finally:
+                if lock is not None:
+                    lock.release()
+        if name in ("workgroupBarrier", "storageBarrier"):
+            if self.barrier is None:
+                raise RuntimeError("workgroupBarrier() outside dispatch_workgroups(threads=True)")
+            self.barrier()
             return None
         if name == "arrayLength":
             return u32(a[0].array_length())
@@ -1214,7 +1338,9 @@ class Module:
         return None
 
     def run(self, stmts, env):
-        env = env + [{}]
+        self.run_here(stmts, env + [{}])
+
+    def run_here(self, stmts, env):
         for s in stmts:
             kind = s[0]
             if kind in ("let", "var"):
@@ -1257,8 +1383,74 @@ class Module:
                 raise _Return(None if s[1] is None else self.eval(s[1], env))
             elif kind == "discard":
                 raise Discard()
+            elif kind == "break":
+                raise _Break()
+            elif kind == "continue":
+                raise _Continue()
+            elif kind == "loop":
+                _, init, cond, step, body = s
+                lenv = env + [{}]
+                if init is not None:
+                    self.run_here([init], lenv)
+                while cond is None or bool(self.eval(cond, lenv)):
+                    try:
+                        self.run(body, lenv)
+                    except _Break:
+                        break
+                    except _Continue:
+                        pass
+                    if step is not None:
+                        self.run_here([step], lenv)
             else:
                 raise TypeError("statement " + kind)
+
+    def dispatch_workgroups(self, entry, num_workgroups, threads=True):
+        """Run a compute entry point whose workgroups cooperate: workgroups one after the other in workgroup-id order (a
+        workgroup that looks back at its predecessors finds them finished), the invocations of a workgroup as threads that
+        meet at workgroupBarrier(); var<workgroup> is zero-initialised per workgroup, var<private> per invocation; atomics
+        are serialised.  threads=False runs the invocations one after the other (entry points without barriers)."""
+        import threading
+        _, _, params, _, body, attrs = self.fns[entry]
+        wg = int(self.const_eval(attrs["workgroup_size"][0]))
+        self.atomic_lock = threading.Lock() if threads else None
+        errors = []
+
+        def invocation(w, l, barrier):
+            scope = {}
+            self.tls.private = {vname: self.zero(vty) for vname, (vty, space) in self.vars.items() if "private" in space}
+            for pname, pty, pattrs in params:
+                which = pattrs["builtin"][0][1]
+                scope[pname] = {"global_invocation_id": Vec([u32(w * wg + l), u32(0), u32(0)]),
+                                "local_invocation_id": Vec([u32(l), u32(0), u32(0)]),
+                                "workgroup_id": Vec([u32(w), u32(0), u32(0)]),
+                                "num_workgroups": Vec([u32(num_workgroups), u32(1), u32(1)])}[which]
+            try:
+                self.run(body, [scope])
+            except _Return:
+                pass
+            except BaseException as e:  # noqa: BLE001  (reported by the dispatching thread)
+                errors.append(e)
+                if barrier is not None:
+                    barrier.abort()
+
+        for w in range(num_workgroups):
+            self.wg = {vname: self.zero(vty) for vname, (vty, space) in self.vars.items() if "workgroup" in space}
+            if threads:
+                barrier = threading.Barrier(wg)
+                self.barrier = barrier.wait
+                ts = [threading.Thread(target=invocation, args=(w, l, barrier)) for l in range(wg)]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+            else:
+                self.barrier = None
+                for l in range(wg):
+                    invocation(w, l, None)
+            if errors:
+                raise errors[0]
+        self.barrier = None
+        self.atomic_lock = None
 
     def dispatch(self, entry, num_workgroups, after_invocation=None):
         """Run a compute entry point: workgroups x workgroup_size invocations in global-invocation order.

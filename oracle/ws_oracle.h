@@ -9,7 +9,9 @@
  * through wgpu/naga; no cargo, no Vulkan ICD), so there is no oracle/_ref.
  *   PINNED to the reference's own source:
  *   - the sort contract, by GPURSSorter::test_sort (src/gpu_rs.rs:295-331: 8192
- *     reversed f32 keys), tests/test_oracle.py;
+ *     reversed f32 keys), tests/test_oracle.py, and by radix_sort.wgsl executed
+ *     from source as GPURSSorter::record_sort drives it (tests/golden/wgsl_sort_*.npz:
+ *     ties, extreme bit patterns, one and two scatter blocks): ascending u32, stable;
  *   - wso_preprocess (K1), wso_preprocess_compressed (K1c) and the fragment
  *     function inside wso_render (K6), by tests/golden/wgsl_*.npz: the outputs of
  *     preprocess.wgsl / preprocess_compressed.wgsl / gaussian.wgsl executed FROM

@@ -13,6 +13,7 @@ shader wrote.  Bindings and the MAX_SH_DEG prefix follow renderer.rs:379-392 (bu
   wgsl_k1_<case>.npz    preprocess.wgsl `preprocess`            -> points_2d, sort_depths, keys_size, dispatch_x (+ the
                         invocation that drew each store index)
   wgsl_k1c_<case>.npz   preprocess_compressed.wgsl `preprocess` -> the same
+  wgsl_sort_<case>.npz  radix_sort.wgsl driven as GPURSSorter::record_sort drives it -> sorted keys and payload
   wgsl_frame.npz        K1 + stable sort + the instanced draw with the pipeline's blend state: a whole 320x240 frame
   wgsl_k6_fragments.npz gaussian.wgsl `vs_main` (4 vertices per instance) and `fs_main` at pixel centres; the
                         screen_pos a fragment receives is the rasteriser's linear interpolation of the four vertices'
@@ -243,6 +244,59 @@ def frame():
     return res
 
 
+# ---- the radix sort (gpu_rs.rs + radix_sort.wgsl) ------------------------------------------------------------------------
+def sort_case(n, seed, subgroup=1):
+    """GPURSSorter::record_sort (gpu_rs.rs:865-873) on n seeded (key, payload) pairs, kernels from radix_sort.wgsl.
+
+    The shader is instantiated as new_with_sg_size does (gpu_rs.rs:177-256: eleven constants in front, three placeholders
+    replaced) with subgroup size 1 -- one of the sizes the reference's own search tries (gpu_rs.rs:65-139).  It is the
+    race-free instantiation: for larger sizes `scatter` relies on the lanes of a subgroup running in lock-step between an
+    atomicStore and the neighbours' atomicLoad (no barrier), which this interpreter -- threads that meet at barriers --
+    does not model.  The sorted order does not depend on that size.  Buffers, GeneralInfo and dispatch sizes follow
+    create_keyval_buffers / create_internal_mem_buffer / create_bind_group / get_scatter_histogram_sizes
+    (gpu_rs.rs:478-663) and record_calculate_histogram / record_prefix_histogram / record_scatter_keys (:729-835); the
+    payload buffers have keysize elements only (the reference's under-allocation), so the padded tail is read and
+    written out of bounds, which WebGPU's robust buffer access turns into zeros / dropped stores."""
+    WG, LOG2, RADIX, KEYVAL, ROWS, PREFIX_WG, SCATTER_WG = 256, 8, 256, 4, 15, 128, 256
+    sweep0 = RADIX // subgroup
+    sweep1 = sweep0 // subgroup
+    consts = [subgroup, WG, LOG2, RADIX, KEYVAL, ROWS, ROWS, RADIX + ROWS * SCATTER_WG, 0, sweep0, sweep0 + sweep1]
+    names = ["histogram_sg_size", "histogram_wg_size", "rs_radix_log2", "rs_radix_size", "rs_keyval_size",
+             "rs_histogram_block_rows", "rs_scatter_block_rows", "rs_mem_dwords", "rs_mem_sweep_0_offset",
+             "rs_mem_sweep_1_offset", "rs_mem_sweep_2_offset"]
+    src = "".join("const %s: u32 = %du;\n" % (k, v) for k, v in zip(names, consts)) + shader("radix_sort.wgsl")
+    src = src.replace("{histogram_wg_size}", str(WG)).replace("{prefix_wg_size}", str(PREFIX_WG)).replace("{scatter_wg_size}", str(SCATTER_WG))
+    block = WG * ROWS
+    scatter_blocks = (n + block - 1) // block
+    count_ru_scatter = scatter_blocks * block
+    histo_blocks = (count_ru_scatter + block - 1) // block
+    padded = histo_blocks * block                                # GeneralInfo::padded_size
+    keybuf_elems = ((n + block) // block + 1) * block            # create_keyval_buffers
+    rng = np.random.default_rng(seed)
+    # depth-like float keys with many ties, a few extreme bit patterns, payload = identity (preprocess.wgsl:275)
+    z = np.round(rng.uniform(0.5, 40.0, size=n).astype(np.float32) * np.float32(8.0)) / np.float32(8.0)
+    keys = z.astype(np.float32).view(np.uint32).copy()
+    keys[:6] = [0, 1, 0x7F7FFFFF, 0x80000000, 0xFFFFFFFE, 0x00800000]
+    payload = np.arange(n, dtype=np.uint32)
+    m = W.Module(src)
+    m.robust = True
+    ka = np.zeros(keybuf_elems, dtype=np.uint32)
+    ka[:n] = keys
+    bufs = dict(infos=m.bind("infos", np.array([n, padded, 4, 0, 0], dtype=np.uint32).tobytes()),
+                histograms=m.bind("histograms", bytes((KEYVAL + scatter_blocks - 1 + 1) * RADIX * 4)),
+                keys=m.bind("keys", ka.tobytes()), keys_b=m.bind("keys_b", bytes(keybuf_elems * 4)),
+                payload_a=m.bind("payload_a", payload.tobytes()), payload_b=m.bind("payload_b", bytes(max(n * 4, 1))))
+    m.dispatch_workgroups("zero_histograms", histo_blocks, threads=False)
+    m.dispatch_workgroups("calculate_histogram", histo_blocks)
+    m.dispatch_workgroups("prefix_histogram", 4)
+    for entry in ("scatter_even", "scatter_odd", "scatter_even", "scatter_odd"):
+        m.dispatch_workgroups(entry, scatter_blocks)
+    out_k = np.frombuffer(bufs["keys"], dtype=np.uint32)[:n].copy()
+    out_p = np.frombuffer(bufs["payload_a"], dtype=np.uint32)[:n].copy()
+    return dict(keys_in=keys, payload_in=payload, keys_out=out_k, payload_out=out_p, subgroup=np.uint32(subgroup),
+                padded_size=np.uint32(padded), scatter_blocks=np.uint32(scatter_blocks))
+
+
 import wgsl_cases  # noqa: E402
 
 CASES = {}
@@ -252,6 +306,8 @@ for c in wgsl_cases.K1C_CASES:
     CASES["k1c_" + c] = (lambda c=c: k1c_case(c))
 CASES["k6_fragments"] = k6_fragments
 CASES["frame"] = frame
+CASES["sort_small"] = lambda: sort_case(700, 11)
+CASES["sort_two_blocks"] = lambda: sort_case(5000, 12)
 
 
 def main():
@@ -262,6 +318,7 @@ def main():
         path = os.path.join(HERE, "wgsl_%s.npz" % name)
         np.savez_compressed(path, **res)
         extra = ("V = %d" % int(res["num_visible"]) if "num_visible" in res else "") + \
+                ("%d pairs" % len(res["keys_in"]) if "keys_in" in res else "") + \
                 (" %d fragments" % (int(res["fragments"]) if "fragments" in res else len(res["frag_keep"]))
                  if ("fragments" in res or "frag_keep" in res) else "")
         print("%-16s %s  %.1f s  %d bytes" % (name, extra, time.time() - t0, os.path.getsize(path)))

@@ -151,3 +151,20 @@ def test_frame_equals_the_reference_shaders(ws, ctx, oracle):
     finally:
         r.close()
         pc.close()
+
+
+@pytest.mark.parametrize("case", ["small", "two_blocks"])
+def test_sorters_equal_the_reference_shader(ws, ctx, case):
+    """GPURSSorter (generic path and the depth-sort specialisation, with a companion value) against radix_sort.wgsl
+    executed from source (tests/golden/wgsl_sort_*.npz): identical keys and payload, ties in input order."""
+    z = load("sort_" + case)
+    k, p = z["keys_in"], z["payload_in"]
+    sorter = ws.GPURSSorter(ctx, len(k))
+    try:
+        gk, gp = sorter.sort_host(k, p)
+        assert np.array_equal(gk, z["keys_out"]) and np.array_equal(gp, z["payload_out"])
+        aux = p * np.uint32(7) + np.uint32(3)
+        dk, dp, da = sorter.sort_host(k, p, depth=True, aux=aux)
+        assert np.array_equal(dk, z["keys_out"]) and np.array_equal(dp, z["payload_out"]) and np.array_equal(da, aux[z["payload_out"]])
+    finally:
+        sorter.close()

@@ -254,3 +254,50 @@ def test_oracle_frame_equals_the_reference_shaders(oracle):
     proof = lambda: scenes.BoundaryProof(splats, order, w, h)  # noqa: E731
     ok, msg, mx, mean, nb = scenes.image_close(img, z["image"], max_abs=1e-5, mean_abs=1e-6, proof=proof)
     assert ok, msg
+
+
+# ---- the radix sort ------------------------------------------------------------------------------------------------------
+def test_interpreter_workgroups_barriers_and_loops():
+    m = W.Module("""
+    var<workgroup> sm : array<atomic<u32>, 8>;
+    var<private> pv : array<u32, 2>;
+    @group(0) @binding(0) var<storage, read_write> out : array<u32>;
+    fn bump(k: u32) { for (var i = 0u; i < k; i++) { if i == 1u { continue; } pv[0] += 1u; } }
+    @compute @workgroup_size(8)
+    fn k(@builtin(local_invocation_id) lid: vec3<u32>, @builtin(workgroup_id) wid: vec3<u32>) {
+      pv[1] = wid.x;
+      bump(lid.x);                                   // private memory is per invocation, visible in callees
+      atomicStore(&sm[lid.x], lid.x * 10u);
+      workgroupBarrier();
+      let v = atomicLoad(&sm[(lid.x + 1u) % 8u]);    // the neighbour's store, ordered by the barrier
+      workgroupBarrier();
+      atomicAdd(&sm[0], 1u);
+      workgroupBarrier();
+      var spins = 0u;
+      while true { spins += 1u; if spins > lid.x { break; } }
+      out[wid.x * 8u + lid.x] = v + pv[1] * 1000u + atomicLoad(&sm[0]) + 100000u * pv[0] + 1000000u * spins;
+      out[100u] = 7u;                                // out of bounds: dropped (robust buffer access)
+    }""")
+    m.robust = True
+    buf = m.bind("out", bytes(64))
+    m.dispatch_workgroups("k", 2)
+    got = np.frombuffer(buf, dtype=np.uint32)
+    want = [(((l + 1) % 8) * 10) + w * 1000 + 8 + 100000 * (l - (1 if l >= 2 else 0)) + 1000000 * (l + 1)
+            for w in range(2) for l in range(8)]
+    assert list(got) == want
+
+
+@pytest.mark.parametrize("case", ["small", "two_blocks"])
+def test_oracle_sort_equals_the_reference_shader(oracle, case):
+    """radix_sort.wgsl executed from source, driven as GPURSSorter::record_sort drives it (zero_histograms,
+    calculate_histogram, prefix_histogram, scatter_even / odd x 2; one and two scatter blocks, the second with the
+    decoupled look-back over the partition words): keys with many ties and extreme bit patterns come out ascending as
+    unsigned 32-bit values and STABLE (equal keys keep their payload order) -- what wso_sort_pairs, numpy's stable
+    argsort and the library's sorters produce."""
+    z = load("sort_" + case)
+    k, p = z["keys_in"], z["payload_in"]
+    assert len(np.unique(k)) < len(k) // 2                        # ties: stability is observable
+    ok, op = oracle.sort_pairs(k, p)
+    assert np.array_equal(ok, z["keys_out"]) and np.array_equal(op, z["payload_out"])
+    order = np.argsort(k, kind="stable")
+    assert np.array_equal(k[order], z["keys_out"]) and np.array_equal(p[order], z["payload_out"])
