@@ -574,18 +574,6 @@ class Parser:
             raise SyntaxError("unexpected %r in statement" % op)
         return ("assign", op, lhs, self.expr())
 
-    def _unused_statement_tail(self):
-        lhs = self.expr()
-        if self.at(";"):
-            self.eat(";")
-            return ("expr", lhs)
-        op = self.eat()
-        if op not in ("=", "+=", "-=", "*=", "/=", "%=", "&=", "|=", "^="):
-            raise SyntaxError("unexpected %r in statement" % op)
-        rhs = self.expr()
-        self.eat(";")
-        return ("assign", op, lhs, rhs)
-
     # -- expressions
     def _left(self, sub, ops):
         e = sub()
