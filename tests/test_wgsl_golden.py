@@ -301,3 +301,19 @@ def test_oracle_sort_equals_the_reference_shader(oracle, case):
     assert np.array_equal(ok, z["keys_out"]) and np.array_equal(op, z["payload_out"])
     order = np.argsort(k, kind="stable")
     assert np.array_equal(k[order], z["keys_out"]) and np.array_equal(p[order], z["payload_out"])
+
+
+# ---- the committed fixtures are what the generator produces ------------------------------------------------------------
+@pytest.mark.skipif(not os.path.isdir(os.environ.get("WEBSPLAT_REFERENCE", "/root/reference")),
+                    reason="the reference checkout is only in the build container (never on the GPU box)")
+@pytest.mark.parametrize("case", ["k1_clip_box", "k1c_deg0", "k6_fragments"])
+def test_fixtures_are_reproducible_from_the_reference_source(case):
+    """Where the reference checkout exists, re-running the generator on its shader text gives the committed vectors byte
+    for byte (three of the cheap cases; the whole set takes four minutes: tests/golden/gen_wgsl_golden.py)."""
+    sys.path.insert(0, GOLDEN)
+    import gen_wgsl_golden as gen
+    fresh = gen.CASES[case]()
+    z = np.load(os.path.join(GOLDEN, "wgsl_%s.npz" % case))
+    assert sorted(fresh.keys()) == sorted(z.files)
+    for k in z.files:
+        assert np.array_equal(np.asarray(fresh[k]), z[k]), k
