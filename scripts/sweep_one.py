@@ -9,6 +9,20 @@ from websplat import synth
 n, w, h = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 streams = [int(x) for x in sys.argv[4:]] or [4, 1]
 ctx = ws.Context(0)
+if os.environ.get("PREHISTORY"):   # what precedes a cell inside scripts/sweep.py: bigger renderers created, used and destroyed
+    for (pn, pw, ph) in ((250_000, 3840, 2160), (250_000, 1920, 1080)):
+        g0 = ws.GenericGaussianPointCloud.from_ply_rows(synth.scene_c2(n=pn, seed=1), 3)
+        p0 = ws.PointCloud(ctx, g0)
+        cj = synth.orbit_cameras(1, pw, ph, float(pw), float(pw))[0]
+        cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, pw, ph)
+        cam.fit_near_far(g0.aabb)
+        a0 = ws.SplattingArgs(camera=cam, viewport=(pw, ph), max_sh_deg=3)
+        r0 = [ws.GaussianRenderer(ctx, "rgba32float", 3, False) for _ in range(4)]
+        for r in r0:
+            r.prepare(p0, a0); r.render(p0)
+        ctx.sync()
+        for r in r0: r.close()
+        p0.close()
 gpc = ws.GenericGaussianPointCloud.from_ply_rows(synth.scene_c2(n=n, seed=1), 3)
 pc = ws.PointCloud(ctx, gpc)
 f = 1200.0 * w / 1200.0
