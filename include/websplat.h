@@ -329,6 +329,12 @@ int ws_context_tile_size(const ws_context* ctx, uint32_t* width, uint32_t* heigh
  * exp2 domain) and the mask of 8x8-pixel quadrants (bit qy * (tile_w / 8) + qx) the kept ellipse may reach. */
 int ws_debug_stage_splat(const uint32_t splat[5], float viewport_w, float viewport_h, float tile_x0, float tile_y0,
                          uint32_t tile_w, uint32_t tile_h, float rec[10], uint32_t* quadrant_mask);
+/* test hook, host only: the binning footprint of ONE splat (words 0..2 of its 20-B record: v1, v2, pos) -- the ids
+ * (ty * ceil(viewport_w / tile_w) + tx) of the binning tiles its kept ellipse a <= 2*CUTOFF (gaussian.wgsl:40-64) can
+ * reach, in the order the binning stage emits them; *count = their number (what K1 stores per splat), of which at most
+ * `capacity` are written.  tile_w / tile_h: 16 or 32. */
+int ws_debug_footprint(const uint32_t splat[3], float viewport_w, float viewport_h, uint32_t tile_w, uint32_t tile_h,
+                       uint32_t capacity, uint32_t* tiles, uint32_t* count);
 /* tuning / analysis read-back: per tile, the length of its depth-ordered splat list and (capture mode)
  * how many of its entries the compositing pass walked before every pixel was saturated.  Syncs. */
 int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t* list_len, uint32_t* consumed,

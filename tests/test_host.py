@@ -183,3 +183,76 @@ def test_quadrant_mask_never_drops_a_covered_pixel(ws, tile):
         flagged += bin(mask).count("1")
     assert needed > 2000
     assert flagged <= needed * 1.02 + 10
+
+
+# ---- the binning footprint (footprint.h), host twin through the ABI ---------------------------------------------
+def _kept_tiles_brute_force(words, viewport, tile):
+    """Tiles holding at least one pixel centre the blend's per-pixel test keeps: the staging step's tile-local affine
+    form (blend_stage.h decode) evaluated in f32 for every pixel of the viewport, with the relative 1e-5 allowance for
+    fma-vs-separate rounding the quadrant-mask test uses."""
+    f = np.float32
+    W, H = f(viewport[0]), f(viewport[1])
+    h = np.asarray(words[:3], dtype=np.uint32).view(np.float16).astype(np.float32)
+    m00, m01 = h[0] * W, h[2] * W
+    m10, m11 = -h[1] * H, -h[3] * H
+    det = f(m00 * m11) - f(m01 * m10)
+    if not np.isfinite(det) or det == 0:
+        return None
+    with np.errstate(all="ignore"):
+        inv = f(1.2011224087864498) / det
+        i00, i01, i10, i11 = m11 * inv, -m01 * inv, -m10 * inv, m00 * inv
+        if not np.all(np.isfinite([i00, i01, i10, i11])):
+            return None
+        tw, th = tile
+        ntx = -(-int(viewport[0]) // tw)
+        ys, xs = np.mgrid[0:int(viewport[1]), 0:int(viewport[0])]
+        ox, oy = (xs // tw * tw).astype(np.float32), (ys // th * th).astype(np.float32)
+        cxl = (h[4] * f(0.5) + f(0.5)) * W - ox
+        cyl = (f(0.5) - h[5] * f(0.5)) * H - oy
+        c0 = -(i00 * cxl + i01 * cyl)
+        c1 = -(i10 * cxl + i11 * cyl)
+        lx, ly = (xs - ox + f(0.5)).astype(np.float32), (ys - oy + f(0.5)).astype(np.float32)
+        p0 = i00 * lx + (i01 * ly + c0)
+        p1 = i10 * lx + (i11 * ly + c1)
+        a = p0 * p0 + p1 * p1
+    cut = f(2 * 2.3539888583335364 * 1.4426950408889634)
+    kept = a <= cut * f(1.00001)
+    return set(np.unique((ys // th * ntx + xs // tw)[kept]).tolist())
+
+
+@pytest.mark.parametrize("tile", [(32, 32), (32, 16), (16, 16)])
+def test_footprint_never_drops_a_touched_tile(ws, tile):
+    """Binning by the kept ellipse (footprint.h): the tile list of a splat must contain every tile in which the blend's
+    per-pixel test keeps a pixel centre, each tile once, in row-major order; and it must stay tight -- the point of the
+    exercise is NOT to list the bounding rectangle."""
+    rng = np.random.default_rng(11)
+    viewport = (416, 304)   # 13 x 9.5 tiles of 32: a ragged last row
+    ntx = -(-viewport[0] // tile[0])
+    needed = listed = rect = 0
+    trials = 0
+    for trial in range(2500):
+        origin = (float(rng.integers(0, viewport[0])), float(rng.integers(0, viewport[1])))
+        words = _random_splat_words(rng, tuple(float(v) for v in viewport), origin, (1, 1))
+        if trial % 7 == 0:   # long thin needles through the viewport: the case a bounding rectangle is worst at
+            hv = words.view(np.float16).copy()
+            s1, s2, th_ = rng.uniform(100, 400), rng.uniform(0.4, 3.0), rng.uniform(0, 2 * np.pi)
+            c, s = np.cos(th_), np.sin(th_)
+            hv[0:4] = np.array([c * s1 / viewport[0], -s * s1 / viewport[1], -s * s2 / viewport[0], -c * s2 / viewport[1]],
+                               dtype=np.float16)
+            words = hv.view(np.uint32)
+        truth = _kept_tiles_brute_force(words, viewport, tile)
+        if truth is None:
+            continue
+        tiles = ws.footprint_tiles(words, viewport, tile)
+        assert len(set(tiles.tolist())) == len(tiles), (trial, tiles)            # each tile once
+        assert np.all(np.diff(tiles.astype(np.int64)) > 0), (trial, tiles)       # rows top to bottom, columns left to right
+        assert truth <= set(tiles.tolist()), (trial, sorted(truth - set(tiles.tolist())), words)
+        trials += 1
+        needed += len(truth)
+        listed += len(tiles)
+        if len(tiles):
+            tx, ty = tiles % ntx, tiles // ntx
+            rect += int((tx.max() - tx.min() + 1) * (ty.max() - ty.min() + 1))
+    assert trials > 2000 and needed > 10000
+    assert listed <= needed * 1.03 + 20, (listed, needed)    # tight: within 3 % of the tiles that hold a kept pixel
+    assert rect >= listed * 1.1                               # ... and visibly fewer than the bounding rectangles

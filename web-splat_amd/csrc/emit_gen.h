@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "footprint.h"
 #include "ws_internal.h"
 
 namespace ws {
@@ -24,12 +25,27 @@ __device__ __forceinline__ uint32_t pad(uint32_t i) { return i + i / EPT; }  // 
 
 struct Source {
     const uint32_t* sorted_idx;   // [V] store indices in draw order
-    const uint32_t* rects_sorted; // [V] packed tile rectangle (rect_pack) by draw position
+    const uint8_t* splats;        // [V] x 20 B Splat records, by store index
     const uint32_t* offsets;      // [V] exclusive prefix of tiles touched, by draw position
     const uint32_t* emit_start;   // draw position owning entry m * EMIT_TILE
     const FrameCounters* counters;
     uint32_t tiles_x;
+    float vw, vh;                 // viewport in pixels (the f32 values K1 used)
+    uint32_t tile_w_log2, tile_h_log2;
 };
+
+// words 0..2 of a Splat record (v1, v2, pos: the geometry; pointcloud.rs:352-358)
+struct Geom {
+    uint32_t w0, w1, w2;
+};
+__device__ __forceinline__ Geom load_geom(const Source& src, uint32_t store_idx) {
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(src.splats + (size_t)store_idx * 20);
+    Geom g;
+    g.w0 = sp[0];
+    g.w1 = sp[1];
+    g.w2 = sp[2];
+    return g;
+}
 
 struct Slice {
     uint32_t e0, ne;        // first entry, number of entries
@@ -94,17 +110,10 @@ __device__ __forceinline__ Slice slice_setup(const Source& src, uint32_t slice, 
     return sl;
 }
 
-// Tile id of the k-th tile (row-major inside the rectangle) of the packed rectangle r.
-__device__ __forceinline__ uint32_t tile_of(uint32_t r, uint32_t k, uint32_t tiles_x) {
-    const uint32_t x0 = r & 0xFFu, y0 = (r >> 8) & 0xFFu;  // x0 | y0 << 8 | (w - 1) << 16 | (h - 1) << 24
-    const uint32_t w = ((r >> 16) & 0xFFu) + 1u;
-    // k / w without the integer-division sequence: k < 2^16 (a rectangle has at most 256 x 256 tiles), far inside the
-    // range where the float path with one correction step is exact
-    uint32_t q = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
-    uint32_t rem = k - q * w;
-    if ((int32_t)rem < 0) { q -= 1u; rem += w; }
-    if (rem >= w) { q += 1u; rem -= w; }
-    return (y0 + q) * tiles_x + (x0 + rem);
+// Tile id of the k-th tile of the splat's footprint (footprint.h): the same function of the same 12 bytes K1 counted.
+__device__ __forceinline__ uint32_t tile_of(const Source& src, const Geom& g, uint32_t k) {
+    const fp::Tiles ft = fp::setup(g.w0, g.w1, g.w2, src.vw, src.vh, src.tile_w_log2, src.tile_h_log2);
+    return fp::tile_at(ft, k, src.tiles_x, src.tile_w_log2, src.tile_h_log2);
 }
 
 // Entry el (0 <= el < sl.ne) of the slice: tile id and splat (store index).
@@ -125,8 +134,8 @@ __device__ __forceinline__ void entry(const Source& src, const Slice& sl, const 
         }
     }
     const uint32_t pos = sl.s_lo + lo;
-    *key = tile_of(src.rects_sorted[pos], e - (sl.in_lds ? s_off[lo] : sl.goff[lo]), src.tiles_x);
     *val = src.sorted_idx[pos];
+    *key = tile_of(src, load_geom(src, *val), e - (sl.in_lds ? s_off[lo] : sl.goff[lo]));
 }
 
 }  // namespace emit

@@ -12,14 +12,15 @@
 //     needed because the word is its own payload.  The reference's atomicAdd(keys_size) order is
 //     nondeterministic (preprocess.wgsl:262); ordered compaction makes equal-depth ties, and hence the
 //     image, reproducible across runs and ranks.
-//   * Besides the reference's outputs (Splat 20 B, depth key) the kernel emits the splat's binning-tile
-//     rectangle (8 B) for the binning stage that replaces the hardware rasteriser.
+//   * Besides the reference's outputs (Splat 20 B, depth key) the kernel emits the number of binning tiles the
+//     splat's kept ellipse reaches (4 B, footprint.h) for the binning stage that replaces the hardware rasteriser.
 //
 // This file is compiled with -ffp-contract=off: f32 operations happen in source order, which is the
 // WGSL expression order, so results can be compared with the CPU restatement at the f16-ulp level.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include "footprint.h"
 #include "lookback.h"
 #include "ws_internal.h"
 
@@ -132,7 +133,7 @@ __device__ __forceinline__ void eval_sh3(const Sh16& sh, float x, float y, float
 struct SplatOut {
     uint32_t w[5];  // Splat: v(4 x f16) pos(2 x f16) color(4 x f16)
     uint32_t key;
-    uint32_t rect;  // rect_pack(), RECT_EMPTY = touches no tile
+    uint32_t tiles; // binning tiles the kept ellipse reaches (footprint.h), 0 = none
 };
 
 #define VM(c, r) (p.cam.view[(c)*4 + (r)])
@@ -304,36 +305,12 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
 
     out->key = k1_depth_key<COMPRESSED>(p, pos2d[2]);
 
-    // tile rectangle of the kept ellipse a <= 2*CUTOFF (gaussian.wgsl:40-64), derived from the
-    // f16-ROUNDED splat so that binning and blending agree on coverage.
+    // binning-tile footprint of the kept ellipse a <= 2*CUTOFF (gaussian.wgsl:40-64): the NUMBER of tiles it reaches,
+    // derived from the f16-ROUNDED splat so that binning and blending agree on coverage (footprint.h; k_bin_emit
+    // re-derives the tiles themselves from the same 12 bytes).
     {
-        const float q1x = h2f(h0), q1y = h2f(h1), q2x = h2f(h2), q2y = h2f(h3);
-        const float m00 = q1x * vw, m01 = q2x * vw;
-        const float m10 = -q1y * vh, m11 = -q2y * vh;
-        const float det = m00 * m11 - m01 * m10;
-        const float cx = (h2f(h4) * 0.5f + 0.5f) * vw;
-        const float cy = (0.5f - h2f(h5) * 0.5f) * vh;
-        const float rad = 2.1697873f * 1.00001f;  // sqrt(2*CUTOFF), padded
-        const float exx = rad * qsqrt(m00 * m00 + m01 * m01) + 1e-3f;
-        const float eyy = rad * qsqrt(m10 * m10 + m11 * m11) + 1e-3f;
-        uint32_t rect = RECT_EMPTY;
-        const bool ok = (fabsf(det) > 0.0f) && (fabsf(det) < 3.0e38f) && (fabsf(cx) < 1.0e9f) && (fabsf(cy) < 1.0e9f) &&
-                        (exx < 1.0e9f) && (eyy < 1.0e9f);
-        if (ok) {
-            // pixel (x, y) has its centre at (x + 0.5, y + 0.5)
-            float x_lo = ceilf(cx - exx - 0.5f), x_hi = floorf(cx + exx - 0.5f);
-            float y_lo = ceilf(cy - eyy - 0.5f), y_hi = floorf(cy + eyy - 0.5f);
-            x_lo = fmaxf(x_lo, 0.0f);
-            y_lo = fmaxf(y_lo, 0.0f);
-            x_hi = fminf(x_hi, vw - 1.0f);
-            y_hi = fminf(y_hi, vh - 1.0f);
-            if (x_lo <= x_hi && y_lo <= y_hi) {
-                const uint32_t tx0 = (uint32_t)x_lo >> p.tile_w_log2, tx1 = (uint32_t)x_hi >> p.tile_w_log2;
-                const uint32_t ty0 = (uint32_t)y_lo >> p.tile_h_log2, ty1 = (uint32_t)y_hi >> p.tile_h_log2;
-                rect = rect_pack(tx0, ty0, tx1, ty1);  // < 256 tiles per axis (ws_renderer_prepare checks the viewport)
-            }
-        }
-        out->rect = rect;
+        const fp::Tiles ft = fp::setup(out->w[0], out->w[1], out->w[2], vw, vh, p.tile_w_log2, p.tile_h_log2);
+        out->tiles = fp::count(ft, p.tile_w_log2, p.tile_h_log2);
     }
 }
 
@@ -591,7 +568,7 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
     for (int it = 0; it < K1_ITEMS; ++it) {
         so[it].w[0] = so[it].w[1] = so[it].w[2] = so[it].w[3] = so[it].w[4] = 0u;
         so[it].key = 0u;
-        so[it].rect = RECT_EMPTY;
+        so[it].tiles = 0u;
     }
     if (!COMPRESSED) {
         const uint32_t safe_idx = block_base < n ? block_base : 0u;  // culled lanes re-read this (cached) record
@@ -670,7 +647,7 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
             sp[3] = so[it].w[3];
             sp[4] = so[it].w[4];
             b.keys[slot] = so[it].key;
-            b.rects[slot] = so[it].rect;
+            b.tile_counts[slot] = so[it].tiles;
             if (b.src_index) b.src_index[slot] = block_base + it * K1_THREADS + tid;
         }
     }

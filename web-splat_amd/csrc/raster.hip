@@ -62,14 +62,14 @@ __device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t
 }
 
 // ---- k_bin_prefix ------------------------------------------------------------------------------------
-// Draw position i (far -> near) -> offsets[i] = sum of tiles touched by positions < i.  The packed tile rectangles
-// arrive IN DRAW ORDER: they ride through the depth sort with the splat index (sort.hip), so this kernel streams
-// (it used to gather rects[sorted_idx[i]] at random: every XCD's L2 pulled the whole array, 3.2 x the algorithmic
-// traffic on the 1 M scene and 122 of this kernel's 137 us on 5 M splats).
+// Draw position i (far -> near) -> offsets[i] = sum of tiles touched by positions < i.  The footprint tile counts
+// (footprint.h) arrive IN DRAW ORDER: they ride through the depth sort with the splat index (sort.hip), so this kernel
+// streams (round 1 gathered per-splat data by sorted index at random: every XCD's L2 pulled the whole array, 3.2 x the
+// algorithmic traffic on the 1 M scene and 122 of this kernel's 137 us on 5 M splats).
 // Also records, for every multiple m*EMIT_TILE of the entry index, the draw position whose entry range
 // contains it (emit_start[m]): the emit kernel then needs no global search to find where its slice starts.
 template <int BIN_IPT>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __restrict__ rects_sorted,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __restrict__ counts_sorted,
                                                            uint32_t* __restrict__ offsets,
                                                            uint32_t* __restrict__ emit_start,
                                                            uint64_t* __restrict__ status,
@@ -108,12 +108,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
 #pragma unroll
     for (int k = 0; k < BIN_IPT; ++k) {
         const uint32_t i = base + k * BIN_THREADS + tid;
-        r[k] = rects_sorted[i < v ? i : v - 1u];
+        r[k] = counts_sorted[i < v ? i : v - 1u];
     }
 #pragma unroll
     for (int k = 0; k < BIN_IPT; ++k) {
         const uint32_t i = base + k * BIN_THREADS + tid;
-        cnt[k] = i < v ? rect_tiles(r[k]) : 0u;
+        cnt[k] = i < v ? r[k] : 0u;
         s_cnt[pad(k * BIN_THREADS + tid)] = cnt[k];
     }
     __syncthreads();
@@ -189,27 +189,26 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
         for (int k = tid; k < RADIX * EMIT_COPIES; k += BIN_THREADS) s_hist[k] = 0u;
         const emit::Slice sl = emit::slice_setup(src, slice, d, v, s_off, s_own, s_wmax);
         if (sl.in_lds) {  // (block-uniform) the usual case
-            // All EPT entries of a thread at once: owners from LDS, then their rectangle and index gathers in flight
-            // together.  (Entry by entry, each one waited for its two dependent loads before the next one's were issued:
-            // 16 serial round trips per thread -- the whole duration of this kernel.)
-            uint32_t lo[emit::EPT], rect[emit::EPT], val[emit::EPT];
+            // All EPT entries of a thread at once: owners from LDS, then their index gathers in flight together, then the
+            // geometry words of their Splat records.  (Entry by entry, each one waited for its dependent loads before
+            // the next one's were issued: 16 serial round trips per thread -- the whole duration of this kernel.)
+            uint32_t lo[emit::EPT], val[emit::EPT];
+            emit::Geom geom[emit::EPT];
 #pragma unroll
             for (int j = 0; j < emit::EPT; ++j) {
                 const uint32_t el = (uint32_t)tid + (uint32_t)j * BIN_THREADS;
                 lo[j] = el < sl.ne ? s_own[emit::pad(el)] : 0u;
             }
 #pragma unroll
-            for (int j = 0; j < emit::EPT; ++j) {
-                const uint32_t pos = sl.s_lo + lo[j];
-                rect[j] = src.rects_sorted[pos];
-                val[j] = src.sorted_idx[pos];
-            }
+            for (int j = 0; j < emit::EPT; ++j) val[j] = src.sorted_idx[sl.s_lo + lo[j]];
+#pragma unroll
+            for (int j = 0; j < emit::EPT; ++j) geom[j] = emit::load_geom(src, val[j]);
 #pragma unroll
             for (int j = 0; j < emit::EPT; ++j) {
                 const uint32_t el = (uint32_t)tid + (uint32_t)j * BIN_THREADS;
                 if (el < sl.ne) {
                     const uint32_t e = sl.e0 + el;
-                    const uint32_t key = emit::tile_of(rect[j], e - s_off[lo[j]], src.tiles_x);
+                    const uint32_t key = emit::tile_of(src, geom[j], e - s_off[lo[j]]);
                     if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
                     else entry_keys[e] = key;
                     entry_vals[e] = val[j];
@@ -866,7 +865,7 @@ uint32_t bin_prefix_blocks(uint32_t max_points) {
 int launch_bin_prefix(const BinBuffers& b, hipStream_t stream) {
     const uint32_t blocks = bin_prefix_blocks(b.max_points);
     if (blocks == 0) return WS_OK;
-    hipLaunchKernelGGL(k_bin_prefix<BIN_IPT>, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.rects_sorted, b.offsets,
+    hipLaunchKernelGGL(k_bin_prefix<BIN_IPT>, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.counts_sorted, b.offsets,
                        b.emit_start, b.block_status, b.counters, b.entry_cap);
     WS_HIP(hipGetLastError());
     return WS_OK;
@@ -878,11 +877,15 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     if (blocks > 2048u) blocks = 2048u;  // slices are strided over; surplus workgroups are not free
     emit::Source src;
     src.sorted_idx = b.sorted_idx;
-    src.rects_sorted = b.rects_sorted;
+    src.splats = b.splats;
     src.offsets = b.offsets;
     src.emit_start = b.emit_start;
     src.counters = b.counters;
     src.tiles_x = b.tiles_x;
+    src.vw = b.vw;
+    src.vh = b.vh;
+    src.tile_w_log2 = b.tile_w_log2;
+    src.tile_h_log2 = b.tile_h_log2;
     hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, src, b.entry_keys, b.entry_vals, b.tile_hist,
                        b.tile_hist_pitch, b.tile_hist_mask, b.key16);
     WS_HIP(hipGetLastError());
@@ -962,6 +965,17 @@ int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, floa
     const float v[10] = {s.i00, s.i01, s.c0, s.i10, s.i11, s.c1, s.alpha, s.r, s.g, s.b};
     for (int i = 0; i < 10; ++i) rec[i] = v[i];
     *mask = s.mask;
+    return WS_OK;
+}
+
+// host-side twin of the binning footprint (footprint.h; CPU unit test, not on any render path): the tile ids the kept
+// ellipse of the splat reaches, in emission order
+int debug_footprint(const uint32_t w[3], float vw, float vh, uint32_t tile_w_log2, uint32_t tile_h_log2, uint32_t tiles_x,
+                    uint32_t capacity, uint32_t* tiles, uint32_t* count) {
+    const fp::Tiles ft = fp::setup(w[0], w[1], w[2], vw, vh, tile_w_log2, tile_h_log2);
+    const uint32_t n = fp::count(ft, tile_w_log2, tile_h_log2);
+    *count = n;
+    for (uint32_t k = 0; k < n && k < capacity; ++k) tiles[k] = fp::tile_at(ft, k, tiles_x, tile_w_log2, tile_h_log2);
     return WS_OK;
 }
 

@@ -114,7 +114,7 @@ struct ws_renderer {
     uint32_t vw = 0, vh = 0, tiles_x = 0, tiles_y = 0;
     uint64_t entry_cap_request = 0;
     uint32_t entry_cap = 0;
-    uint32_t *rects_a = nullptr, *rects_b = nullptr;  // packed tile rectangles: store order / ping-pong of the depth sort
+    uint32_t *tcount_a = nullptr, *tcount_b = nullptr;  // footprint tile counts (footprint.h): store order / ping-pong of the depth sort
     uint8_t* splats = nullptr;      // Splat[N], 20 B each (pointcloud.rs:103-108 allocates it in PointCloud;
                                     // here it is per renderer so that renderers never share scratch)
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
@@ -130,7 +130,7 @@ struct ws_renderer {
     FrameCounters* counters = nullptr;  // = &zero->counters
     SortScratch sort_depth, sort_tiles;
     DepthSortScratch dsort;          // range-adaptive three-pass depth sort (the default; WS_DEPTH_SORT=classic: sort_depth)
-    uint32_t* rects_sorted = nullptr;  // where the last frame's draw-ordered rectangles are
+    uint32_t* counts_sorted = nullptr;  // where the last frame's draw-ordered footprint tile counts are
     uint32_t epoch = 0;
     uint32_t* sticky = nullptr;      // device error word that survives the per-frame memset (ws_renderer_errors)
 
@@ -150,7 +150,7 @@ struct ws_renderer {
         uint64_t generation = 0;   // scratch generation the graph was captured for
         uint32_t next = 0;
         bool valid = false;
-        uint32_t *sorted_idx = nullptr, *sorted_keys = nullptr, *rects_sorted = nullptr, *entries_sorted = nullptr;
+        uint32_t *sorted_idx = nullptr, *sorted_keys = nullptr, *counts_sorted = nullptr, *entries_sorted = nullptr;
     } fg;
     uint64_t scratch_generation = 0;
 
@@ -220,8 +220,8 @@ static void renderer_free_scratch(ws_renderer* r) {
     dfree(r->keys_b);
     dfree(r->vals_a);
     dfree(r->vals_b);
-    dfree(r->rects_a);
-    dfree(r->rects_b);
+    dfree(r->tcount_a);
+    dfree(r->tcount_b);
     dfree(r->dsort.tile_off);
     dfree(r->dsort.group_off);
     dfree(r->dsort.status);
@@ -271,8 +271,8 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     if ((rc = dmalloc(&r->keys_b, np))) return rc;
     if ((rc = dmalloc(&r->vals_a, np))) return rc;
     if ((rc = dmalloc(&r->vals_b, np))) return rc;
-    if ((rc = dmalloc(&r->rects_a, np))) return rc;
-    if ((rc = dmalloc(&r->rects_b, np))) return rc;
+    if ((rc = dmalloc(&r->tcount_a, np))) return rc;
+    if ((rc = dmalloc(&r->tcount_b, np))) return rc;
     if ((rc = dmalloc(&r->src_index, np))) return rc;
     if ((rc = dmalloc(&r->bin_offsets, np))) return rc;
     const size_t k1_words = (size_t)preprocess_blocks(n) + 1, bin_words = (size_t)bin_prefix_blocks(n) + 1;
@@ -321,7 +321,7 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
         WS_HIP(hipMemset(ds.status, 0, gw * sizeof(uint64_t)));
         ds.keys_alt = r->keys_b;
         ds.vals_alt = r->vals_b;
-        ds.aux_alt = r->rects_b;
+        ds.aux_alt = r->tcount_b;
         ds.key_range = r->zero->key_range;
         ds.tickets = r->counters->sort_ticket;  // [0..2]; the tile sort uses [4..7]
         ds.error = &r->counters->overflow;
@@ -394,6 +394,16 @@ int ws_debug_stage_splat(const uint32_t splat[5], float viewport_w, float viewpo
     if (!splat || !rec || !quadrant_mask) return fail(WS_ERR_INVALID, "ws_debug_stage_splat: null argument");
     return debug_stage_splat(splat, viewport_w, viewport_h, tile_x0, tile_y0, tile_w / QUAD, tile_h / QUAD, rec,
                              quadrant_mask);
+}
+
+int ws_debug_footprint(const uint32_t splat[3], float viewport_w, float viewport_h, uint32_t tile_w, uint32_t tile_h,
+                       uint32_t capacity, uint32_t* tiles, uint32_t* count) {
+    if (!splat || !count || (capacity && !tiles)) return fail(WS_ERR_INVALID, "ws_debug_footprint: null argument");
+    if ((tile_w != 16 && tile_w != 32) || (tile_h != 16 && tile_h != 32) || !(viewport_w >= 1.0f) || !(viewport_h >= 1.0f))
+        return fail(WS_ERR_INVALID, "ws_debug_footprint: tile size must be 16 or 32 per axis, the viewport at least one pixel");
+    const uint32_t twl = tile_w == 32 ? 5u : 4u, thl = tile_h == 32 ? 5u : 4u;
+    const uint32_t tiles_x = ((uint32_t)viewport_w + tile_w - 1) / tile_w;
+    return debug_footprint(splat, viewport_w, viewport_h, twl, thl, tiles_x, capacity, tiles, count);
 }
 
 int ws_sync(ws_context* ctx, void* stream) {
@@ -749,32 +759,32 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
         r->last_stream = stream;
         return WS_OK;
     }
-    // depth sort: V (key, store index) pairs, values start as iota (preprocess.wgsl:274), the packed tile rectangle
-    // rides along as a companion value.  Default: the generic 4 x 8-bit sorter (GPURSSorter's shape);
+    // depth sort: V (key, store index) pairs, values start as iota (preprocess.wgsl:274), the splat's footprint tile
+    // count rides along as a companion value.  Default: the generic 4 x 8-bit sorter (GPURSSorter's shape);
     // WS_DEPTH_SORT=adaptive: three range-adaptive digit passes (launch_depth_sort; measured: no faster).
     if (!r->ctx->depth_sort_adaptive) {
-        const bool carry = r->ctx->sort_algo != 1;  // (the one-sweep cross-check path gathers the rectangles afterwards)
+        const bool carry = r->ctx->sort_algo != 1;  // (the one-sweep cross-check path gathers the counts afterwards)
         uint32_t *sk = nullptr, *sv = nullptr;
         if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
                                     true, false, r->ctx->sort_algo, r->epoch, stream, &sk, &sv, km, "depth:", nullptr, 0,
-                                    RADIX_BITS, false, carry ? r->rects_a : nullptr, carry ? r->rects_b : nullptr)))
+                                    RADIX_BITS, false, carry ? r->tcount_a : nullptr, carry ? r->tcount_b : nullptr)))
             return rc;
         r->sorted_idx = sv;
         r->sorted_keys = sk;
         if (carry) {
-            r->rects_sorted = (sv == r->vals_a) ? r->rects_a : r->rects_b;  // where the payload went
+            r->counts_sorted = (sv == r->vals_a) ? r->tcount_a : r->tcount_b;  // where the payload went
         } else {
-            if ((rc = launch_gather_u32(r->rects_a, sv, &r->counters->num_visible, pc->num_points, r->rects_b, stream))) return rc;
-            km_mark(km, "k_gather_rects");
-            r->rects_sorted = r->rects_b;
+            if ((rc = launch_gather_u32(r->tcount_a, sv, &r->counters->num_visible, pc->num_points, r->tcount_b, stream))) return rc;
+            km_mark(km, "k_gather_counts");
+            r->counts_sorted = r->tcount_b;
         }
     } else {
-        if ((rc = launch_depth_sort(r->dsort, r->keys_a, r->vals_a, r->rects_a, &r->counters->num_visible, pc->num_points,
+        if ((rc = launch_depth_sort(r->dsort, r->keys_a, r->vals_a, r->tcount_a, &r->counters->num_visible, pc->num_points,
                                     true, r->epoch, stream, km)))
             return rc;
         r->sorted_idx = r->vals_b;    // three passes: A -> B -> A -> B
         r->sorted_keys = r->keys_b;
-        r->rects_sorted = r->rects_b;
+        r->counts_sorted = r->tcount_b;
     }
     if (r->timers) WS_HIP(hipEventRecord(r->ev[2], stream));
     if (cut == 2) {  // analysis only (WS_DEBUG_CUT): the image is NOT produced
@@ -787,7 +797,12 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     // tile binning
     BinBuffers bb;
     bb.sorted_idx = r->sorted_idx;
-    bb.rects_sorted = r->rects_sorted;
+    bb.counts_sorted = r->counts_sorted;
+    bb.splats = r->splats;
+    bb.vw = kp.cam.viewport[0];
+    bb.vh = kp.cam.viewport[1];
+    bb.tile_w_log2 = kp.tile_w_log2;
+    bb.tile_h_log2 = kp.tile_h_log2;
     bb.offsets = r->bin_offsets;
     bb.emit_start = r->emit_start;
     bb.block_status = r->bin_status;
@@ -850,12 +865,14 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     if (!r || !pc || !args) return fail(WS_ERR_INVALID, "ws_renderer_prepare: null argument");
     if (pc->compressed != r->compressed)
         return fail(WS_ERR_INVALID, "ws_renderer_prepare: renderer and point cloud disagree on `compressed`");
-    // a splat's tile rectangle is packed into 4 bytes (ws_internal.h): at most 256 binning tiles per axis = 8192 px with
-    // the default 32-px tile -- the default wgpu max_texture_dimension_2d of the reference's render targets
+    // Tile coordinates are 16-bit (ws_internal.h): 65535 binning tiles per axis, i.e. any target the reference can create
+    // (it asks for the adapter's own max_texture_dimension_2d, src/lib.rs:99-110: 16384 or 32768 on today's adapters).
+    // Pixel coordinates are converted through f32 (exact below 2^24).
     if (args->viewport[0] == 0 || args->viewport[1] == 0 ||
-        args->viewport[0] > RECT_MAX_TILES_PER_AXIS * QUAD * r->ctx->tile_qw ||
-        args->viewport[1] > RECT_MAX_TILES_PER_AXIS * QUAD * r->ctx->tile_qh)
-        return fail(WS_ERR_INVALID, "ws_renderer_prepare: bad viewport (at most 256 binning tiles per axis: 8192 px at 32-px tiles)");
+        (uint64_t)args->viewport[0] > (uint64_t)MAX_TILES_PER_AXIS * QUAD * r->ctx->tile_qw ||
+        (uint64_t)args->viewport[1] > (uint64_t)MAX_TILES_PER_AXIS * QUAD * r->ctx->tile_qh ||
+        args->viewport[0] > (1u << 24) || args->viewport[1] > (1u << 24))
+        return fail(WS_ERR_INVALID, "ws_renderer_prepare: bad viewport (at most 65535 binning tiles per axis)");
     if (args->max_sh_deg > 3) return fail(WS_ERR_UNSUPPORTED, "ws_renderer_prepare: max_sh_deg > 3");
     if (!pc->compressed && args->max_sh_deg > pc->sh_deg) {
         // the 96-B record always holds 16 coefficients (zeros above the file's degree): harmless, as in the reference
@@ -897,7 +914,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     kb.covars = pc->covars;
     kb.splats = r->splats;
     kb.keys = r->keys_a;
-    kb.rects = r->rects_a;
+    kb.tile_counts = r->tcount_a;
     kb.key_range = r->zero->key_range;
     kb.src_index = r->capture ? r->src_index : nullptr;
     kb.block_status = r->k1_status;
@@ -963,7 +980,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         g.generation = r->scratch_generation;
         g.sorted_idx = r->sorted_idx;
         g.sorted_keys = r->sorted_keys;
-        g.rects_sorted = r->rects_sorted;
+        g.counts_sorted = r->counts_sorted;
         g.entries_sorted = r->entries_sorted;
         g.valid = true;
     }
@@ -979,7 +996,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     g.used[slot] = true;
     r->sorted_idx = g.sorted_idx;
     r->sorted_keys = g.sorted_keys;
-    r->rects_sorted = g.rects_sorted;
+    r->counts_sorted = g.counts_sorted;
     r->entries_sorted = g.entries_sorted;
     r->prepared = true;
     r->prepared_pc = pc;

@@ -66,19 +66,13 @@ struct FrameZero {
     // uint2 tile_ranges[tiles] follows
 };
 
-// ---- tile rectangle of a splat, packed into 4 bytes ----------------------------------------------------------
-// x0 | y0 << 8 | (w - 1) << 16 | (h - 1) << 24 in binning tiles, all four < 256: up to 256 x 256 tiles, i.e. 8192 x 8192
-// pixels with the default 32 x 32 binning tile (the default wgpu limit max_texture_dimension_2d of the reference's
-// targets), 4096 x 4096 with 16 x 16.  0xFFFFFFFF (x0 = 255 with w = 256: impossible for a clamped rectangle) = empty.
-// 4 bytes instead of 8 so that the rectangle can ride through the depth sort with the splat index (sort.hip).
-constexpr uint32_t RECT_EMPTY = 0xFFFFFFFFu;
-constexpr uint32_t RECT_MAX_TILES_PER_AXIS = 256u;
-__host__ __device__ inline uint32_t rect_pack(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
-    return x0 | (y0 << 8) | ((x1 - x0) << 16) | ((y1 - y0) << 24);
-}
-__host__ __device__ inline uint32_t rect_tiles(uint32_t r) {
-    return r == RECT_EMPTY ? 0u : (((r >> 16) & 0xFFu) + 1u) * ((r >> 24) + 1u);
-}
+// ---- binning footprint of a splat ----------------------------------------------------------------------------------
+// K1 stores, per visible splat, the NUMBER of binning tiles its kept ellipse reaches (footprint.h; 0 = none).  That
+// word rides through the depth sort with the splat index (sort.hip), so the binning prefix streams the counts in draw
+// order; k_bin_emit re-derives the tiles themselves from the 12 geometry bytes of the Splat record.  (Rounds 1-2 carried
+// the packed bounding rectangle, 8 bits per field: 256 tiles per axis at most and every tile of the rectangle listed.)
+// Tile coordinates are 16-bit (the blend packs tx | ty << 16): up to 65535 tiles per axis.
+constexpr uint32_t MAX_TILES_PER_AXIS = 65535u;
 
 // ---- kernel parameter blocks (passed by value; the analogue of the reference's uniform buffers) ---
 struct K1Params {
@@ -212,7 +206,7 @@ struct K1Buffers {
     const uint8_t* covars;       // compressed: 12-B covariance codebook
     uint8_t* splats;             // [N] x 20 B  (pointcloud.rs:352-358 Splat)
     uint32_t* keys;              // [N] depth keys
-    uint32_t* rects;             // [N] packed tile rectangle (rect_pack), RECT_EMPTY = touches no tile
+    uint32_t* tile_counts;       // [N] binning tiles the splat's kept ellipse reaches (footprint.h), 0 = none
     uint32_t* src_index;         // [N] or nullptr (capture mode)
     uint64_t* block_status;      // [blocks] epoch-tagged look-back words
     FrameCounters* counters;
@@ -227,7 +221,10 @@ constexpr int EMIT_TILE = SORT_TILE;  // tile entries produced per workgroup of 
 
 struct BinBuffers {
     const uint32_t* sorted_idx;  // [V] store indices in draw order (far -> near)
-    const uint32_t* rects_sorted;  // [N] packed tile rectangles by draw position (carried through the depth sort)
+    const uint32_t* counts_sorted; // [N] footprint tile counts by draw position (carried through the depth sort)
+    const uint8_t* splats;       // [V] x 20 B Splat records (k_bin_emit re-derives the footprint from words 0..2)
+    float vw, vh;                // viewport in pixels, as the camera uniform holds it
+    uint32_t tile_w_log2, tile_h_log2;
     uint32_t* offsets;           // [N] exclusive prefix of tiles touched, by draw position
     uint32_t* emit_start;        // [cap / EMIT_TILE + 2] draw position owning entry m * EMIT_TILE
     uint64_t* block_status;      // look-back words of the prefix kernel
@@ -270,6 +267,9 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
 int launch_empty(hipStream_t stream);
 int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, float tile_y0, uint32_t qw, uint32_t qh,
                       float rec[10], uint32_t* mask);
+
+int debug_footprint(const uint32_t w[3], float vw, float vh, uint32_t tile_w_log2, uint32_t tile_h_log2, uint32_t tiles_x,
+                    uint32_t capacity, uint32_t* tiles, uint32_t* count);
 
 // ---- PLY row decode on the GPU (ply_decode.hip) -------------------------------------------------------
 int launch_ply_decode(const float* d_rows, uint32_t n, uint32_t sh_deg, uint4* planes, hipStream_t stream);

@@ -147,6 +147,18 @@ def stage_splat(words, viewport, tile_origin, tile_size=(16, 16)):
     return np.array(rec[:], dtype=np.float32), mask.value
 
 
+def footprint_tiles(words, viewport, tile_size=(32, 32)):
+    """Host-side twin of the binning footprint (test hook): tile ids the splat's kept ellipse reaches, emission order."""
+    w = (C.c_uint32 * 3)(*[int(x) for x in words[:3]])
+    n = C.c_uint32()
+    check(lib.ws_debug_footprint(w, float(viewport[0]), float(viewport[1]), int(tile_size[0]), int(tile_size[1]), 0, None,
+                                 C.byref(n)))
+    out = np.empty(max(n.value, 1), dtype=np.uint32)
+    check(lib.ws_debug_footprint(w, float(viewport[0]), float(viewport[1]), int(tile_size[0]), int(tile_size[1]),
+                                 len(out), out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n)))
+    return out[:n.value]
+
+
 class Context:
     def __init__(self, device: int = 0):
         h = C.c_void_p()
