@@ -1,10 +1,12 @@
 #!/bin/bash
 # Round-3 GPU batch (run through gpurun).  Everything lands in gpurun_out/r03_<TAG>/; copy what should be judged into
-# profiles/r03/.   WHAT=tests,equal,ab,prof  LIBS="lib_base lib"  WORKLOADS="hd1m c3"  TAG=a  STEPS=600
-#   tests  pytest -m gpu on the default library (PYTEST_ARGS narrows it; TEST_LIBS="lib_x ..." repeats it per build)
-#   equal  scripts/dump_images.py per library, images compared bit for bit against the FIRST library of LIBS
-#   ab     per library and workload: per-kernel event times of one frame (scripts/tile_stats.py) + bench.py frames/s
-#   prof   rocprofv3 --kernel-trace --stats of bench.py (one frame in flight) on the LAST library of LIBS
+# profiles/r03/.
+#   VARIANTS="name=libdir[,ENV=VALUE...] ..."   e.g. "base=lib_base rect=lib ellipse=lib,WS_FOOTPRINT=ellipse dma=lib,WS_BLEND_DMA=1"
+#   WHAT=tests,equal,ab,prof  WORKLOADS="hd1m c3"  TAG=a  STEPS=600
+#   tests  pytest -m gpu per variant of TEST_VARIANTS (default: the first of VARIANTS named in it; PYTEST_ARGS narrows it)
+#   equal  scripts/dump_images.py per variant, images compared bit for bit against the FIRST variant
+#   ab     per variant and workload: per-kernel event times of one frame (scripts/tile_stats.py) + bench.py frames/s
+#   prof   rocprofv3 --kernel-trace --stats of bench.py (one frame in flight) for the variants of PROF_VARIANTS
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
@@ -13,36 +15,44 @@ OUT=gpurun_out/r03_$TAG
 mkdir -p $OUT
 STEPS=${STEPS:-600}
 WORKLOADS=${WORKLOADS:-hd1m c3}
-LIBS=${LIBS:-lib_base lib}
+VARIANTS=${VARIANTS:-"base=lib_base new=lib"}
 WHAT=${WHAT:-tests,equal,ab,prof}
-rm -f $OUT/summary.txt
+rm -f $OUT/summary.txt $OUT/ab.txt
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9|Compute Unit" | head -6 > $OUT/device.txt
-libpath() { echo "$PWD/web-splat_amd/$1/libwebsplat_hip.so"; }
+# variant spec -> "env ..." prefix
+venv() {  # $1 = spec "lib[,K=V...]"
+  local spec=$1 lib=${1%%,*} rest=""
+  [[ $spec == *,* ]] && rest=${spec#*,}
+  echo "WEBSPLAT_LIB=$PWD/web-splat_amd/$lib/libwebsplat_hip.so ${rest//,/ }"
+}
+vspec() { for v in $VARIANTS; do [[ ${v%%=*} == $1 ]] && echo ${v#*=}; done; }
 if [[ $WHAT == *tests* ]]; then
-  for L in ${TEST_LIBS:-lib}; do
-    WEBSPLAT_LIB=$(libpath $L) timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -x ${PYTEST_ARGS:-} 2>&1 | tail -40 > $OUT/tests_gpu_$L.log
-    echo "tests $L exit=${PIPESTATUS[0]}" >> $OUT/summary.txt; tail -3 $OUT/tests_gpu_$L.log >> $OUT/summary.txt
+  for N in ${TEST_VARIANTS:-$(echo $VARIANTS | awk '{print $NF}' | cut -d= -f1)}; do
+    env $(venv $(vspec $N)) timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -x ${PYTEST_ARGS:-} 2>&1 | tail -40 > $OUT/tests_gpu_$N.log
+    echo "tests $N exit=${PIPESTATUS[0]}" >> $OUT/summary.txt; tail -3 $OUT/tests_gpu_$N.log >> $OUT/summary.txt
   done
   cp gpurun_out/parity_fullsize.json $OUT/ 2>/dev/null
 fi
 if [[ $WHAT == *equal* ]]; then
   first=""
-  for L in $LIBS; do
+  for v in $VARIANTS; do
+    N=${v%%=*}
     for W in ${EQUAL_WORKLOADS:-$WORKLOADS}; do
-      WEBSPLAT_LIB=$(libpath $L) timeout 600 python scripts/dump_images.py $W /tmp/img_$L 0 3 > $OUT/dump_${L}_$W.log 2>&1 || echo "dump $L $W FAILED" >> $OUT/summary.txt
+      env $(venv ${v#*=}) timeout 600 python scripts/dump_images.py $W /tmp/img_$N 0 3 > $OUT/dump_${N}_$W.log 2>&1 || echo "dump $N $W FAILED" >> $OUT/summary.txt
     done
-    if [[ -z $first ]]; then first=$L; else
-      python scripts/dump_images.py --compare /tmp/img_$first /tmp/img_$L > $OUT/equal_${first}_vs_$L.txt 2>&1; echo "equal $first vs $L exit=$?" >> $OUT/summary.txt
+    if [[ -z $first ]]; then first=$N; else
+      python scripts/dump_images.py --compare /tmp/img_$first /tmp/img_$N > $OUT/equal_${first}_vs_$N.txt 2>&1; echo "equal $first vs $N exit=$?" >> $OUT/summary.txt
     fi
   done
 fi
 if [[ $WHAT == *ab* ]]; then
   for W in $WORKLOADS; do
-    for L in $LIBS; do
-      echo "== $W $L" >> $OUT/ab.txt
-      WEBSPLAT_LIB=$(libpath $L) timeout 600 python scripts/tile_stats.py $W 2>&1 | grep -E "^view 0|consumed|kernel times" | head -3 >> $OUT/ab.txt
-      WEBSPLAT_LIB=$(libpath $L) timeout 600 python bench.py --steps $STEPS --warmup 30 --no-cpu-baseline --workload $W 2> $OUT/bench_${L}_$W.err | tail -1 > $OUT/bench_${L}_$W.json
-      python - $OUT/bench_${L}_$W.json >> $OUT/ab.txt <<'PY'
+    for v in $VARIANTS; do
+      N=${v%%=*}
+      echo "== $W $N (${v#*=})" >> $OUT/ab.txt
+      env $(venv ${v#*=}) timeout 600 python scripts/tile_stats.py $W 2>&1 | grep -E "^view 0|consumed|kernel times" | head -3 >> $OUT/ab.txt
+      env $(venv ${v#*=}) timeout 600 python bench.py --steps $STEPS --warmup 30 --no-cpu-baseline --workload $W 2> $OUT/bench_${N}_$W.err | tail -1 > $OUT/bench_${N}_$W.json
+      python - $OUT/bench_${N}_$W.json >> $OUT/ab.txt <<'PY'
 import json,sys
 try:
     j=json.loads(open(sys.argv[1]).read())
@@ -57,13 +67,14 @@ PY
   cat $OUT/ab.txt >> $OUT/summary.txt
 fi
 if [[ $WHAT == *prof* ]]; then
-  L=$(echo $LIBS | awk '{print $NF}')
-  for W in ${PROF_WORKLOADS:-$WORKLOADS}; do
-    rm -rf $OUT/prof_$W
-    WEBSPLAT_LIB=$(libpath $L) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$W -o prof -- python bench.py --steps 60 --warmup 10 --streams 1 --workload $W --no-cpu-baseline --no-dist > $OUT/prof_$W.log 2>&1; echo "prof $W ($L) exit=$?" >> $OUT/summary.txt
-    python scripts/frame_timeline.py $OUT/prof_$W/prof_kernel_trace.csv > $OUT/${W}_${L}_frame_timeline.txt 2>&1
-    cp $OUT/prof_$W/prof_kernel_stats.csv $OUT/${W}_${L}_kernel_stats.csv 2>/dev/null
-    find $OUT/prof_$W -name "*kernel_trace*" -size +4M -delete
+  for N in ${PROF_VARIANTS:-$(echo $VARIANTS | awk '{print $NF}' | cut -d= -f1)}; do
+    for W in ${PROF_WORKLOADS:-$WORKLOADS}; do
+      rm -rf $OUT/prof_${N}_$W
+      env $(venv $(vspec $N)) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${N}_$W -o prof -- python bench.py --steps 60 --warmup 10 --streams 1 --workload $W --no-cpu-baseline --no-dist > $OUT/prof_${N}_$W.log 2>&1; echo "prof $W ($N) exit=$?" >> $OUT/summary.txt
+      python scripts/frame_timeline.py $OUT/prof_${N}_$W/prof_kernel_trace.csv > $OUT/${W}_${N}_frame_timeline.txt 2>&1
+      cp $OUT/prof_${N}_$W/prof_kernel_stats.csv $OUT/${W}_${N}_kernel_stats.csv 2>/dev/null
+      find $OUT/prof_${N}_$W -name "*kernel_trace*" -size +4M -delete
+    done
   done
 fi
 cat $OUT/summary.txt

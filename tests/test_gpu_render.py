@@ -357,15 +357,19 @@ def _coverage_tiles(splats_f16, viewport, tile=(16, 16)):
     return out
 
 
+@pytest.mark.parametrize("footprint", ["rect", "ellipse", "wide"])
 @pytest.mark.parametrize("shape", [None, "2x2", "4x2", "4x4"])
 @pytest.mark.parametrize("kind", ["c1", "needles"])
-def test_binning_covers_every_touched_tile(ws, oracle, kind, shape, monkeypatch):
-    """Binning hands the blend the tiles the kept ellipse reaches (footprint.h: per tile row the exact column span, not
-    the bounding rectangle).  It may list a tile the ellipse just misses (the blend's exact per-quadrant test drops it)
-    but never drop one it touches: every tile holding a covered pixel centre must list the splat, exactly once, each
-    tile's list must be in draw order, and the lists must stay within a few percent of the tiles actually covered."""
+def test_binning_covers_every_touched_tile(ws, oracle, kind, shape, footprint, monkeypatch):
+    """Binning hands the blend the tiles of the kept ellipse's bounding rectangle (default; "wide": the same rectangle
+    through the tile-count form that viewports beyond 256 tiles per axis take) or, with WS_FOOTPRINT=ellipse, the tiles
+    the ellipse itself reaches (footprint.h: per tile row the exact column span).  It may list a tile the ellipse misses
+    (the blend's exact per-quadrant test drops it) but never drop one it touches: every tile holding a covered pixel
+    centre must list the splat, exactly once, and each tile's list must be in draw order."""
     if shape:
         monkeypatch.setenv("WS_TILE_SHAPE", shape)
+    if footprint == "ellipse":
+        monkeypatch.setenv("WS_FOOTPRINT", "ellipse")
     ctx = ws.Context(0)
     tile = ctx.tile_size()
     if shape:
@@ -377,10 +381,11 @@ def test_binning_covers_every_touched_tile(ws, oracle, kind, shape, monkeypatch)
         rows = synth.scene_c1(n=3000, seed=22)
         rows[:, -7:-4] = np.log(np.stack([rng.uniform(0.1, 0.4, 3000), rng.uniform(0.003, 0.01, 3000),
                                           rng.uniform(0.003, 0.01, 3000)], 1)).astype(np.float32)
-    viewport = (640, 400)
+    # "wide": more than 256 binning tiles per axis (even at 32-px tiles) -> the footprint word is a tile count
+    viewport = (8256, 80) if footprint == "wide" else (640, 400)
     gpc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
     cj = synth.camera_c1(*viewport)
-    cj.fx = cj.fy = 600.0
+    cj.fx = cj.fy = 6000.0 if footprint == "wide" else 600.0
     cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, *viewport)
     cam.fit_near_far(gpc.aabb)
     args = ws.SplattingArgs(camera=cam, viewport=viewport, max_sh_deg=3)
@@ -408,7 +413,10 @@ def test_binning_covers_every_touched_tile(ws, oracle, kind, shape, monkeypatch)
         missing = [(i, sorted(c - listed[i])) for i, c in enumerate(cov) if not c <= listed[i]]
         assert not missing, missing[:5]
         n_cov, n_listed = sum(len(c) for c in cov), sum(len(l) for l in listed)
-        assert n_listed <= 1.05 * n_cov + 50, (n_listed, n_cov)  # the ellipse's footprint, not its bounding rectangle
+        if footprint == "ellipse":
+            assert n_listed <= 1.05 * n_cov + 50, (n_listed, n_cov)  # the ellipse's footprint, not its bounding rectangle
+        else:
+            assert n_listed <= (1.6 if kind == "c1" else 6.0) * n_cov + 50, (n_listed, n_cov)  # bounding rectangles, not more
     finally:
         r.close()
         pc.close()
@@ -475,3 +483,29 @@ def test_wave_stats_capture(ws, ctx, oracle):
     finally:
         r.close()
         pc.close()
+
+
+def test_footprint_modes_draw_the_same_image(ws, oracle, monkeypatch):
+    """The footprint word only decides which tiles LIST a splat; the blend's per-pixel test decides what is drawn.  The
+    ellipse footprint (WS_FOOTPRINT=ellipse) must therefore give the bit-identical image with fewer tile entries."""
+    sc = scenes.c1(ws, oracle, n=20_000, viewport=(800, 600), seed=31)
+    out = {}
+    for mode in ("rect", "ellipse"):
+        if mode == "ellipse":
+            monkeypatch.setenv("WS_FOOTPRINT", "ellipse")
+        c = ws.Context(0)
+        pc = ws.PointCloud(c, sc.gpc)
+        r = ws.GaussianRenderer(c, "rgba32float", 3, False)
+        try:
+            r.prepare(pc, sc.args)
+            r.render(pc, background=(0.1, 0.2, 0.3, 1.0))
+            out[mode] = (r.download_target(), r.frame_stats())
+        finally:
+            r.close()
+            pc.close()
+            c.close()
+    (img_r, st_r), (img_e, st_e) = out["rect"], out["ellipse"]
+    assert st_r["overflow"] == 0 and st_e["overflow"] == 0
+    assert st_r["num_visible"] == st_e["num_visible"]
+    assert st_e["num_tile_entries"] < st_r["num_tile_entries"]
+    assert np.array_equal(img_r.view(np.uint32), img_e.view(np.uint32))

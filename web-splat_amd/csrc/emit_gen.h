@@ -25,13 +25,15 @@ __device__ __forceinline__ uint32_t pad(uint32_t i) { return i + i / EPT; }  // 
 
 struct Source {
     const uint32_t* sorted_idx;   // [V] store indices in draw order
-    const uint8_t* splats;        // [V] x 20 B Splat records, by store index
+    const uint32_t* fp_sorted;    // [V] footprint words by draw position (FP_RECT_PACKED: the packed rectangle)
+    const uint8_t* splats;        // [V] x 20 B Splat records, by store index (the other footprint modes)
     const uint32_t* offsets;      // [V] exclusive prefix of tiles touched, by draw position
     const uint32_t* emit_start;   // draw position owning entry m * EMIT_TILE
     const FrameCounters* counters;
     uint32_t tiles_x;
     float vw, vh;                 // viewport in pixels (the f32 values K1 used)
     uint32_t tile_w_log2, tile_h_log2;
+    bool ellipse;                 // FP_ELLIPSE: per-row spans; FP_RECT_COUNT: the whole rectangle
 };
 
 // words 0..2 of a Splat record (v1, v2, pos: the geometry; pointcloud.rs:352-358)
@@ -112,11 +114,25 @@ __device__ __forceinline__ Slice slice_setup(const Source& src, uint32_t slice, 
 
 // Tile id of the k-th tile of the splat's footprint (footprint.h): the same function of the same 12 bytes K1 counted.
 __device__ __forceinline__ uint32_t tile_of(const Source& src, const Geom& g, uint32_t k) {
-    const fp::Tiles ft = fp::setup(g.w0, g.w1, g.w2, src.vw, src.vh, src.tile_w_log2, src.tile_h_log2);
+    const fp::Tiles ft = fp::setup(g.w0, g.w1, g.w2, src.vw, src.vh, src.tile_w_log2, src.tile_h_log2, src.ellipse);
     return fp::tile_at(ft, k, src.tiles_x, src.tile_w_log2, src.tile_h_log2);
 }
 
+// FP_RECT_PACKED: tile id of the k-th tile (row-major inside the rectangle) of the packed rectangle r.
+__device__ __forceinline__ uint32_t tile_of_rect(uint32_t r, uint32_t k, uint32_t tiles_x) {
+    const uint32_t x0 = r & 0xFFu, y0 = (r >> 8) & 0xFFu;  // x0 | y0 << 8 | (w - 1) << 16 | (h - 1) << 24
+    const uint32_t w = ((r >> 16) & 0xFFu) + 1u;
+    // k / w without the integer-division sequence: k < 2^16 (a rectangle has at most 256 x 256 tiles), far inside the
+    // range where the float path with one correction step is exact
+    uint32_t q = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
+    uint32_t rem = k - q * w;
+    if ((int32_t)rem < 0) { q -= 1u; rem += w; }
+    if (rem >= w) { q += 1u; rem -= w; }
+    return (y0 + q) * tiles_x + (x0 + rem);
+}
+
 // Entry el (0 <= el < sl.ne) of the slice: tile id and splat (store index).
+template <bool PACKED>
 __device__ __forceinline__ void entry(const Source& src, const Slice& sl, const uint32_t* s_off, const uint32_t* s_own,
                                       uint32_t el, uint32_t* key, uint32_t* val) {
     const uint32_t e = sl.e0 + el;
@@ -135,7 +151,8 @@ __device__ __forceinline__ void entry(const Source& src, const Slice& sl, const 
     }
     const uint32_t pos = sl.s_lo + lo;
     *val = src.sorted_idx[pos];
-    *key = tile_of(src, load_geom(src, *val), e - (sl.in_lds ? s_off[lo] : sl.goff[lo]));
+    const uint32_t k = e - (sl.in_lds ? s_off[lo] : sl.goff[lo]);
+    *key = PACKED ? tile_of_rect(src.fp_sorted[pos], k, src.tiles_x) : tile_of(src, load_geom(src, *val), k);
 }
 
 }  // namespace emit

@@ -44,7 +44,8 @@ struct Tiles {
 
 // Splat words 0..2 (v1 f16x2, v2 f16x2, pos f16x2; pointcloud.rs:352-358), the viewport in pixels as the f32 the camera
 // uniform holds, log2 of the binning tile size.
-WS_HD Tiles setup(uint32_t w0, uint32_t w1, uint32_t w2, float vw, float vh, uint32_t tw_log2, uint32_t th_log2) {
+WS_HD Tiles setup(uint32_t w0, uint32_t w1, uint32_t w2, float vw, float vh, uint32_t tw_log2, uint32_t th_log2,
+                  bool spans = true) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
@@ -80,6 +81,7 @@ WS_HD Tiles setup(uint32_t w0, uint32_t w1, uint32_t w2, float vw, float vh, uin
     t.ty0 = (uint32_t)y_lo >> th_log2;
     t.ty1 = (uint32_t)y_hi >> th_log2;
     t.any = true;
+    if (!spans) return t;  // (FP_RECT_COUNT: every row spans the rectangle)
     // the blend's quadratic form (blend_stage.h decode): I' = sqrt(log2 e) * M^-1
     const float inv = stage::SQRT_LOG2E_F / det;
     const float i00 = m11 * inv, i01 = -m01 * inv, i10 = -m10 * inv, i11 = m00 * inv;

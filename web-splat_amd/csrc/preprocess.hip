@@ -133,7 +133,7 @@ __device__ __forceinline__ void eval_sh3(const Sh16& sh, float x, float y, float
 struct SplatOut {
     uint32_t w[5];  // Splat: v(4 x f16) pos(2 x f16) color(4 x f16)
     uint32_t key;
-    uint32_t tiles; // binning tiles the kept ellipse reaches (footprint.h), 0 = none
+    uint32_t fp;    // the binning footprint word (ws_internal.h FootprintMode)
 };
 
 #define VM(c, r) (p.cam.view[(c)*4 + (r)])
@@ -151,7 +151,7 @@ __device__ __forceinline__ uint32_t k1_depth_key(const K1Params& p, float clip_z
 }
 
 // From the frustum test onward: preprocess.wgsl:194-273 / preprocess_compressed.wgsl:234-325.
-template <bool COMPRESSED>
+template <bool COMPRESSED, int FPMODE>
 __device__ void k1_math(const K1Params& p, const float xyz[3], const float camspace[4], const float pos2d[4],
                         float opacity, const float cov6[6], const Sh16& sh, SplatOut* out) {
 #if !WS_K1_STRICT
@@ -305,12 +305,41 @@ __device__ void k1_math(const K1Params& p, const float xyz[3], const float camsp
 
     out->key = k1_depth_key<COMPRESSED>(p, pos2d[2]);
 
-    // binning-tile footprint of the kept ellipse a <= 2*CUTOFF (gaussian.wgsl:40-64): the NUMBER of tiles it reaches,
-    // derived from the f16-ROUNDED splat so that binning and blending agree on coverage (footprint.h; k_bin_emit
-    // re-derives the tiles themselves from the same 12 bytes).
-    {
-        const fp::Tiles ft = fp::setup(out->w[0], out->w[1], out->w[2], vw, vh, p.tile_w_log2, p.tile_h_log2);
-        out->tiles = fp::count(ft, p.tile_w_log2, p.tile_h_log2);
+    // Binning footprint of the kept ellipse a <= 2*CUTOFF (gaussian.wgsl:40-64), derived from the f16-ROUNDED splat so
+    // that binning and blending agree on coverage.  The packed bounding rectangle by default; the tile COUNT of the
+    // rectangle (wide viewports) or of the ellipse itself (WS_FOOTPRINT=ellipse) through footprint.h, whose tiles
+    // k_bin_emit re-derives from the same 12 bytes.
+    if (FPMODE == FP_RECT_PACKED) {
+        const float q1x = h2f(h0), q1y = h2f(h1), q2x = h2f(h2), q2y = h2f(h3);
+        const float m00 = q1x * vw, m01 = q2x * vw;
+        const float m10 = -q1y * vh, m11 = -q2y * vh;
+        const float det = m00 * m11 - m01 * m10;
+        const float cx = (h2f(h4) * 0.5f + 0.5f) * vw;
+        const float cy = (0.5f - h2f(h5) * 0.5f) * vh;
+        const float rad = 2.1697873f * 1.00001f;  // sqrt(2*CUTOFF), padded
+        const float exx = rad * qsqrt(m00 * m00 + m01 * m01) + 1e-3f;
+        const float eyy = rad * qsqrt(m10 * m10 + m11 * m11) + 1e-3f;
+        uint32_t rect = RECT_EMPTY;
+        const bool ok = (fabsf(det) > 0.0f) && (fabsf(det) < 3.0e38f) && (fabsf(cx) < 1.0e9f) && (fabsf(cy) < 1.0e9f) &&
+                        (exx < 1.0e9f) && (eyy < 1.0e9f);
+        if (ok) {
+            // pixel (x, y) has its centre at (x + 0.5, y + 0.5)
+            float x_lo = ceilf(cx - exx - 0.5f), x_hi = floorf(cx + exx - 0.5f);
+            float y_lo = ceilf(cy - eyy - 0.5f), y_hi = floorf(cy + eyy - 0.5f);
+            x_lo = fmaxf(x_lo, 0.0f);
+            y_lo = fmaxf(y_lo, 0.0f);
+            x_hi = fminf(x_hi, vw - 1.0f);
+            y_hi = fminf(y_hi, vh - 1.0f);
+            if (x_lo <= x_hi && y_lo <= y_hi) {
+                const uint32_t tx0 = (uint32_t)x_lo >> p.tile_w_log2, tx1 = (uint32_t)x_hi >> p.tile_w_log2;
+                const uint32_t ty0 = (uint32_t)y_lo >> p.tile_h_log2, ty1 = (uint32_t)y_hi >> p.tile_h_log2;
+                rect = rect_pack(tx0, ty0, tx1, ty1);  // < 256 tiles per axis (ws_renderer_prepare picks the mode by the viewport)
+            }
+        }
+        out->fp = rect;
+    } else {
+        const fp::Tiles ft = fp::setup(out->w[0], out->w[1], out->w[2], vw, vh, p.tile_w_log2, p.tile_h_log2, FPMODE == FP_ELLIPSE);
+        out->fp = fp::count(ft, p.tile_w_log2, p.tile_h_log2);
     }
 }
 
@@ -402,6 +431,7 @@ __device__ __forceinline__ void k1_back_load(const K1Params& p, const K1Buffers&
     }
 }
 
+template <int FPMODE>
 __device__ __forceinline__ void k1_back_math(const K1Params& p, const Front& f, const RawBack& rb, SplatOut* so) {
     float camspace[4], pos2d[4];
     (void)k1_project<false>(p, f.xyz, camspace, pos2d);  // same instruction sequence as the front end
@@ -423,10 +453,11 @@ __device__ __forceinline__ void k1_back_math(const K1Params& p, const Front& f, 
     Sh16 sh;
 #pragma unroll
     for (int e = 0; e < 48; ++e) sh.c[e / 3][e % 3] = h2f(hw[e / 2] >> ((e & 1) * 16));
-    k1_math<false>(p, f.xyz, camspace, pos2d, h2f(f.w3), cov6, sh, so);
+    k1_math<false, FPMODE>(p, f.xyz, camspace, pos2d, h2f(f.w3), cov6, sh, so);
 }
 
 // Back end for one survivor of the COMPRESSED layout: de-quantise, gather the codebooks, run the maths.
+template <int FPMODE>
 __device__ __forceinline__ void k1_back_compressed(const K1Params& p, const K1Buffers& b, const Front& f, SplatOut* so) {
     float camspace[4], pos2d[4];
     (void)k1_project<true>(p, f.xyz, camspace, pos2d);
@@ -492,7 +523,7 @@ __device__ __forceinline__ void k1_back_compressed(const K1Params& p, const K1Bu
             }
         }
     }
-    k1_math<true>(p, f.xyz, camspace, pos2d, opacity, cov6, sh, so);
+    k1_math<true, FPMODE>(p, f.xyz, camspace, pos2d, opacity, cov6, sh, so);
 }
 
 // One workgroup = one ticket = K1_ITEMS x 256 consecutive Gaussians (1024): a single device-wide atomic per
@@ -501,7 +532,7 @@ __device__ __forceinline__ void k1_back_compressed(const K1Params& p, const K1Bu
 #ifndef WS_K1_MINWAVES
 #define WS_K1_MINWAVES 1
 #endif
-template <bool COMPRESSED>
+template <bool COMPRESSED, int FPMODE>
 __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const K1Params p, const K1Buffers b) {
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_cnt[K1_ITEMS][K1_THREADS / 64];
@@ -568,7 +599,7 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
     for (int it = 0; it < K1_ITEMS; ++it) {
         so[it].w[0] = so[it].w[1] = so[it].w[2] = so[it].w[3] = so[it].w[4] = 0u;
         so[it].key = 0u;
-        so[it].tiles = 0u;
+        so[it].fp = FPMODE == FP_RECT_PACKED ? RECT_EMPTY : 0u;
     }
     if (!COMPRESSED) {
         const uint32_t safe_idx = block_base < n ? block_base : 0u;  // culled lanes re-read this (cached) record
@@ -583,13 +614,13 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
 #pragma unroll
             for (int u = 0; u < K1_BACK_GROUP; ++u) {
                 const int it = grp + u;
-                if (vis[it]) k1_back_math(p, fr[it], rb[u], &so[it]);
+                if (vis[it]) k1_back_math<FPMODE>(p, fr[it], rb[u], &so[it]);
             }
         }
     } else {
 #pragma unroll
         for (int it = 0; it < K1_ITEMS; ++it)
-            if (vis[it]) k1_back_compressed(p, b, fr[it], &so[it]);
+            if (vis[it]) k1_back_compressed<FPMODE>(p, b, fr[it], &so[it]);
     }
 
     // ---- range of the block's depth keys (the depth sort sizes its digits by the frame's range, sort.hip) ----------
@@ -647,7 +678,7 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
             sp[3] = so[it].w[3];
             sp[4] = so[it].w[4];
             b.keys[slot] = so[it].key;
-            b.tile_counts[slot] = so[it].tiles;
+            b.footprints[slot] = so[it].fp;
             if (b.src_index) b.src_index[slot] = block_base + it * K1_THREADS + tid;
         }
     }
@@ -655,19 +686,24 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
 
 }  // namespace
 
-const void* preprocess_kernel_func(bool compressed) {
-    return compressed ? reinterpret_cast<const void*>(&k_preprocess<true>) : reinterpret_cast<const void*>(&k_preprocess<false>);
+namespace {
+typedef void (*K1Kernel)(const K1Params, const K1Buffers);
+K1Kernel k1_kernel(bool compressed, int mode) {
+    if (compressed) return mode == FP_ELLIPSE ? &k_preprocess<true, FP_ELLIPSE> : (mode == FP_RECT_COUNT ? &k_preprocess<true, FP_RECT_COUNT> : &k_preprocess<true, FP_RECT_PACKED>);
+    return mode == FP_ELLIPSE ? &k_preprocess<false, FP_ELLIPSE> : (mode == FP_RECT_COUNT ? &k_preprocess<false, FP_RECT_COUNT> : &k_preprocess<false, FP_RECT_PACKED>);
+}
+}  // namespace
+
+const void* preprocess_kernel_func(bool compressed, int footprint_mode) {
+    return reinterpret_cast<const void*>(k1_kernel(compressed, footprint_mode));
 }
 
 uint32_t preprocess_blocks(uint32_t n) { return (n + K1_THREADS * K1_ITEMS - 1) / (K1_THREADS * K1_ITEMS); }
 
-int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, hipStream_t stream) {
+int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, int footprint_mode, hipStream_t stream) {
     const uint32_t blocks = preprocess_blocks(p.num_points);
     if (blocks == 0) return WS_OK;
-    if (compressed)
-        hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(K1_THREADS), 0, stream, p, b);
-    else
-        hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(K1_THREADS), 0, stream, p, b);
+    hipLaunchKernelGGL(k1_kernel(compressed, footprint_mode), dim3(blocks), dim3(K1_THREADS), 0, stream, p, b);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }

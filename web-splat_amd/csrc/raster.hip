@@ -62,14 +62,14 @@ __device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t
 }
 
 // ---- k_bin_prefix ------------------------------------------------------------------------------------
-// Draw position i (far -> near) -> offsets[i] = sum of tiles touched by positions < i.  The footprint tile counts
-// (footprint.h) arrive IN DRAW ORDER: they ride through the depth sort with the splat index (sort.hip), so this kernel
+// Draw position i (far -> near) -> offsets[i] = sum of tiles touched by positions < i.  The footprint words (packed tile
+// rectangles, or tile counts: ws_internal.h FootprintMode) arrive IN DRAW ORDER: they ride through the depth sort with the splat index (sort.hip), so this kernel
 // streams (round 1 gathered per-splat data by sorted index at random: every XCD's L2 pulled the whole array, 3.2 x the
 // algorithmic traffic on the 1 M scene and 122 of this kernel's 137 us on 5 M splats).
 // Also records, for every multiple m*EMIT_TILE of the entry index, the draw position whose entry range
 // contains it (emit_start[m]): the emit kernel then needs no global search to find where its slice starts.
 template <int BIN_IPT>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __restrict__ counts_sorted,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __restrict__ fp_sorted, const int packed,
                                                            uint32_t* __restrict__ offsets,
                                                            uint32_t* __restrict__ emit_start,
                                                            uint64_t* __restrict__ status,
@@ -108,12 +108,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
 #pragma unroll
     for (int k = 0; k < BIN_IPT; ++k) {
         const uint32_t i = base + k * BIN_THREADS + tid;
-        r[k] = counts_sorted[i < v ? i : v - 1u];
+        r[k] = fp_sorted[i < v ? i : v - 1u];
     }
 #pragma unroll
     for (int k = 0; k < BIN_IPT; ++k) {
         const uint32_t i = base + k * BIN_THREADS + tid;
-        cnt[k] = i < v ? r[k] : 0u;
+        cnt[k] = i < v ? (packed ? rect_tiles(r[k]) : r[k]) : 0u;
         s_cnt[pad(k * BIN_THREADS + tid)] = cnt[k];
     }
     __syncthreads();
@@ -172,6 +172,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
 // not pay for generating everything twice, once to count and once to scatter.)
 constexpr int EMIT_COPIES = 2;
 
+template <bool PACKED>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src, uint32_t* __restrict__ entry_keys,
                                                          uint32_t* __restrict__ entry_vals,
                                                          uint32_t* __restrict__ tile_hist, uint32_t tile_hist_pitch,
@@ -192,23 +193,30 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
             // All EPT entries of a thread at once: owners from LDS, then their index gathers in flight together, then the
             // geometry words of their Splat records.  (Entry by entry, each one waited for its dependent loads before
             // the next one's were issued: 16 serial round trips per thread -- the whole duration of this kernel.)
-            uint32_t lo[emit::EPT], val[emit::EPT];
-            emit::Geom geom[emit::EPT];
+            uint32_t lo[emit::EPT], val[emit::EPT], rect[PACKED ? emit::EPT : 1];
+            emit::Geom geom[PACKED ? 1 : emit::EPT];
 #pragma unroll
             for (int j = 0; j < emit::EPT; ++j) {
                 const uint32_t el = (uint32_t)tid + (uint32_t)j * BIN_THREADS;
                 lo[j] = el < sl.ne ? s_own[emit::pad(el)] : 0u;
             }
 #pragma unroll
-            for (int j = 0; j < emit::EPT; ++j) val[j] = src.sorted_idx[sl.s_lo + lo[j]];
+            for (int j = 0; j < emit::EPT; ++j) {
+                const uint32_t pos = sl.s_lo + lo[j];
+                if (PACKED) rect[j] = src.fp_sorted[pos];
+                val[j] = src.sorted_idx[pos];
+            }
+            if (!PACKED) {
 #pragma unroll
-            for (int j = 0; j < emit::EPT; ++j) geom[j] = emit::load_geom(src, val[j]);
+                for (int j = 0; j < emit::EPT; ++j) geom[j] = emit::load_geom(src, val[j]);
+            }
 #pragma unroll
             for (int j = 0; j < emit::EPT; ++j) {
                 const uint32_t el = (uint32_t)tid + (uint32_t)j * BIN_THREADS;
                 if (el < sl.ne) {
                     const uint32_t e = sl.e0 + el;
-                    const uint32_t key = emit::tile_of(src, geom[j], e - s_off[lo[j]]);
+                    const uint32_t key = PACKED ? emit::tile_of_rect(rect[j], e - s_off[lo[j]], src.tiles_x)
+                                                : emit::tile_of(src, geom[j], e - s_off[lo[j]]);
                     if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
                     else entry_keys[e] = key;
                     entry_vals[e] = val[j];
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
         } else {
             for (uint32_t el = tid; el < sl.ne; el += BIN_THREADS) {
                 uint32_t key, val;
-                emit::entry(src, sl, s_off, s_own, el, &key, &val);
+                emit::entry<PACKED>(src, sl, s_off, s_own, el, &key, &val);
                 const uint32_t e = sl.e0 + el;
                 if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
                 else entry_keys[e] = key;
@@ -356,6 +364,27 @@ __device__ __forceinline__ RawSplat blend_fetch_raw(const BlendParams& p, uint2 
     return blend_gather(p, blend_entry_idx<STAGE>(p, range, hi, tid));
 }
 
+// ---- gfx950 LDS-DMA staging (k_blend<..., DMA = true>) ------------------------------------------------------------------
+// The gather above holds five VGPRs per thread from the load to the decode, a whole batch later; under the 64-VGPR cap
+// (two 1024-thread workgroups per CU) that is what made every deeper prefetch fail.  global_load_lds_dwordx4 /
+// _dword write the record straight into LDS: nothing is held while the load flies.  The destination of lane l is the
+// wave-uniform base + l * size, so a wave's 64 records land in its own 64 consecutive slots of two raw planes
+// (16-B part, 4-B part), and only that wave reads them back: s_waitcnt vmcnt(0) in the same wave is all the
+// synchronisation they need.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void blend_gather_lds(const BlendParams& p, uint32_t idx, void* raw4_wave, void* raw1_wave) {
+    const char* sp = reinterpret_cast<const char*>(p.splats) + (size_t)idx * 20;
+    __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)raw4_wave, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(sp + 16), (lptr_t)raw1_wave, 4, 0, 0);
+}
+// Workgroup barrier that leaves vector-memory loads in flight.  __syncthreads() carries a workgroup-scope release: with an
+// LDS-DMA outstanding the compiler drains vmcnt(0) in front of it, and the prefetch stops being one.  Here: this wave's own
+// LDS traffic has completed (lgkmcnt), then the bare barrier; the "memory" clobber keeps the compiler from moving LDS
+// accesses across it.
+__device__ __forceinline__ void wg_barrier_keep_loads() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wait_vector_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // LDS layout of a staged batch: two planes of 16-B records with the SAME slot stride, so one byte offset
 // (slot * 16, what the per-wave lists store) addresses both with immediate offsets: two ds_read_b128 per record
 // (4 LDS cycles each; the LDS array serves the CU's four SIMDs, and at ~16 VALU instructions per (record, wave)
@@ -406,7 +435,7 @@ __device__ __forceinline__ void blend_composite(const BlendRec& r, float lx, flo
 #ifndef WS_BLEND_STAGE_MAX
 #define WS_BLEND_STAGE_MAX 512
 #endif
-template <int FORMAT, int QW, int QH, bool MULTI, bool CAPTURE>
+template <int FORMAT, int QW, int QH, bool MULTI, bool CAPTURE, bool DMA>
 __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const BlendParams p, const uint32_t tpw_log2_arg) {
     const uint32_t tpw_log2 = MULTI ? tpw_log2_arg : 0u;  // MULTI = several tiles per workgroup (4K-class tile counts)
     constexpr int NW = QW * QH;                  // waves = quadrants
@@ -429,6 +458,11 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     __shared__ uint2 s_range[16];   // [begin, end) of this workgroup's tiles in the sorted entry list
     __shared__ uint32_t s_txy[16];  // tx | ty << 16, or 0xFFFFFFFF for a slot outside the image
     __shared__ uint32_t s_dbg_max;  // capture mode: most records any wave walked in the current batch
+    // DMA: raw Splat records as the LDS-DMA leaves them, plane of the 16-B parts and plane of the 4-B parts; two buffers:
+    // the tile being composited stages out of one, the first batch of the workgroup's NEXT tile lands in the other
+    __shared__ __attribute__((aligned(16))) u32x4_t s_raw4[DMA ? (MULTI ? 2 : 1) * STAGE : 1];
+    __shared__ uint32_t s_raw1[DMA ? (MULTI ? 2 : 1) * STAGE : 1];
+    __shared__ uint32_t s_alive[2];  // DMA: "some pixel of the tile is not saturated yet", per batch parity
 
     // The frame's error bits (entry overflow, look-back spin time-outs) live in the per-frame zero arena; the last
     // kernel of the frame folds them into a word that survives the next frame's memset, so a batch of frames enqueued
@@ -471,19 +505,29 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     uint32_t* my_list = s_list[wave];
 
     RawSplat raw = {{0u, 0u, 0u, 0u}, 0u};
+    uint32_t rbuf = 0u;  // DMA: the raw buffer (slot offset 0 or STAGE) the current tile stages out of
+    const uint32_t wslot = (uint32_t)wave * 64u;  // first raw slot of this wave (stager waves only)
     if (stager) {
         const uint2 r0 = s_range[0];
-        if (r0.y > r0.x) raw = blend_fetch_raw<STAGE>(p, r0, r0.y, tid);  // (an empty tile must not touch the entry list)
+        if (r0.y > r0.x) {  // (an empty tile must not touch the entry list)
+            if (DMA) blend_gather_lds(p, blend_entry_idx<STAGE>(p, r0, r0.y, tid), s_raw4 + wslot, s_raw1 + wslot);
+            else raw = blend_fetch_raw<STAGE>(p, r0, r0.y, tid);
+        }
     }
     for (uint32_t k = 0; k < tpw; ++k) {
     const uint32_t code = s_txy[k];
     const uint2 range = s_range[k];
     // the first batch of the NEXT tile (entry index -> Splat record: two dependent round trips) flies while this
-    // tile is composited
+    // tile is composited.  (DMA: issued from the first staging step of this tile, behind its s_waitcnt vmcnt(0): every
+    // older LDS-DMA into that buffer -- the unused prefetch of an earlier tile that saturated -- has landed by then.)
     RawSplat raw_next_tile = {{0u, 0u, 0u, 0u}, 0u};
+    uint2 range_nt = make_uint2(0u, 0u);  // non-empty: the next tile's first batch is still to be requested (DMA)
     if (MULTI && stager && k + 1u < tpw) {
         const uint2 rn = s_range[k + 1u];
-        if (rn.y > rn.x) raw_next_tile = blend_fetch_raw<STAGE>(p, rn, rn.y, tid);
+        if (rn.y > rn.x) {
+            if (DMA) range_nt = rn;
+            else raw_next_tile = blend_fetch_raw<STAGE>(p, rn, rn.y, tid);
+        }
     }
     if (code != 0xFFFFFFFFu) {  // block-uniform
     const uint32_t tx = code & 0xFFFFu, ty = code >> 16;
@@ -510,11 +554,22 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         if (tid == 0) s_dbg_max = 0u;
         __syncthreads();
     }
+    uint32_t bpar = 0u;  // DMA: parity of the batch (which s_alive word it uses)
     while (hi > range.x) {
         const uint32_t nb = (hi - range.x) < (uint32_t)STAGE ? (hi - range.x) : (uint32_t)STAGE;
         const uint32_t hi_next = hi - nb;
         if (stager) {
             uint32_t mask = 0u;
+            uint32_t idx_nt = 0u;
+            const bool fetch_nt = DMA && MULTI && range_nt.y > range_nt.x;  // (first batch of this tile only: cleared below)
+            if (DMA) {
+                // this wave's LDS-DMA of the batch (issued one batch, or one tile, ago) and its index loads have landed
+                wait_vector_loads();
+                if (fetch_nt) idx_nt = blend_entry_idx<STAGE>(p, range_nt, range_nt.y, tid);  // consumed behind the decode
+                if (tid == 0) s_alive[bpar] = 0u;  // (its readers of two batches ago are long past; its writers come after the barrier)
+                raw.a = s_raw4[rbuf + (uint32_t)tid];
+                raw.w4 = s_raw1[rbuf + (uint32_t)tid];
+            }
             if ((uint32_t)tid < nb) {
                 const stage::Staged s = stage::decode<QW, QH>(raw.a.x, raw.a.y, raw.a.z, raw.a.w, raw.w4, W, H, tile_x0,
                                                               tile_y0, CUT_A2);
@@ -523,14 +578,20 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
                 s_rec[SLOTS + tid] = make_float4(s.i11, s.c1, __uint_as_float(raw.a.w), __uint_as_float(raw.w4));
             }
             s_m[((uint32_t)tid / LCAP) * LCAP + ((uint32_t)tid & 63u) * (LCAP / 64) + (((uint32_t)tid % LCAP) >> 6)] = (uint16_t)mask;
+            if (fetch_nt) {
+                blend_gather_lds(p, idx_nt, s_raw4 + (rbuf ^ (uint32_t)STAGE) + wslot, s_raw1 + (rbuf ^ (uint32_t)STAGE) + wslot);
+                range_nt = make_uint2(0u, 0u);
+            }
             // the next batch's gathers fly while this batch is composited; wasted only when the tile saturates first.
             // UNCONDITIONAL (the address is clamped into the tile's range): under `if (hi_next > range.x)` the compiler
             // merged the loaded words with the old ones at the join -- s_waitcnt vmcnt directly behind the loads and three
             // v_mov, i.e. the "prefetch" waited for its own data before the barrier, one exposed round trip per batch
-            raw = blend_gather(p, idx_next);
+            if (DMA) blend_gather_lds(p, idx_next, s_raw4 + rbuf + wslot, s_raw1 + rbuf + wslot);
+            else raw = blend_gather(p, idx_next);
             idx_next = blend_entry_idx<STAGE>(p, range, hi_next - range.x > (uint32_t)STAGE ? hi_next - (uint32_t)STAGE : range.x, tid);
         }
-        __syncthreads();
+        if (DMA) wg_barrier_keep_loads();
+        else __syncthreads();
         const uint32_t dbg_before = dbg_walked;
         // a wave whose 64 pixels are saturated only keeps staging
         for (uint32_t sub = 0; sub < nb && __ballot(T >= T_MIN) != 0ull; sub += (uint32_t)LCAP) {
@@ -584,7 +645,15 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         }
         hi = hi_next;
         if ((CAPTURE && p.debug_walked) && lane == 0) atomicMax(&s_dbg_max, dbg_walked - dbg_before);
-        const bool all_done = __syncthreads_and(T < T_MIN ? 1 : 0);
+        bool all_done;
+        if (DMA) {  // __syncthreads_and() without the release fence that would drain the staging DMA
+            if (lane == 0 && __ballot(T >= T_MIN) != 0ull) s_alive[bpar] = 1u;
+            wg_barrier_keep_loads();
+            all_done = s_alive[bpar] == 0u;
+            bpar ^= 1u;
+        } else {
+            all_done = __syncthreads_and(T < T_MIN ? 1 : 0);
+        }
         if ((CAPTURE && p.debug_walked)) {
             dbg_lockstep += s_dbg_max;
             __syncthreads();
@@ -610,9 +679,20 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     }
     }  // tile inside the image
     if (!MULTI) break;
-    raw = raw_next_tile;
-    __syncthreads();  // the staging buffers are reused by the next tile
+    if (DMA) {
+        if (stager && range_nt.y > range_nt.x) {  // this tile had no batch to issue the next tile's first batch from
+            wait_vector_loads();
+            blend_gather_lds(p, blend_entry_idx<STAGE>(p, range_nt, range_nt.y, tid), s_raw4 + (rbuf ^ (uint32_t)STAGE) + wslot,
+                             s_raw1 + (rbuf ^ (uint32_t)STAGE) + wslot);
+        }
+        rbuf ^= (uint32_t)STAGE;
+        wg_barrier_keep_loads();  // the staging buffers are reused by the next tile
+    } else {
+        raw = raw_next_tile;
+        __syncthreads();  // the staging buffers are reused by the next tile
+    }
     }  // tiles of this workgroup
+    if (DMA) wait_vector_loads();  // a prefetch the tile did not consume must have landed before the workgroup's LDS is released
 }
 
 // ---- k_blend_q: one WAVE per 8x8 quadrant, no LDS, no barriers -------------------------------------------
@@ -865,7 +945,8 @@ uint32_t bin_prefix_blocks(uint32_t max_points) {
 int launch_bin_prefix(const BinBuffers& b, hipStream_t stream) {
     const uint32_t blocks = bin_prefix_blocks(b.max_points);
     if (blocks == 0) return WS_OK;
-    hipLaunchKernelGGL(k_bin_prefix<BIN_IPT>, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.counts_sorted, b.offsets,
+    hipLaunchKernelGGL(k_bin_prefix<BIN_IPT>, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.fp_sorted,
+                       b.footprint_mode == FP_RECT_PACKED ? 1 : 0, b.offsets,
                        b.emit_start, b.block_status, b.counters, b.entry_cap);
     WS_HIP(hipGetLastError());
     return WS_OK;
@@ -877,7 +958,9 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     if (blocks > 2048u) blocks = 2048u;  // slices are strided over; surplus workgroups are not free
     emit::Source src;
     src.sorted_idx = b.sorted_idx;
+    src.fp_sorted = b.fp_sorted;
     src.splats = b.splats;
+    src.ellipse = b.footprint_mode == FP_ELLIPSE;
     src.offsets = b.offsets;
     src.emit_start = b.emit_start;
     src.counters = b.counters;
@@ -886,8 +969,12 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     src.vh = b.vh;
     src.tile_w_log2 = b.tile_w_log2;
     src.tile_h_log2 = b.tile_h_log2;
-    hipLaunchKernelGGL(k_bin_emit, dim3(blocks), dim3(BIN_THREADS), 0, stream, src, b.entry_keys, b.entry_vals, b.tile_hist,
-                       b.tile_hist_pitch, b.tile_hist_mask, b.key16);
+    if (b.footprint_mode == FP_RECT_PACKED)
+        hipLaunchKernelGGL(k_bin_emit<true>, dim3(blocks), dim3(BIN_THREADS), 0, stream, src, b.entry_keys, b.entry_vals,
+                           b.tile_hist, b.tile_hist_pitch, b.tile_hist_mask, b.key16);
+    else
+        hipLaunchKernelGGL(k_bin_emit<false>, dim3(blocks), dim3(BIN_THREADS), 0, stream, src, b.entry_keys, b.entry_vals,
+                           b.tile_hist, b.tile_hist_pitch, b.tile_hist_mask, b.key16);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }
@@ -902,13 +989,17 @@ static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
     const bool capture = p.debug_consumed != nullptr || p.debug_walked != nullptr;  // analysis build of the kernel
     // tuning knob (WS_BLEND_LDS_PAD_KB): unused dynamic LDS that lowers the number of blend workgroups per CU
     const size_t pad = (size_t)p.lds_pad_kb * 1024u;
-#define WS_LAUNCH_BLEND(FMT)                                                                                         \
-    if (capture)                                                                                                     \
-        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, true>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);      \
-    else if (tpw_log2 > 0u)                                                                                          \
-        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);     \
-    else                                                                                                             \
-        hipLaunchKernelGGL((k_blend<FMT, QW, QH, false, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2)
+#define WS_LAUNCH_BLEND(FMT)                                                                                              \
+    if (capture)                                                                                                          \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, true, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);    \
+    else if (tpw_log2 > 0u && p.dma)                                                                                      \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, false, true>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);    \
+    else if (tpw_log2 > 0u)                                                                                               \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, false, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);   \
+    else if (p.dma)                                                                                                       \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, false, false, true>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);   \
+    else                                                                                                                  \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, false, false, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2)
     switch (p.format) {
         case WS_FORMAT_RGBA32_FLOAT:
             WS_LAUNCH_BLEND(WS_FORMAT_RGBA32_FLOAT);

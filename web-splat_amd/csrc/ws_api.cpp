@@ -114,7 +114,7 @@ struct ws_renderer {
     uint32_t vw = 0, vh = 0, tiles_x = 0, tiles_y = 0;
     uint64_t entry_cap_request = 0;
     uint32_t entry_cap = 0;
-    uint32_t *tcount_a = nullptr, *tcount_b = nullptr;  // footprint tile counts (footprint.h): store order / ping-pong of the depth sort
+    uint32_t *fpw_a = nullptr, *fpw_b = nullptr;  // footprint words (FootprintMode): store order / ping-pong of the depth sort
     uint8_t* splats = nullptr;      // Splat[N], 20 B each (pointcloud.rs:103-108 allocates it in PointCloud;
                                     // here it is per renderer so that renderers never share scratch)
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
@@ -130,7 +130,8 @@ struct ws_renderer {
     FrameCounters* counters = nullptr;  // = &zero->counters
     SortScratch sort_depth, sort_tiles;
     DepthSortScratch dsort;          // range-adaptive three-pass depth sort (the default; WS_DEPTH_SORT=classic: sort_depth)
-    uint32_t* counts_sorted = nullptr;  // where the last frame's draw-ordered footprint tile counts are
+    uint32_t* fp_sorted = nullptr;  // where the last frame's draw-ordered footprint words are
+    int footprint_mode = FP_RECT_PACKED;  // of the current scratch (chosen by the viewport and WS_FOOTPRINT)
     uint32_t epoch = 0;
     uint32_t* sticky = nullptr;      // device error word that survives the per-frame memset (ws_renderer_errors)
 
@@ -150,7 +151,7 @@ struct ws_renderer {
         uint64_t generation = 0;   // scratch generation the graph was captured for
         uint32_t next = 0;
         bool valid = false;
-        uint32_t *sorted_idx = nullptr, *sorted_keys = nullptr, *counts_sorted = nullptr, *entries_sorted = nullptr;
+        uint32_t *sorted_idx = nullptr, *sorted_keys = nullptr, *fp_sorted = nullptr, *entries_sorted = nullptr;
     } fg;
     uint64_t scratch_generation = 0;
 
@@ -220,8 +221,8 @@ static void renderer_free_scratch(ws_renderer* r) {
     dfree(r->keys_b);
     dfree(r->vals_a);
     dfree(r->vals_b);
-    dfree(r->tcount_a);
-    dfree(r->tcount_b);
+    dfree(r->fpw_a);
+    dfree(r->fpw_b);
     dfree(r->dsort.tile_off);
     dfree(r->dsort.group_off);
     dfree(r->dsort.status);
@@ -271,8 +272,8 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     if ((rc = dmalloc(&r->keys_b, np))) return rc;
     if ((rc = dmalloc(&r->vals_a, np))) return rc;
     if ((rc = dmalloc(&r->vals_b, np))) return rc;
-    if ((rc = dmalloc(&r->tcount_a, np))) return rc;
-    if ((rc = dmalloc(&r->tcount_b, np))) return rc;
+    if ((rc = dmalloc(&r->fpw_a, np))) return rc;
+    if ((rc = dmalloc(&r->fpw_b, np))) return rc;
     if ((rc = dmalloc(&r->src_index, np))) return rc;
     if ((rc = dmalloc(&r->bin_offsets, np))) return rc;
     const size_t k1_words = (size_t)preprocess_blocks(n) + 1, bin_words = (size_t)bin_prefix_blocks(n) + 1;
@@ -321,7 +322,7 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
         WS_HIP(hipMemset(ds.status, 0, gw * sizeof(uint64_t)));
         ds.keys_alt = r->keys_b;
         ds.vals_alt = r->vals_b;
-        ds.aux_alt = r->tcount_b;
+        ds.aux_alt = r->fpw_b;
         ds.key_range = r->zero->key_range;
         ds.tickets = r->counters->sort_ticket;  // [0..2]; the tile sort uses [4..7]
         ds.error = &r->counters->overflow;
@@ -366,6 +367,11 @@ int ws_context_create(int hip_device, ws_context** out) {
     if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
     ctx->use_graph = env_int("WS_GRAPH", 0);
     ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
+    ctx->blend_dma = env_int("WS_BLEND_DMA", 0) ? 1 : 0;
+    {
+        const char* fm = std::getenv("WS_FOOTPRINT");  // ellipse | rect (default)
+        ctx->footprint = (fm && std::strcmp(fm, "ellipse") == 0) ? FP_ELLIPSE : FP_RECT_PACKED;
+    }
     ctx->num_cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
     ctx->blend_lds_pad_kb = env_int("WS_BLEND_LDS_PAD_KB", 0);
     if (ctx->blend_lds_pad_kb < 0 || ctx->blend_lds_pad_kb > 96) ctx->blend_lds_pad_kb = 0;
@@ -744,7 +750,7 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     KernelMarks* km = r->marks.active ? &r->marks : nullptr;
     if (km) km->begin(stream, true);
     if (r->timers) WS_HIP(hipEventRecord(r->ev[0], stream));
-    if ((rc = launch_preprocess(kp, kb, pc->compressed, stream))) return rc;
+    if ((rc = launch_preprocess(kp, kb, pc->compressed, r->footprint_mode, stream))) return rc;
     km_mark(km, pc->compressed ? "k_preprocess<compressed>" : "k_preprocess");
     if (r->timers) WS_HIP(hipEventRecord(r->ev[1], stream));
     if (km) {  // calibration interval between two kernels: the dispatch latency of a dependent launch
@@ -759,32 +765,32 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
         r->last_stream = stream;
         return WS_OK;
     }
-    // depth sort: V (key, store index) pairs, values start as iota (preprocess.wgsl:274), the splat's footprint tile
-    // count rides along as a companion value.  Default: the generic 4 x 8-bit sorter (GPURSSorter's shape);
+    // depth sort: V (key, store index) pairs, values start as iota (preprocess.wgsl:274), the splat's footprint word
+    // (packed tile rectangle, or tile count) rides along as a companion value.  Default: the generic 4 x 8-bit sorter (GPURSSorter's shape);
     // WS_DEPTH_SORT=adaptive: three range-adaptive digit passes (launch_depth_sort; measured: no faster).
     if (!r->ctx->depth_sort_adaptive) {
-        const bool carry = r->ctx->sort_algo != 1;  // (the one-sweep cross-check path gathers the counts afterwards)
+        const bool carry = r->ctx->sort_algo != 1;  // (the one-sweep cross-check path gathers the footprint words afterwards)
         uint32_t *sk = nullptr, *sv = nullptr;
         if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
                                     true, false, r->ctx->sort_algo, r->epoch, stream, &sk, &sv, km, "depth:", nullptr, 0,
-                                    RADIX_BITS, false, carry ? r->tcount_a : nullptr, carry ? r->tcount_b : nullptr)))
+                                    RADIX_BITS, false, carry ? r->fpw_a : nullptr, carry ? r->fpw_b : nullptr)))
             return rc;
         r->sorted_idx = sv;
         r->sorted_keys = sk;
         if (carry) {
-            r->counts_sorted = (sv == r->vals_a) ? r->tcount_a : r->tcount_b;  // where the payload went
+            r->fp_sorted = (sv == r->vals_a) ? r->fpw_a : r->fpw_b;  // where the payload went
         } else {
-            if ((rc = launch_gather_u32(r->tcount_a, sv, &r->counters->num_visible, pc->num_points, r->tcount_b, stream))) return rc;
-            km_mark(km, "k_gather_counts");
-            r->counts_sorted = r->tcount_b;
+            if ((rc = launch_gather_u32(r->fpw_a, sv, &r->counters->num_visible, pc->num_points, r->fpw_b, stream))) return rc;
+            km_mark(km, "k_gather_footprints");
+            r->fp_sorted = r->fpw_b;
         }
     } else {
-        if ((rc = launch_depth_sort(r->dsort, r->keys_a, r->vals_a, r->tcount_a, &r->counters->num_visible, pc->num_points,
+        if ((rc = launch_depth_sort(r->dsort, r->keys_a, r->vals_a, r->fpw_a, &r->counters->num_visible, pc->num_points,
                                     true, r->epoch, stream, km)))
             return rc;
         r->sorted_idx = r->vals_b;    // three passes: A -> B -> A -> B
         r->sorted_keys = r->keys_b;
-        r->counts_sorted = r->tcount_b;
+        r->fp_sorted = r->fpw_b;
     }
     if (r->timers) WS_HIP(hipEventRecord(r->ev[2], stream));
     if (cut == 2) {  // analysis only (WS_DEBUG_CUT): the image is NOT produced
@@ -797,7 +803,8 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     // tile binning
     BinBuffers bb;
     bb.sorted_idx = r->sorted_idx;
-    bb.counts_sorted = r->counts_sorted;
+    bb.fp_sorted = r->fp_sorted;
+    bb.footprint_mode = r->footprint_mode;
     bb.splats = r->splats;
     bb.vw = kp.cam.viewport[0];
     bb.vh = kp.cam.viewport[1];
@@ -885,6 +892,14 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     r->prepared = false;
     int rc = renderer_ensure_scratch(r, pc->num_points, args->viewport[0], args->viewport[1]);
     if (rc) return rc;
+    // the footprint word K1 leaves per splat (ws_internal.h): the packed rectangle while the viewport has at most 256
+    // binning tiles per axis, the rectangle's tile count beyond that; WS_FOOTPRINT=ellipse: the ellipse's own tile count
+    const int fp_mode = r->ctx->footprint == FP_ELLIPSE ? FP_ELLIPSE
+                        : ((r->tiles_x > RECT_PACKED_MAX_TILES_PER_AXIS || r->tiles_y > RECT_PACKED_MAX_TILES_PER_AXIS) ? FP_RECT_COUNT : FP_RECT_PACKED);
+    if (fp_mode != r->footprint_mode) {
+        renderer_free_graph(r);  // (a captured frame graph holds the other mode's kernels)
+        r->footprint_mode = fp_mode;
+    }
 
     K1Params kp;
     std::memset(&kp, 0, sizeof kp);
@@ -914,7 +929,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     kb.covars = pc->covars;
     kb.splats = r->splats;
     kb.keys = r->keys_a;
-    kb.tile_counts = r->tcount_a;
+    kb.footprints = r->fpw_a;
     kb.key_range = r->zero->key_range;
     kb.src_index = r->capture ? r->src_index : nullptr;
     kb.block_status = r->k1_status;
@@ -957,7 +972,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         WS_HIP(hipGraphGetNodes(graph, nullptr, &nn));
         std::vector<hipGraphNode_t> nodes(nn);
         WS_HIP(hipGraphGetNodes(graph, nodes.data(), &nn));
-        const void* k1_func = preprocess_kernel_func(pc->compressed);
+        const void* k1_func = preprocess_kernel_func(pc->compressed, r->footprint_mode);
         for (size_t i = 0; i < nn && !g.k1_node; ++i) {
             hipGraphNodeType ty;
             if (hipGraphNodeGetType(nodes[i], &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
@@ -980,7 +995,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         g.generation = r->scratch_generation;
         g.sorted_idx = r->sorted_idx;
         g.sorted_keys = r->sorted_keys;
-        g.counts_sorted = r->counts_sorted;
+        g.fp_sorted = r->fp_sorted;
         g.entries_sorted = r->entries_sorted;
         g.valid = true;
     }
@@ -996,7 +1011,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     g.used[slot] = true;
     r->sorted_idx = g.sorted_idx;
     r->sorted_keys = g.sorted_keys;
-    r->counts_sorted = g.counts_sorted;
+    r->fp_sorted = g.fp_sorted;
     r->entries_sorted = g.entries_sorted;
     r->prepared = true;
     r->prepared_pc = pc;
@@ -1030,6 +1045,7 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.format = (int)r->format;
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
     bp.lds_pad_kb = r->ctx->blend_lds_pad_kb;
+    bp.dma = r->ctx->blend_dma;
     bp.range_row_shift = 0;
     // Two 512-thread workgroups (32x16 halves) per 32x32 binning tile, both reading the tile's list.  Automatic: when the
     // frame has fewer binning tiles than the chip holds 1024-thread blend workgroups (two per CU) -- small viewports --

@@ -66,13 +66,29 @@ struct FrameZero {
     // uint2 tile_ranges[tiles] follows
 };
 
-// ---- binning footprint of a splat ----------------------------------------------------------------------------------
-// K1 stores, per visible splat, the NUMBER of binning tiles its kept ellipse reaches (footprint.h; 0 = none).  That
-// word rides through the depth sort with the splat index (sort.hip), so the binning prefix streams the counts in draw
-// order; k_bin_emit re-derives the tiles themselves from the 12 geometry bytes of the Splat record.  (Rounds 1-2 carried
-// the packed bounding rectangle, 8 bits per field: 256 tiles per axis at most and every tile of the rectangle listed.)
-// Tile coordinates are 16-bit (the blend packs tx | ty << 16): up to 65535 tiles per axis.
-constexpr uint32_t MAX_TILES_PER_AXIS = 65535u;
+// ---- binning footprint of a splat: the companion value of the depth sort ----------------------------------------
+// K1 stores one 32-bit word per visible splat that says which binning tiles the splat is listed in; it rides through the
+// depth sort with the splat index (sort.hip), so the binning prefix streams it in draw order.  Three forms:
+//   FP_RECT_PACKED (default)  the bounding rectangle of the kept ellipse, x0 | y0 << 8 | (w - 1) << 16 | (h - 1) << 24
+//                  in binning tiles: at most 256 tiles per axis (8192 px at the default 32-px tile); RECT_EMPTY = no
+//                  tile.  k_bin_emit derives a tile from the word alone.
+//   FP_RECT_COUNT  the NUMBER of tiles of the same rectangle; k_bin_emit re-derives the rectangle from the 12 geometry
+//                  bytes of the Splat record (footprint.h).  Taken automatically for viewports beyond 256 tiles per axis:
+//                  any target the reference can create (it asks for the adapter's own max_texture_dimension_2d,
+//                  src/lib.rs:99-110) is accepted, at the price of a slower emit kernel.
+//   FP_ELLIPSE     the number of tiles the kept ELLIPSE reaches (per tile row the exact column span, footprint.h):
+//                  15 % fewer entries on the 1 M / 1080p scene, but the span arithmetic costs more VALU time in K1 and
+//                  k_bin_emit than the entries cost downstream (profiles/r03/footprint_*) -- WS_FOOTPRINT=ellipse.
+enum FootprintMode { FP_RECT_PACKED = 0, FP_RECT_COUNT = 1, FP_ELLIPSE = 2 };
+constexpr uint32_t RECT_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t RECT_PACKED_MAX_TILES_PER_AXIS = 256u;
+constexpr uint32_t MAX_TILES_PER_AXIS = 65535u;  // tile coordinates are 16-bit (the blend packs tx | ty << 16)
+__host__ __device__ inline uint32_t rect_pack(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    return x0 | (y0 << 8) | ((x1 - x0) << 16) | ((y1 - y0) << 24);
+}
+__host__ __device__ inline uint32_t rect_tiles(uint32_t r) {
+    return r == RECT_EMPTY ? 0u : (((r >> 16) & 0xFFu) + 1u) * ((r >> 24) + 1u);
+}
 
 // ---- kernel parameter blocks (passed by value; the analogue of the reference's uniform buffers) ---
 struct K1Params {
@@ -206,14 +222,14 @@ struct K1Buffers {
     const uint8_t* covars;       // compressed: 12-B covariance codebook
     uint8_t* splats;             // [N] x 20 B  (pointcloud.rs:352-358 Splat)
     uint32_t* keys;              // [N] depth keys
-    uint32_t* tile_counts;       // [N] binning tiles the splat's kept ellipse reaches (footprint.h), 0 = none
+    uint32_t* footprints;        // [N] the splat's binning footprint word (FootprintMode)
     uint32_t* src_index;         // [N] or nullptr (capture mode)
     uint64_t* block_status;      // [blocks] epoch-tagged look-back words
     FrameCounters* counters;
     uint32_t* key_range;         // FrameZero::key_range
 };
-int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, hipStream_t stream);
-const void* preprocess_kernel_func(bool compressed);  // host-side kernel symbol (identifies K1's node in a captured graph)
+int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, int footprint_mode, hipStream_t stream);
+const void* preprocess_kernel_func(bool compressed, int footprint_mode);  // host-side kernel symbol (identifies K1's node in a captured graph)
 uint32_t preprocess_blocks(uint32_t n);
 
 // ---- binning + blend ----------------------------------------------------------------------------
@@ -221,8 +237,9 @@ constexpr int EMIT_TILE = SORT_TILE;  // tile entries produced per workgroup of 
 
 struct BinBuffers {
     const uint32_t* sorted_idx;  // [V] store indices in draw order (far -> near)
-    const uint32_t* counts_sorted; // [N] footprint tile counts by draw position (carried through the depth sort)
-    const uint8_t* splats;       // [V] x 20 B Splat records (k_bin_emit re-derives the footprint from words 0..2)
+    const uint32_t* fp_sorted;   // [N] footprint words by draw position (carried through the depth sort)
+    int footprint_mode;          // FootprintMode of those words
+    const uint8_t* splats;       // [V] x 20 B Splat records (modes other than FP_RECT_PACKED: k_bin_emit re-derives the footprint from words 0..2)
     float vw, vh;                // viewport in pixels, as the camera uniform holds it
     uint32_t tile_w_log2, tile_h_log2;
     uint32_t* offsets;           // [N] exclusive prefix of tiles touched, by draw position
@@ -256,6 +273,7 @@ struct BlendParams {
     int format;
     int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
     int lds_pad_kb;             // tuning: extra (unused) dynamic LDS per workgroup, limits workgroups per CU
+    int dma;                    // stage the Splat records with gfx950's LDS-DMA (global_load_lds) instead of through VGPRs
     uint32_t range_row_shift;   // 0, or 1 = "split" mode: tiles_y counts HALF binning tiles (32x16 px, 8 waves) and the list of
                                 //   blend tile (tx, ty) is the binning tile's (tx, ty >> 1): two workgroups share one list
     const FrameCounters* counters;  // this frame's counters: the error bits are folded into *sticky by the blend
@@ -296,6 +314,8 @@ struct ws_context {
     int debug_cut = 0;        // WS_DEBUG_CUT (analysis): 0 = whole frame
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
+    int footprint = 0;        // WS_FOOTPRINT=ellipse: FP_ELLIPSE (the default is FP_RECT_PACKED, FP_RECT_COUNT for wide viewports)
+    int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
     int blend_split = -1;     // WS_BLEND_SPLIT: 4x4 binning tiles composited by two 4x2 workgroups each; -1 = when tiles < 2 x CUs
     int num_cus = 256;
     int use_graph = 0;        // WS_GRAPH=1: prepare() on a real stream replays a captured frame graph instead of enqueueing 22
