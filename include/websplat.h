@@ -309,6 +309,15 @@ int ws_renderer_stage_times(ws_renderer* r, ws_stage_times* out);
  * Each time is a HIP-event interval = dispatch latency of a dependent launch + the kernel; the entry
  * "_empty_launch" (after the preprocess kernel) is an empty kernel recorded the same way (subtract it to compare with rocprofv3 durations). */
 int ws_renderer_kernel_times(ws_renderer* r, uint32_t capacity, ws_kernel_time* out, uint32_t* count);
+/* How render() composites (src/renderer.rs:63-67 PREMULTIPLIED_ALPHA_BLENDING on the pass's target):
+ *   WS_BLEND_FAST (default)      front to back with early termination, accumulators in f32, ONE rounding at the store;
+ *   WS_BLEND_TARGET_PRECISION    the reference's fixed-function blend literally: back to front over the clear colour,
+ *                                the destination rounded to the target's precision (f16 RNE / unorm8 RNE / f32) after
+ *                                EVERY splat, no early termination -- what bin/render.rs:154 (Rgba16Float) and
+ *                                bin/measure.rs:184 (Rgba8Unorm) write.  Several times slower; ws_render_views uses it.
+ * Takes effect at the next render(). */
+typedef enum ws_blend_mode { WS_BLEND_FAST = 0, WS_BLEND_TARGET_PRECISION = 1 } ws_blend_mode;
+int ws_renderer_set_blend_mode(ws_renderer* r, int mode);
 /* parity tooling: also record the original Gaussian index of every store slot (costs 4 B per visible splat) */
 int ws_renderer_enable_capture(ws_renderer* r, int enable);
 /* tuning: capacity of the (tile, splat) entry list; 0 = automatic. Takes effect at the next prepare. */
@@ -427,7 +436,9 @@ int ws_sorter_sort(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, const ui
                    void* stream);
 /* The same contract (record_sort / record_sort_indirect) through the renderer's depth-sort specialisation: three digit
  * passes whose width follows the range of the keys (typically 3 x 9 bits for a frame's depth keys instead of 4 x 8),
- * two launches per pass; d_aux (may be NULL) is a 4-byte companion that travels with the payload.  In place. */
+ * two launches per pass; d_aux (may be NULL) is a 4-byte companion that travels with the payload.  In place.
+ * d_keys must be 16-byte aligned (both entry points: the histogram kernels read the keys four at a time);
+ * WS_ERR_INVALID otherwise. */
 int ws_sorter_sort_depth(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, uint32_t* d_aux, const uint32_t* d_count,
                          uint32_t n, void* stream);
 /* GPURSSorter::test_sort (gpu_rs.rs:295-331): 8192 reversed f32 keys must come out ascending. 1 = pass */

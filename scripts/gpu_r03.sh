@@ -50,7 +50,7 @@ if [[ $WHAT == *ab* ]]; then
     for v in $VARIANTS; do
       N=${v%%=*}
       echo "== $W $N (${v#*=})" >> $OUT/ab.txt
-      env $(venv ${v#*=}) timeout 600 python scripts/tile_stats.py $W 2>&1 | grep -E "^view 0|consumed|kernel times" | head -3 >> $OUT/ab.txt
+      env $(venv ${v#*=}) timeout 600 python scripts/tile_stats.py $W 2>&1 | grep -E "^view 0|^  consumed|kernel times" | head -3 >> $OUT/ab.txt
       env $(venv ${v#*=}) timeout 600 python bench.py --steps $STEPS --warmup 30 --no-cpu-baseline --workload $W 2> $OUT/bench_${N}_$W.err | tail -1 > $OUT/bench_${N}_$W.json
       python - $OUT/bench_${N}_$W.json >> $OUT/ab.txt <<'PY'
 import json,sys

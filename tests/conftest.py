@@ -30,3 +30,18 @@ def ctx(ws):
     c = ws.Context(0)
     yield c
     c.close()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU runs: how many depth keys of the compared K1 frames were not bit-identical to the oracle's / the reference
+    shader's (tests/test_gpu_preprocess.py collects one entry per frame) -> gpurun_out/k1_key_report.json."""
+    mod = sys.modules.get("test_gpu_preprocess")
+    rep = getattr(mod, "KEY_REPORT", None) if mod else None
+    if rep:
+        import json
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        tot = {"frames": len(rep), "keys": sum(r["keys"] for r in rep), "differ": sum(r["differ"] for r in rep),
+               "max": max(r["max"] for r in rep)}
+        with open(os.path.join(out, "k1_key_report.json"), "w") as f:
+            json.dump({"total": tot, "frames": rep}, f, indent=1)

@@ -194,20 +194,23 @@ def k6_fragments():
 
 
 # ---- a whole frame: K1 -> stable sort by key -> instanced draw with premultiplied "over" ----------------------------------
-def frame():
+def frame(name="frame"):
     """preprocess.wgsl, then the draw of renderer.rs:240-283: instances in ascending key order (stable: equal keys keep
     their store order, gpu_rs.rs), vs_main / fs_main from source for every pixel centre inside an instance's quad, and
     the pipeline's blend state PREMULTIPLIED_ALPHA_BLENDING (renderer.rs:65: dst = src + dst * (1 - src.a), f32 here)
-    on a transparent target.  The kept disc (radius sqrt(2 CUTOFF) in screen_pos units) lies strictly inside the quad
+    on a target cleared to the case's background (transparent for `frame`, opaque for `frame_opaque`).  The kept disc (radius sqrt(2 CUTOFF) in screen_pos units) lies strictly inside the quad
     (half-width CUTOFF), so the rasteriser's edge rules never decide a pixel."""
-    res = k1_case("frame")
+    import wgsl_cases
+    res = k1_case(name)
     w, h = (int(x) for x in res["viewport"])
     splats, keys = res["splats"], res["keys"]
     order = np.argsort(keys, kind="stable").astype(np.uint32)
     m = W.Module(shader("gaussian.wgsl"))
     m.bind("points_2d", splats.tobytes())
     m.bind("indices", order.tobytes())
-    img = np.zeros((h, w, 4), dtype=np.float32)
+    background = np.array(wgsl_cases.FRAME_BACKGROUND[name], dtype=np.float32)
+    img = np.empty((h, w, 4), dtype=np.float32)
+    img[:] = background   # begin_render_pass: LoadOp::Clear(background)
     one = np.float32(1.0)
     nfrag = 0
     for inst in range(len(order)):
@@ -240,7 +243,7 @@ def frame():
                 src = np.array([c for c in o.c], dtype=np.float32)
                 img[y, x] = src + img[y, x] * (one - src[3])
                 nfrag += 1
-    res.update(order=order, image=img, fragments=np.uint32(nfrag))
+    res.update(order=order, image=img, fragments=np.uint32(nfrag), background=background)
     return res
 
 
@@ -305,7 +308,8 @@ for c in wgsl_cases.K1_CASES:
 for c in wgsl_cases.K1C_CASES:
     CASES["k1c_" + c] = (lambda c=c: k1c_case(c))
 CASES["k6_fragments"] = k6_fragments
-CASES["frame"] = frame
+for c in wgsl_cases.FRAME_CASES:
+    CASES[c] = (lambda c=c: frame(c))
 CASES["sort_small"] = lambda: sort_case(700, 11)
 CASES["sort_two_blocks"] = lambda: sort_case(5000, 12)
 

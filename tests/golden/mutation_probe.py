@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Are the committed WGSL vectors sensitive to the reference's shader text?  (build container only)
+
+Copies $WEBSPLAT_REFERENCE/src/shaders, applies ONE small mutation, re-runs the generator on the mutated text and counts
+the fixture files whose outputs change.  A vector set that a transposed T = W * J or a moved lambda2 floor leaves
+untouched does not pin those lines (round-2 verdict: with the identity-rotation camera nine of eleven K1 cases did not).
+
+    python tests/golden/mutation_probe.py            # all mutations, all K1 / K1c cases -> a table
+"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("WEBSPLAT_REFERENCE", "/root/reference")
+
+MUTATIONS = {
+    # name: (file, old text, new text, fixture prefix it should move)
+    "T=J*W": ("preprocess.wgsl", "let T = W * J;", "let T = J * W;", "k1_"),
+    "W not transposed": ("preprocess.wgsl", "let W = transpose(mat3x3<f32>(camera.view[0].xyz, camera.view[1].xyz, camera.view[2].xyz));",
+                         "let W = mat3x3<f32>(camera.view[0].xyz, camera.view[1].xyz, camera.view[2].xyz);", "k1_"),
+    "lambda2 floor 0.1->0.2": ("preprocess.wgsl", "let lambda2 = max(mid - radius, 0.1);", "let lambda2 = max(mid - radius, 0.2);", "k1_"),
+    "SH_C0 4th decimal": ("preprocess.wgsl", "0.28209479177387814", "0.28219479177387814", "k1_"),
+    "cull z <= 0 -> z < 0": ("preprocess.wgsl", "z <= 0.", "z < 0.", "k1_"),
+    "K1c T=J*W": ("preprocess_compressed.wgsl", "let T = W * J;", "let T = J * W;", "k1c_"),
+    "K1c cull z < 0 -> z <= 0": ("preprocess_compressed.wgsl", "z < 0.", "z <= 0.", "k1c_"),
+}
+
+
+def changed_files(mutation, only=None):
+    fname, old, new, prefix = MUTATIONS[mutation]
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copytree(os.path.join(REF, "src", "shaders"), os.path.join(td, "src", "shaders"))
+        path = os.path.join(td, "src", "shaders", fname)
+        text = open(path).read()
+        if text.count(old) < 1:
+            return None, "pattern not found in " + fname
+        open(path, "w").write(text.replace(old, new))
+        os.environ["WEBSPLAT_REFERENCE"] = td
+        for m in [k for k in sys.modules if k in ("gen_wgsl_golden",)]:
+            del sys.modules[m]
+        sys.path.insert(0, HERE)
+        import gen_wgsl_golden as gen
+        gen.REF = td
+        moved, same = [], []
+        for case, fn in gen.CASES.items():
+            if not case.startswith(prefix) or (only is not None and case not in only):
+                continue
+            z = np.load(os.path.join(HERE, "wgsl_%s.npz" % case))
+            try:
+                fresh = fn()
+                diff = any(not np.array_equal(np.asarray(fresh[k]), z[k]) for k in ("splats", "keys", "num_visible", "src_index"))
+            except Exception as e:  # noqa: BLE001  (a mutation may make a case fail outright: that is a change)
+                diff = True
+            (moved if diff else same).append(case)
+        return moved, same
+
+
+def main():
+    for name in (sys.argv[1:] or list(MUTATIONS)):
+        moved, same = changed_files(name)
+        if moved is None:
+            print(f"{name}: {same}")
+            continue
+        print(f"{name}: {len(moved)} of {len(moved) + len(same)} fixture files change; unchanged: {', '.join(same) or '-'}")
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,12 @@ class Scene:
         w, h = self.viewport
         return self.oracle.render(splats, order, w, h, background, target_mode), (splats, keys, src, order)
 
+    def proof(self, oracle_frame, background=(0.0, 0.0, 0.0, 0.0)):
+        """For image_close(proof=...): a lazily built BoundaryProof of the frame oracle_image() returned."""
+        splats, _, _, order = oracle_frame
+        w, h = self.viewport
+        return lambda: BoundaryProof(splats, order, w, h, background)
+
 
 def c1(ws, oracle, n=10_000, viewport=(800, 600), seed=0, sh_deg=3, **kw):
     rows = synth.scene_c1(n=n, seed=seed, sh_deg=sh_deg)

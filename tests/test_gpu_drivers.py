@@ -25,7 +25,8 @@ def _oracle_image_compressed(ws, oracle, gpc, pc, cam, viewport, max_deg):
                                    for n in ("color_dc", "color_rest", "opacity", "scaling_factor")})
     splats, keys, _ = oracle.preprocess_compressed(gpc.gaussians, gpc.sh_coefs, gpc.covars, oq, gpc.sh_deg, cu, rs)
     _, order = oracle.sort_pairs(keys, np.arange(len(keys), dtype=np.uint32))
-    return args, oracle.render(splats, order, viewport[0], viewport[1], (0, 0, 0, 0), 0)
+    proof = lambda: scenes.BoundaryProof(splats, order, viewport[0], viewport[1])  # noqa: E731
+    return args, oracle.render(splats, order, viewport[0], viewport[1], (0, 0, 0, 0), 0), proof
 
 
 def test_npz_scene_image_vs_oracle(ws, ctx, oracle, tmp_path):
@@ -42,7 +43,7 @@ def test_npz_scene_image_vs_oracle(ws, ctx, oracle, tmp_path):
         cj = synth.look_at_camera(0, [0.3, -0.2, -3.0], [0, 0, 0], viewport[0], viewport[1], 700.0, 700.0)
         cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, *viewport)
         cam.fit_near_far(pc.bbox())
-        args, ref = _oracle_image_compressed(ws, oracle, gpc, pc, cam, viewport, 2)
+        args, ref, proof = _oracle_image_compressed(ws, oracle, gpc, pc, cam, viewport, 2)
         assert (ref[..., 3] > 0).mean() > 0.05
         r = ws.GaussianRenderer(ctx, "rgba32float", 2, True)
         r.prepare(pc, args)
@@ -53,7 +54,7 @@ def test_npz_scene_image_vs_oracle(ws, ctx, oracle, tmp_path):
         assert st["overflow"] == 0 and st["num_visible"] > 10_000
         # exp() of the scaling factor comes from ocml on the GPU and glibc in the oracle: a few splats differ by an
         # f16 ulp in their axes, which the image tolerance absorbs
-        ok, msg, *_ = scenes.image_close(img, ref)
+        ok, msg, *_ = scenes.image_close(img, ref, proof=proof)
         assert ok, msg
         # The packed int8 SH records are laid out by the CLOUD's degree (27 B here), whatever degree the renderer was
         # created for: a default degree-3 renderer draws the same image (it must not read 48-B records), and a renderer

@@ -120,7 +120,11 @@ def test_c5_compressed_4k_vs_oracle(ws, ctx, oracle, tmp_path):
         assert len(keys) == st["num_visible"]
         _, order = oracle.sort_pairs(keys, np.arange(len(keys), dtype=np.uint32))
         ref = oracle.render(splats, order, viewport[0], viewport[1], (0, 0, 0, 0), 0)
-        ok, msg, *_ = scenes.image_close(img, ref)
+        ok, msg, mx, mean, nb = scenes.image_close(img, ref, proof=lambda: scenes.BoundaryProof(splats, order, *viewport))
+        _REPORT["c5/view1"] = {"gaussians": int(gpc.num_points), "viewport": list(viewport), "visible": int(len(keys)),
+                               "tile_entries": int(st["num_tile_entries"]),
+                               "f32_target_vs_oracle_f32": {"max_abs": mx, "mean_abs": mean, "boundary_pixels_proven": nb}}
+        _write_report()
         assert ok, msg
     finally:
         r.close()
@@ -288,9 +292,31 @@ def _full_parity(ws, ctx, oracle, tag, rows, cams, viewport):
             entry["unorm8_target_vs_oracle_unorm8_per_blend"] = _gap(img8, oracle.render(splats, order, w, h, (0, 0, 0, 0), 2))
             entry["f16_target_vs_oracle_f32"] = _gap(img16, ref)
             entry["unorm8_target_vs_oracle_f32"] = _gap(img8, ref)
+            # GATED: the target-precision blend mode (back to front, the destination rounded after every splat: what the
+            # reference's fixed-function blender leaves in an Rgba16Float / Rgba8Unorm target) against the oracle's
+            # per-blend-rounding modes, in units of the target's last place
+            strict = {}
+            for f, mode in (("rgba16float", 1), ("rgba8unorm", 2)):
+                rs[f].set_blend_mode("target")
+                rs[f].render(pc)
+                got = rs[f].download_target()
+                rs[f].set_blend_mode("fast")
+                # the blend alone: the oracle composites the LIBRARY's Splat records in the library's draw order (K1 and the
+                # sort have their own parity tests; an f16 ulp in a record would otherwise show up here as a flipped rounding)
+                fr = rs[f].download_frame()
+                want = oracle.render(fr["splats"], fr["sorted"], w, h, (0, 0, 0, 0), mode)
+                if mode == 1:
+                    lsb = scenes.half_ulp_diff(got.view(np.uint16), want.astype(np.float16).view(np.uint16)).astype(np.int64)
+                else:
+                    lsb = np.abs(got.astype(np.int64) - np.rint(want * 255.0).astype(np.int64))
+                strict[f] = {"max_lsb": int(lsb.max()), "values_off_by_1": int((lsb == 1).sum()),
+                             "values_off_by_more": int((lsb > 1).sum()), "values": int(lsb.size)}
+            entry["target_precision_blend_vs_oracle_per_blend"] = strict
             _REPORT[f"{tag}/view{vi}"] = entry
             _write_report()
             assert ok, (tag, vi, msg)
+            for f, g in strict.items():   # <= 1 LSB, and that for at most 1 value in 1000 (exp and FMA ordering flip a rounding)
+                assert g["max_lsb"] <= 1 and g["values_off_by_1"] <= 1e-3 * g["values"], (tag, vi, f, g)
             # the library's own f16 / unorm8 stores are the f32 image rounded once
             assert np.abs(img16 - imgs["rgba32float"]).max() <= 2.0 ** -10 * max(1.0, float(imgs["rgba32float"].max()))
             assert np.abs(img8 - np.clip(imgs["rgba32float"], 0, 1)).max() <= 0.5 / 255 + 1e-6

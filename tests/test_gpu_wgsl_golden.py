@@ -43,12 +43,12 @@ def test_k1_equals_the_reference_shader(ws, ctx, oracle, case):
         o = z["splats"].copy()
         oh = o.view(np.uint16).reshape(-1, 10)
         undefined = ((oh[:, :4] & 0x7FFF) > 0x7C00).any(axis=1)   # normalize((0,0)): indeterminate in WGSL
-        assert undefined.any() == (case in ("fade_in", "extremes"))
+        assert undefined.any() == (case in ("fade_in", "extremes", "kernel_0"))
         if undefined.any():
             assert frame["num_visible"] == len(z["keys"])
             gh = frame["splats"].view(np.uint16).reshape(-1, 10)
             ax = gh[undefined][:, :4].view(np.float16).astype(np.float32)
-            assert np.isfinite(ax).all() and (ax[:, 1] == 0).all() and (ax[:, 2] == 0).all() and (ax[:, 0] > 0).all()
+            assert np.isfinite(ax).all() and (ax[:, 1] == 0).all() and (ax[:, 2] == 0).all() and (ax[:, 0] >= 0).all()  # (kernel_0: a zero covariance has lambda1 = 0)
             oh[undefined, :4] = gh[undefined, :4]
         inexact = _compare(frame, o, z["keys"], z["src_index"])
         assert stats["overflow"] == 0 and inexact <= 0.02
@@ -129,11 +129,15 @@ def test_fragments_equal_the_reference_shader(ws, ctx, oracle):
     assert checked > 800, checked
 
 
-def test_frame_equals_the_reference_shaders(ws, ctx, oracle):
+@pytest.mark.parametrize("case", wgsl_cases.FRAME_CASES)
+def test_frame_equals_the_reference_shaders(ws, ctx, oracle, case):
     """The whole HIP frame (K1 -> depth sort -> binning -> tile sort -> blend) against the frame the reference's shaders
-    draw when executed from source (tests/golden/wgsl_frame.npz): the stated image tolerance, boundary pixels proven."""
-    z = load("frame")
-    sc = wgsl_cases.k1_scene(ws, oracle, "frame")
+    draw when executed from source (tests/golden/wgsl_frame*.npz; oblique camera; transparent and opaque clear colour):
+    the stated image tolerance, boundary pixels proven."""
+    z = load(case)
+    sc = wgsl_cases.k1_scene(ws, oracle, case)
+    background = tuple(float(x) for x in z["background"])
+    assert background == wgsl_cases.FRAME_BACKGROUND[case]
     w, h = sc.viewport
     pc = ws.PointCloud(ctx, sc.gpc)
     r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
@@ -141,10 +145,10 @@ def test_frame_equals_the_reference_shaders(ws, ctx, oracle):
         assert _bytes(sc.args.camera.uniform(sc.viewport)) == z["camera_uniform"].tobytes()
         assert _bytes(pc.settings_uniform(sc.args)) == z["settings_uniform"].tobytes()
         r.prepare(pc, sc.args)
-        r.render(pc)
+        r.render(pc, background=background)
         img = r.download_target()
         assert r.frame_stats()["num_visible"] == int(z["num_visible"])
-        proof = lambda: scenes.BoundaryProof(z["splats"], z["order"], w, h)  # noqa: E731
+        proof = lambda: scenes.BoundaryProof(z["splats"], z["order"], w, h, background)  # noqa: E731
         ok, msg, mx, mean, nb = scenes.image_close(img, z["image"], proof=proof)
         assert ok, msg
         assert mean < 2e-5, mean

@@ -151,12 +151,12 @@ def test_oracle_k1_equals_the_reference_shader(oracle, case):
     # interpreter gives NaN axes; it happens exactly where the screen covariance is isotropic (fade-in not started:
     # covariance = the dilation kernel alone).  The oracle and the library define the direction as (1, 0) there.
     undefined = ((o[:, :4] & 0x7FFF) > 0x7C00).any(axis=1)
-    assert undefined.any() == (case in ("fade_in", "extremes"))   # (extremes: splats far below a pixel, covariance = the kernel)
+    assert undefined.any() == (case in ("fade_in", "extremes", "kernel_0"))   # (extremes, kernel_0: splats far below a pixel: covariance = the kernel, or zero)
     assert np.array_equal(g[~undefined], o[~undefined])
     assert np.array_equal(g[undefined][:, 4:], o[undefined][:, 4:])
     if undefined.any():
         ax = g[undefined][:, :4].view(np.float16).astype(np.float32)
-        assert np.isfinite(ax).all() and (ax[:, 1] == 0).all() and (ax[:, 2] == 0).all() and (ax[:, 0] > 0).all()
+        assert np.isfinite(ax).all() and (ax[:, 1] == 0).all() and (ax[:, 2] == 0).all() and (ax[:, 0] >= 0).all()  # (kernel_0: a zero covariance has lambda1 = 0)
         assert 0 < undefined.sum() < len(keys)
     # the indirect-dispatch word the reference keeps beside the count (preprocess.wgsl:187, :276-279): one per 256 * 15
     # keys started, plus a safety block that is added only when Gaussian 0 is inside the clipping box (a quirk: the
@@ -237,11 +237,15 @@ def test_oracle_fragment_function_equals_the_reference_shader(oracle):
 
 
 # ---- a whole frame -----------------------------------------------------------------------------------------------------
-def test_oracle_frame_equals_the_reference_shaders(oracle):
+@pytest.mark.parametrize("case", wgsl_cases.FRAME_CASES)
+def test_oracle_frame_equals_the_reference_shaders(oracle, case):
     """preprocess.wgsl -> stable key sort -> vs_main / fs_main per covered pixel centre -> PREMULTIPLIED_ALPHA_BLENDING, all
-    from the reference's source (118 k kept fragments, 320x240), against ws_oracle.c's whole frame: the same draw order,
-    and an image that differs only by the rounding of `a` (measured max-abs 1.4e-6)."""
-    z = load("frame")
+    from the reference's source (320x240, oblique camera; `frame` on a transparent target, `frame_opaque` on an opaque clear
+    colour), against ws_oracle.c's whole frame: the same draw order, and an image that differs only by the rounding of `a`
+    (measured max-abs 1.4e-6)."""
+    z = load(case)
+    background = tuple(float(x) for x in z["background"])
+    assert background == wgsl_cases.FRAME_BACKGROUND[case]
     cu, rs = _oracle_structs(oracle, z)
     w, h = (int(x) for x in z["viewport"])
     g, sh = np.ascontiguousarray(z["gaussians"]), np.ascontiguousarray(z["sh_coefs"])
@@ -249,9 +253,9 @@ def test_oracle_frame_equals_the_reference_shaders(oracle):
     assert np.array_equal(splats, z["splats"]) and np.array_equal(keys, z["keys"])
     _, order = oracle.sort_pairs(keys, np.arange(len(keys), dtype=np.uint32))
     assert np.array_equal(order, z["order"])
-    img, _ = oracle.render_frame(g, sh, cu, rs, w, h)
+    img, _ = oracle.render_frame(g, sh, cu, rs, w, h, background)
     assert (z["image"][..., 3] > 0).mean() > 0.5
-    proof = lambda: scenes.BoundaryProof(splats, order, w, h)  # noqa: E731
+    proof = lambda: scenes.BoundaryProof(splats, order, w, h, background)  # noqa: E731
     ok, msg, mx, mean, nb = scenes.image_close(img, z["image"], max_abs=1e-5, mean_abs=1e-6, proof=proof)
     assert ok, msg
 
@@ -306,7 +310,7 @@ def test_oracle_sort_equals_the_reference_shader(oracle, case):
 # ---- the committed fixtures are what the generator produces ------------------------------------------------------------
 @pytest.mark.skipif(not os.path.isdir(os.environ.get("WEBSPLAT_REFERENCE", "/root/reference")),
                     reason="the reference checkout is only in the build container (never on the GPU box)")
-@pytest.mark.parametrize("case", ["k1_clip_box", "k1c_deg0", "k6_fragments"])
+@pytest.mark.parametrize("case", ["k1_clip_box", "k1_kernel_0", "k1_planes", "k1c_deg0", "k1c_deg3_planes", "k6_fragments"])
 def test_fixtures_are_reproducible_from_the_reference_source(case):
     """Where the reference checkout exists, re-running the generator on its shader text gives the committed vectors byte
     for byte (three of the cheap cases; the whole set takes four minutes: tests/golden/gen_wgsl_golden.py)."""
@@ -317,3 +321,29 @@ def test_fixtures_are_reproducible_from_the_reference_source(case):
     assert sorted(fresh.keys()) == sorted(z.files)
     for k in z.files:
         assert np.array_equal(np.asarray(fresh[k]), z[k]), k
+
+
+@pytest.mark.skipif(not os.path.isdir(os.environ.get("WEBSPLAT_REFERENCE", "/root/reference")),
+                    reason="the reference checkout is only in the build container (never on the GPU box)")
+def test_fixtures_notice_a_mutated_shader(monkeypatch):
+    """The vectors pin the shader text only if a small change of that text moves them (round-2 verdict: with an identity
+    view rotation a swapped T = W * J left nine of eleven K1 cases unchanged).  tests/golden/mutation_probe.py copies the
+    reference's shaders, applies one mutation and regenerates: every oblique-camera case must notice the swapped product,
+    the no-dilation case the moved lambda2 floor, the on-the-planes cases the changed comparison operators
+    (the whole table: profiles/r03/golden_mutation_probe.txt)."""
+    sys.path.insert(0, GOLDEN)
+    import mutation_probe as mp
+    ref = os.environ.get("WEBSPLAT_REFERENCE", "/root/reference")
+    try:
+        oblique = ["k1_default", "k1_sh1", "k1_sh2", "k1_mip_on", "k1_kernel_0p1", "k1_scaling_0p5", "k1_inside"]
+        moved, same = mp.changed_files("T=J*W", only=oblique)
+        assert sorted(moved) == sorted(oblique) and not same
+        moved, same = mp.changed_files("lambda2 floor 0.1->0.2", only=["k1_kernel_0", "k1_default"])
+        assert moved == ["k1_kernel_0"] and same == ["k1_default"]   # (0.3 px^2 of dilation keeps lambda2 above any such floor)
+        moved, _ = mp.changed_files("cull z <= 0 -> z < 0", only=["k1_planes"])
+        assert moved == ["k1_planes"]
+        moved, _ = mp.changed_files("K1c cull z < 0 -> z <= 0", only=["k1c_deg3_planes"])
+        assert moved == ["k1c_deg3_planes"]
+    finally:
+        os.environ["WEBSPLAT_REFERENCE"] = ref
+        sys.modules.pop("gen_wgsl_golden", None)

@@ -647,7 +647,8 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         if ((CAPTURE && p.debug_walked) && lane == 0) atomicMax(&s_dbg_max, dbg_walked - dbg_before);
         bool all_done;
         if (DMA) {  // __syncthreads_and() without the release fence that would drain the staging DMA
-            if (lane == 0 && __ballot(T >= T_MIN) != 0ull) s_alive[bpar] = 1u;
+            const bool wave_alive = __ballot(T >= T_MIN) != 0ull;  // (evaluated by ALL lanes, not behind `lane == 0 &&`)
+            if (lane == 0 && wave_alive) s_alive[bpar] = 1u;
             wg_barrier_keep_loads();
             all_done = s_alive[bpar] == 0u;
             bpar ^= 1u;
@@ -711,6 +712,7 @@ struct StagedSplat {
 
 __device__ __forceinline__ StagedSplat decode_splat(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4,
                                                     float W, float H, float qx_lo, float qy_lo, bool valid) {
+#pragma clang fp contract(off)  // (k_blend_strict: the oracle's setup_splat, operation by operation)
     StagedSplat s;
     const float v1x = h2f(w0), v1y = h2f(w0 >> 16), v2x = h2f(w1), v2y = h2f(w1 >> 16);
     const float m00 = v1x * W, m01 = v2x * W;
@@ -862,6 +864,77 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
             reinterpret_cast<uint32_t*>(row)[px] = q8(r) | (q8(g) << 8) | (q8(bch) << 16) | (q8(al) << 24);
         }
     }
+}
+
+// ---- k_blend_strict: the reference's blend, literally -------------------------------------------------------------
+// The render pass of the reference clears the target to the background and lets the fixed-function blender apply
+// PREMULTIPLIED_ALPHA_BLENDING (src/renderer.rs:63-67) once per splat, BACK TO FRONT, on a target of the pass's own
+// precision: Rgba16Float in bin/render.rs:154, Rgba8Unorm in bin/measure.rs:184, i.e. the destination is rounded to
+// f16 / unorm8 after EVERY splat.  k_blend rounds once, at the store (and stops early): closer to the exact integral,
+// but not what the reference's binaries write.  This variant (ws_renderer_set_blend_mode(.., WS_BLEND_TARGET_PRECISION);
+// the default of ws_render_views) walks each tile's list far -> near with no early-out and rounds the destination after
+// every splat the way the oracle's target modes do: dst = q(src + dst * (1 - src.a)), q = f16 RNE / unorm8 RNE / identity.
+// One wave per 8x8 quadrant (the shape of k_blend_q): lane = pixel, records broadcast with v_readlane; the quadrant test
+// is the padded bounding box -- the per-pixel test a <= 2*CUTOFF decides, exactly as gaussian.wgsl:59-66.
+// Throughput is not the point of this kernel (every entry of every list is walked).
+template <int FORMAT>
+__device__ __forceinline__ float quantize_target(float v) {
+    if (FORMAT == WS_FORMAT_RGBA16_FLOAT) return __half2float(__float2half_rn(v));
+    if (FORMAT == WS_FORMAT_RGBA8_UNORM) return rintf(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f) / 255.0f;
+    return v;
+}
+
+template <int FORMAT>
+__global__ __launch_bounds__(64) void k_blend_strict(const BlendParams p) {
+#pragma clang fp contract(off)  // the oracle's arithmetic: separate multiplies and adds
+    const uint32_t b = blockIdx.x;
+    if (b == 0 && threadIdx.x == 0 && p.sticky) {  // as in k_blend
+        const uint32_t bits = p.counters->overflow;
+        if (bits) atomicOr(p.sticky, bits);
+    }
+    const uint32_t xcd = b & 7u, j = b >> 3;
+    const uint32_t nq = p.qw * p.qh;
+    const uint32_t q = j % nq;
+    const uint32_t tile = (j / nq) * 8u + xcd;
+    if (tile >= p.tiles_x * p.tiles_y) return;
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int lane = threadIdx.x;
+    const uint32_t qx0 = tx * p.qw * 8u + (q % p.qw) * 8u, qy0 = ty * p.qh * 8u + (q / p.qw) * 8u;
+    const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < p.width && py < p.height;
+    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    const float qx_lo = (float)qx0 + 0.5f, qy_lo = (float)qy0 + 0.5f;
+    const float W = (float)p.width, H = (float)p.height;
+    float d0 = quantize_target<FORMAT>(p.background[0]), d1 = quantize_target<FORMAT>(p.background[1]),
+          d2 = quantize_target<FORMAT>(p.background[2]), d3 = quantize_target<FORMAT>(p.background[3]);
+    uint2 range = p.tile_ranges[tile];
+    range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
+    for (uint32_t lo = range.x; lo < range.y; lo += 64u) {  // far -> near: ascending position in the tile's list
+        const uint32_t e = lo + (uint32_t)lane;
+        const bool valid = e < range.y;
+        const uint32_t idx = p.entry_vals[valid ? e : range.y - 1u];
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx * 20);
+        const StagedSplat s = decode_splat(sp[0], sp[1], sp[2], sp[3], sp[4], W, H, qx_lo, qy_lo, valid);
+        unsigned long long rel = __ballot(s.touch);
+        while (rel) {
+            const int k = __ffsll((long long)rel) - 1;
+            rel &= rel - 1ull;
+            // gaussian.wgsl:59-66 with the oracle's operation order (oracle/ws_oracle.c wso_render)
+            const float dx = fx - bcast(s.cx, k), dy = fy - bcast(s.cy, k);
+            const float p0 = bcast(s.i00, k) * dx + bcast(s.i01, k) * dy;
+            const float p1 = bcast(s.i10, k) * dx + bcast(s.i11, k) * dy;
+            const float a = p0 * p0 + p1 * p1;
+            if (a <= CUT_A) {
+                const float bb = fminf(0.99f, expf(-a) * bcast(s.alpha, k));
+                const float om = 1.0f - bb;
+                d0 = quantize_target<FORMAT>(bcast(s.r, k) * bb + d0 * om);
+                d1 = quantize_target<FORMAT>(bcast(s.g, k) * bb + d1 * om);
+                d2 = quantize_target<FORMAT>(bcast(s.b, k) * bb + d2 * om);
+                d3 = quantize_target<FORMAT>(1.0f * bb + d3 * om);
+            }
+        }
+    }
+    if (inside) store_pixel<FORMAT>(p, px, py, d0, d1, d2, d3);
 }
 
 }  // namespace
@@ -1021,6 +1094,24 @@ static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
     const uint32_t ntiles = p.tiles_x * p.tiles_y;
     if (ntiles == 0) return WS_OK;
+    if (variant == 2) {  // WS_BLEND_TARGET_PRECISION: back to front, destination rounded after every splat
+        const uint32_t groups = ((ntiles + 7u) / 8u) * 8u * p.qw * p.qh;
+        switch (p.format) {
+            case WS_FORMAT_RGBA32_FLOAT:
+                hipLaunchKernelGGL(k_blend_strict<WS_FORMAT_RGBA32_FLOAT>, dim3(groups), dim3(64), 0, stream, p);
+                break;
+            case WS_FORMAT_RGBA16_FLOAT:
+                hipLaunchKernelGGL(k_blend_strict<WS_FORMAT_RGBA16_FLOAT>, dim3(groups), dim3(64), 0, stream, p);
+                break;
+            case WS_FORMAT_RGBA8_UNORM:
+                hipLaunchKernelGGL(k_blend_strict<WS_FORMAT_RGBA8_UNORM>, dim3(groups), dim3(64), 0, stream, p);
+                break;
+            default:
+                return fail(WS_ERR_INVALID, "blend: unknown colour format");
+        }
+        WS_HIP(hipGetLastError());
+        return WS_OK;
+    }
     if (variant == 1) {  // one wave per 8x8 quadrant, no LDS (cross-check)
         const uint32_t groups = ((ntiles + 7u) / 8u) * 8u * p.qw * p.qh;
         switch (p.format) {

@@ -129,7 +129,8 @@ struct ws_renderer {
     uint2* tile_ranges = nullptr;    // inside the zero arena
     FrameCounters* counters = nullptr;  // = &zero->counters
     SortScratch sort_depth, sort_tiles;
-    DepthSortScratch dsort;          // range-adaptive three-pass depth sort (the default; WS_DEPTH_SORT=classic: sort_depth)
+    DepthSortScratch dsort;          // range-adaptive three-pass depth sort (WS_DEPTH_SORT=adaptive only; the default is the
+                                     // generic 4 x 8-bit sorter, sort_depth); allocated only when that path is selected
     uint32_t* fp_sorted = nullptr;  // where the last frame's draw-ordered footprint words are
     int footprint_mode = FP_RECT_PACKED;  // of the current scratch (chosen by the viewport and WS_FOOTPRINT)
     uint32_t epoch = 0;
@@ -163,6 +164,7 @@ struct ws_renderer {
     uint32_t* entries_sorted = nullptr;
     hipStream_t last_stream = nullptr;
 
+    int blend_mode = WS_BLEND_FAST;  // ws_renderer_set_blend_mode
     bool capture = false;
     uint32_t* debug_consumed = nullptr;  // [tiles], capture mode only
     uint32_t* debug_walked = nullptr;    // [tiles][17], capture mode only
@@ -311,7 +313,8 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     r->sort_tiles.tickets = r->counters->sort_ticket + 4;
     r->sort_depth.error = &r->counters->overflow;
     r->sort_tiles.error = &r->counters->overflow;
-    {  // depth sort scratch: per-tile / per-group digit offsets, look-back words (zeroed once; epoch-tagged afterwards)
+    if (r->ctx->depth_sort_adaptive) {  // scratch of the cross-check depth sort: per-tile / per-group digit offsets,
+                                        // look-back words (zeroed once; epoch-tagged afterwards)
         DepthSortScratch& ds = r->dsort;
         ds.cap = n ? n : 1;
         const size_t gw = depth_sort_group_words();
@@ -577,21 +580,29 @@ int ws_pointcloud_create_from_ply_rows(ws_context* ctx, const float* rows, uint3
         pc->has_background = meta->has_background_color != 0;
         std::memcpy(pc->background, meta->background_color, sizeof pc->background);
     }
+    // Upload and decode run on a PRIVATE stream and are waited for with hipStreamSynchronize: no legacy-NULL-stream work
+    // (it would serialise against every renderer and break replays of a captured frame graph) and no
+    // device-wide synchronisation of other renderers' frames.
     float* d_rows = nullptr;
+    hipStream_t ls = nullptr;
     if (rc == WS_OK) {
         pc->device_bytes = (size_t)n * PC_PLANES * 16;
         const size_t row_bytes = (size_t)n * row_len * sizeof(float);
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&pc->planes), pc->device_bytes);
+        hipError_t e = hipStreamCreateWithFlags(&ls, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&pc->planes), pc->device_bytes);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rows), row_bytes);
-        if (e == hipSuccess) e = hipMemcpy(d_rows, rows, row_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows, row_bytes, hipMemcpyHostToDevice, ls);
         if (e != hipSuccess) rc = hip_fail(e, "ws_pointcloud_create_from_ply_rows: upload");
     }
-    if (rc == WS_OK) rc = launch_ply_decode(d_rows, n, sh_deg, pc->planes, nullptr);
+    if (rc == WS_OK) rc = launch_ply_decode(d_rows, n, sh_deg, pc->planes, ls);
     if (rc == WS_OK) {
-        hipError_t e = hipDeviceSynchronize();
+        hipError_t e = hipStreamSynchronize(ls);
         if (e != hipSuccess) rc = hip_fail(e, "ws_pointcloud_create_from_ply_rows: decode");
+    } else if (ls) {
+        (void)hipStreamSynchronize(ls);
     }
     if (d_rows) (void)hipFree(d_rows);
+    if (ls) (void)hipStreamDestroy(ls);
     if (rc != WS_OK) {
         ws_pointcloud_destroy(pc);
         return rc;
@@ -725,6 +736,14 @@ int ws_renderer_enable_timers(ws_renderer* r, int enable) {
         if (rc) return rc;
         r->marks.active = true;
     }
+    return WS_OK;
+}
+
+int ws_renderer_set_blend_mode(ws_renderer* r, int mode) {
+    if (!r) return fail(WS_ERR_INVALID, "ws_renderer_set_blend_mode: null renderer");
+    if (mode != WS_BLEND_FAST && mode != WS_BLEND_TARGET_PRECISION)
+        return fail(WS_ERR_INVALID, "ws_renderer_set_blend_mode: unknown mode");
+    r->blend_mode = mode;
     return WS_OK;
 }
 
@@ -939,7 +958,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     if (++r->epoch == 0) {
         WS_HIP(hipMemsetAsync(r->k1_status, 0, ((size_t)preprocess_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
         WS_HIP(hipMemsetAsync(r->bin_status, 0, ((size_t)bin_prefix_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
-        WS_HIP(hipMemsetAsync(r->dsort.status, 0, depth_sort_group_words() * sizeof(uint64_t), stream));
+        if (r->dsort.status) WS_HIP(hipMemsetAsync(r->dsort.status, 0, depth_sort_group_words() * sizeof(uint64_t), stream));
         if (r->ctx->sort_algo == 1) {
             WS_HIP(hipMemsetAsync(r->sort_depth.status, 0, 4 * (size_t)r->sort_depth.tiles * RADIX * sizeof(uint64_t), stream));
             WS_HIP(hipMemsetAsync(r->sort_tiles.status, 0, 4 * (size_t)r->sort_tiles.tiles * RADIX * sizeof(uint64_t), stream));
@@ -1053,7 +1072,7 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     // doubled staging costs more with frames in flight than the finer synchronisation saves.
     const bool split = r->ctx->blend_split >= 0 ? r->ctx->blend_split != 0
                                                  : (r->tiles_x * r->tiles_y < 2u * (uint32_t)r->ctx->num_cus);
-    if (split && bp.qw == 4 && bp.qh == 4 && !r->capture && r->ctx->blend_variant == 0) {
+    if (split && bp.qw == 4 && bp.qh == 4 && !r->capture && r->ctx->blend_variant == 0 && r->blend_mode == WS_BLEND_FAST) {
         bp.qh = 2;
         bp.tiles_y = (r->vh + 15u) / 16u;
         bp.range_row_shift = 1;
@@ -1070,9 +1089,9 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     if (km) km->begin(stream, false);
     if (r->timers) WS_HIP(hipEventRecord(r->ev[4], stream));
     if (r->ctx->debug_cut >= 1 && r->ctx->debug_cut <= 4) return WS_OK;  // analysis only
-    int rc = launch_blend(bp, r->ctx->blend_variant, stream);
+    int rc = launch_blend(bp, r->blend_mode == WS_BLEND_TARGET_PRECISION ? 2 : r->ctx->blend_variant, stream);
     if (rc) return rc;
-    km_mark(km, "k_blend");
+    km_mark(km, r->blend_mode == WS_BLEND_TARGET_PRECISION ? "k_blend_strict" : "k_blend");
     if (r->timers) {
         WS_HIP(hipEventRecord(r->ev[5], stream));
         r->ev_render_valid = true;
@@ -1098,10 +1117,12 @@ int ws_renderer_errors(ws_renderer* r, uint32_t* bits, uint32_t* entries_needed,
     if (!r || !bits) return fail(WS_ERR_INVALID, "ws_renderer_errors: null argument");
     *bits = 0;
     if (entries_needed) *entries_needed = 0;
-    if (!r->prepared) return WS_OK;  // nothing rendered yet
+    if (!r->sticky) return WS_OK;  // (never: allocated with the renderer)
+    // The sticky word outlives failed prepare() calls and scratch reallocations (both clear `prepared`): bits that earlier
+    // frames left must not disappear behind them.  Only the per-frame counter needs a prepared frame.
     WS_HIP(hipStreamSynchronize(r->last_stream));
     { int rc_ = copy_d2h(bits, r->sticky, sizeof(uint32_t), r->last_stream); if (rc_) return rc_; }
-    if (entries_needed) { int rc_ = copy_d2h(entries_needed, &r->counters->entries_needed, sizeof(uint32_t), r->last_stream); if (rc_) return rc_; }
+    if (entries_needed && r->prepared && r->counters) { int rc_ = copy_d2h(entries_needed, &r->counters->entries_needed, sizeof(uint32_t), r->last_stream); if (rc_) return rc_; }
     if (reset && *bits) {
         WS_HIP(hipMemsetAsync(r->sticky, 0, sizeof(uint32_t), r->last_stream));
         WS_HIP(hipStreamSynchronize(r->last_stream));
@@ -1309,6 +1330,9 @@ int ws_sorter_sort_depth(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, ui
                          uint32_t n, void* stream_v) {
     if (!s || !d_keys || !d_payload) return fail(WS_ERR_INVALID, "ws_sorter_sort_depth: null argument");
     if (n > s->ds.cap) return fail(WS_ERR_INVALID, "ws_sorter_sort_depth: n exceeds the sorter's capacity");
+    // k_dsort_hist reads the keys 16 bytes at a time: the same alignment ws_sorter_sort asks for
+    if ((reinterpret_cast<uintptr_t>(d_keys) & 15u) != 0)
+        return fail(WS_ERR_INVALID, "ws_sorter_sort_depth: keys must be 16-byte aligned");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (++s->epoch == 0) {
         WS_HIP(hipMemsetAsync(s->ds.status, 0, depth_sort_group_words() * sizeof(uint64_t), stream));
