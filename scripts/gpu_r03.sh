@@ -3,7 +3,8 @@
 # profiles/r03/.
 #   VARIANTS="name=libdir[,ENV=VALUE...] ..."   e.g. "base=lib_base rect=lib ellipse=lib,WS_FOOTPRINT=ellipse dma=lib,WS_BLEND_DMA=1"
 #   WHAT=tests,equal,ab,prof  WORKLOADS="hd1m c3"  TAG=a  STEPS=600
-#   tests  pytest -m gpu per variant of TEST_VARIANTS (default: the first of VARIANTS named in it; PYTEST_ARGS narrows it)
+#   tests  pytest -m gpu per variant of TEST_VARIANTS (PYTEST_ARGS_<variant> or PYTEST_ARGS narrow it)
+#          [was:] pytest -m gpu per variant of TEST_VARIANTS (default: the first of VARIANTS named in it; PYTEST_ARGS narrows it)
 #   equal  scripts/dump_images.py per variant, images compared bit for bit against the FIRST variant
 #   ab     per variant and workload: per-kernel event times of one frame (scripts/tile_stats.py) + bench.py frames/s
 #   prof   rocprofv3 --kernel-trace --stats of bench.py (one frame in flight) for the variants of PROF_VARIANTS
@@ -25,10 +26,11 @@ venv() {  # $1 = spec "lib[,K=V...]"
   [[ $spec == *,* ]] && rest=${spec#*,}
   echo "WEBSPLAT_LIB=$PWD/web-splat_amd/$lib/libwebsplat_hip.so ${rest//,/ }"
 }
-vspec() { for v in $VARIANTS; do [[ ${v%%=*} == $1 ]] && echo ${v#*=}; done; }
+vspec() { for v in $VARIANTS; do [[ ${v%%=*} == ${1:-} ]] && echo ${v#*=}; done; true; }
 if [[ $WHAT == *tests* ]]; then
   for N in ${TEST_VARIANTS:-$(echo $VARIANTS | awk '{print $NF}' | cut -d= -f1)}; do
-    env $(venv $(vspec $N)) timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -x ${PYTEST_ARGS:-} 2>&1 | tail -40 > $OUT/tests_gpu_$N.log
+    av=PYTEST_ARGS_$N   # per-variant pytest arguments (e.g. PYTEST_ARGS_dma="-k image"), else PYTEST_ARGS
+    env $(venv $(vspec $N)) timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -x ${!av:-${PYTEST_ARGS:-}} 2>&1 | tail -40 > $OUT/tests_gpu_$N.log
     echo "tests $N exit=${PIPESTATUS[0]}" >> $OUT/summary.txt; tail -3 $OUT/tests_gpu_$N.log >> $OUT/summary.txt
   done
   cp gpurun_out/parity_fullsize.json $OUT/ 2>/dev/null

@@ -85,8 +85,8 @@ def _small_scene(ws, oracle, tmp_path, n_cams=9):
 
 def test_render_views_writes_reference_pngs(ws, ctx, oracle, tmp_path):
     """bin/render.rs:33-128 + 187-246: per split, index-named PNGs; width capped at 1600 with the height rescaled by
-    truncation; pixels = clamp(f16) * 255 truncated.  Compared with the oracle's image of the same camera: the
-    reference blends in an f16 target, this library rounds once, so +-2 LSB (cut-off boundary pixels aside)."""
+    truncation; pixels = clamp(f16) * 255 truncated.  Compared with the oracle's image of the same camera blended at
+    f16 precision per splat, as the reference's Rgba16Float target is: +-1 LSB of the PNG (cut-off boundary pixels aside)."""
     ply, cj, cams = _small_scene(ws, oracle, tmp_path)
     pc = ws.PointCloud.load(ctx, ply)
     scene = ws.Scene.from_json(cj)
@@ -111,10 +111,12 @@ def test_render_views_writes_reference_pngs(ws, ctx, oracle, tmp_path):
         args = ws.SplattingArgs(camera=cam, viewport=(200, 150), max_sh_deg=3)
         cu = oracle.copy_struct(oracle.CameraUniform, cam.uniform((200, 150)))
         rs = oracle.copy_struct(oracle.SettingsUniform, pc.settings_uniform(args))
-        ref = oracle.render_frame(gpc.gaussians, gpc.sh_coefs, cu, rs, 200, 150)[0]
+        # the reference's target is Rgba16Float (bin/render.rs:154): the oracle blends at f16 precision per splat, and so
+        # does ws_render_views (target-precision blend mode)
+        ref = oracle.render_frame(gpc.gaussians, gpc.sh_coefs, cu, rs, 200, 150, (0, 0, 0, 0), 1)[0]
         want = oio.download_texture_u8(ref)
         d = np.abs(got.astype(np.int32) - want.astype(np.int32))
-        assert (d.max(axis=-1) > 2).sum() <= 4 and d.max() <= 5, (int(d.max()), int((d > 2).sum()))
+        assert (d.max(axis=-1) > 1).sum() <= 4 and d.max() <= 3, (int(d.max()), int((d > 1).sum()))
         assert got[..., 3].max() > 200
     finally:
         scene.close()

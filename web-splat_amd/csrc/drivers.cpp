@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -109,6 +110,13 @@ int ws_render_views(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* sc
     ws_renderer* r = nullptr;
     int rc = ws_renderer_create(ctx, WS_FORMAT_RGBA16_FLOAT, ws_pointcloud_sh_deg(pc), ws_pointcloud_compressed(pc), &r);
     if (rc) return rc;
+    // bin/render.rs:154 draws into an Rgba16Float target: the fixed-function blender rounds the destination to f16 after
+    // every splat.  The target-precision blend mode reproduces that (WS_RENDER_VIEWS_BLEND=fast: the throughput blend,
+    // one rounding at the store).
+    {
+        const char* bm = std::getenv("WS_RENDER_VIEWS_BLEND");
+        if (!(bm && std::strcmp(bm, "fast") == 0)) (void)ws_renderer_set_blend_mode(r, WS_BLEND_TARGET_PRECISION);
+    }
     void* target = nullptr;
     size_t target_bytes = 0;
     std::vector<uint8_t> rgba;

@@ -371,6 +371,7 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->use_graph = env_int("WS_GRAPH", 0);
     ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
     ctx->blend_dma = env_int("WS_BLEND_DMA", 0) ? 1 : 0;
+    ctx->blend_persist = env_int("WS_BLEND_PERSIST", 0) ? 1 : 0;
     {
         const char* fm = std::getenv("WS_FOOTPRINT");  // ellipse | rect (default)
         ctx->footprint = (fm && std::strcmp(fm, "ellipse") == 0) ? FP_ELLIPSE : FP_RECT_PACKED;
@@ -1065,6 +1066,9 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
     bp.lds_pad_kb = r->ctx->blend_lds_pad_kb;
     bp.dma = r->ctx->blend_dma;
+    bp.persist = r->ctx->blend_persist;
+    bp.num_cus = r->ctx->num_cus;
+    bp.queue = r->zero ? r->zero->blend_queue : nullptr;
     bp.range_row_shift = 0;
     // Two 512-thread workgroups (32x16 halves) per 32x32 binning tile, both reading the tile's list.  Automatic: when the
     // frame has fewer binning tiles than the chip holds 1024-thread blend workgroups (two per CU) -- small viewports --

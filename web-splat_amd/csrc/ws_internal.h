@@ -63,6 +63,7 @@ struct FrameZero {
     uint32_t depth_hist[4 * RADIX];
     uint32_t tile_hist[4 * RADIX];
     uint32_t key_range[KEY_RANGE_SLOTS * KEY_RANGE_STRIDE];
+    uint32_t blend_queue[2 * 8 * 16];  // k_blend_persist: per XCD a tile ticket and an exit counter, one 64-B line each
     // uint2 tile_ranges[tiles] follows
 };
 
@@ -274,6 +275,9 @@ struct BlendParams {
     int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
     int lds_pad_kb;             // tuning: extra (unused) dynamic LDS per workgroup, limits workgroups per CU
     int dma;                    // stage the Splat records with gfx950's LDS-DMA (global_load_lds) instead of through VGPRs
+    int persist;                // k_blend_persist: resident workgroups draw tiles from per-XCD queues (4x4 tiles only)
+    int num_cus;
+    uint32_t* queue;            // FrameZero::blend_queue
     uint32_t range_row_shift;   // 0, or 1 = "split" mode: tiles_y counts HALF binning tiles (32x16 px, 8 waves) and the list of
                                 //   blend tile (tx, ty) is the binning tile's (tx, ty >> 1): two workgroups share one list
     const FrameCounters* counters;  // this frame's counters: the error bits are folded into *sticky by the blend
@@ -315,6 +319,7 @@ struct ws_context {
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
     int footprint = 0;        // WS_FOOTPRINT=ellipse: FP_ELLIPSE (the default is FP_RECT_PACKED, FP_RECT_COUNT for wide viewports)
+    int blend_persist = 0;    // WS_BLEND_PERSIST=1: k_blend_persist
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
     int blend_split = -1;     // WS_BLEND_SPLIT: 4x4 binning tiles composited by two 4x2 workgroups each; -1 = when tiles < 2 x CUs
     int num_cus = 256;
