@@ -184,7 +184,7 @@ def init_distributed(a, torch):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world == 1 and a.gpus > 1:
         raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
-    backend = "gloo" if a.dry_run else "nccl"
+    backend = "gloo" if (a.dry_run or a.dist_backend == "gloo") else "nccl"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
     if world == 1:
@@ -193,7 +193,7 @@ def init_distributed(a, torch):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
     try:
-        kw = {} if a.dry_run else {"device_id": torch.device("cuda", local_rank)}
+        kw = {} if backend == "gloo" else {"device_id": torch.device("cuda", local_rank)}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     except Exception as e:  # noqa: BLE001
         if world > 1:
@@ -234,6 +234,14 @@ def main():
                          "(the views of a batch are independent; 1 = strictly one frame at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dist", action="store_true", help="skip the one-rank RCCL communicator at N = 1")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo: the collectives run on host tensors (tests: several ranks sharing ONE GPU, where RCCL refuses "
+                         "two ranks on a device); the rendering path is unchanged")
+    ap.add_argument("--single-device", action="store_true",
+                    help="every rank renders on cuda:0 (tests of the N-rank path on a one-GPU box)")
+    ap.add_argument("--check-shard-determinism", action="store_true",
+                    help="after the timed region every rank also renders the first view of EVERY rank's shard; rank 0 "
+                         "compares the bytes (a view's image must not depend on the rank that draws it)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU only (backend gloo): sharding, planning, barrier and reduction without rendering")
     a = ap.parse_args()
@@ -246,7 +254,9 @@ def main():
 
     import torch
     dist, rank, local_rank, world, dist_note = init_distributed(a, torch)
-    dev = "cpu" if a.dry_run else "cuda"
+    if a.single_device:
+        local_rank = 0
+    dev = "cpu" if (a.dry_run or a.dist_backend == "gloo") else "cuda"   # where the reduced tensors live
     if not a.dry_run:
         torch.cuda.set_device(local_rank)
 
@@ -359,6 +369,26 @@ def main():
         if a.dry_run:
             out["dry_run"] = True
             out["config"]["rank0_views"] = view_ids
+    if a.check_shard_determinism and not a.dry_run:
+        # SURVEY 7 view_shard_determinism: the first view of every rank's shard, drawn by EVERY rank on its own renderer
+        # scratch; the digests meet on rank 0 (off the timed path)
+        import hashlib
+        probe = [views_for_rank(len(views), q, world)[0] for q in range(world) if views_for_rank(len(views), q, world)]
+        digests = []
+        for vi in probe:
+            r.prepare(pc, views[vi])
+            r.render(pc, target_ptr=targets[0].data_ptr())
+            torch.cuda.synchronize()
+            digests.append(hashlib.sha256(targets[0].cpu().numpy().tobytes()).hexdigest())
+        got = [None] * world
+        if dist is not None:
+            dist.all_gather_object(got, digests)
+        else:
+            got = [digests]
+        if out is not None:
+            out["config"]["shard_determinism"] = {"views": probe, "ranks": world,
+                                                  "identical": all(g == got[0] for g in got),
+                                                  "distinct_images": len(set(got[0]))}
     if rank == 0 and not a.dry_run:
         analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world)
     barrier()

@@ -99,3 +99,34 @@ def test_sticky_error_bits_and_driver_retry(ws, ctx, oracle, tmp_path):
     finally:
         r.close()
         pc.close()
+
+
+def test_two_ranks_share_one_gpu_and_draw_identical_views():
+    """The N-rank path of bench.py with REAL frames on a one-GPU box: two processes launched exactly as the driver
+    launches the 8-GPU run (torch.distributed.run, one process per rank), both rendering their shard of the views on
+    cuda:0 (--single-device), the collectives on host tensors (--dist-backend gloo: RCCL refuses two ranks on one device).
+    Rank 1 draws the odd views, rank 0 the even ones; afterwards every rank draws the first view of every shard and rank 0
+    compares the digests: a view's image does not depend on the rank (view_shard_determinism).  The 1 -> 8 GPU
+    curve itself stays unmeasured on this box."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "30",
+           "--warmup", "6", "--views", "8", "--no-cpu-baseline", "--dist-backend", "gloo", "--single-device",
+           "--check-shard-determinism"]
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 30 and out["scaling"] == "weak" and out["value"] > 0
+    cfg = out["config"]
+    assert "gloo communicator, world size 2" in cfg["collective"] and cfg["error_bits"] == 0
+    sd = cfg["shard_determinism"]
+    assert sd["views"] == [0, 1] and sd["ranks"] == 2 and sd["identical"] is True and sd["distinct_images"] == 2
+    # whole-job value: both ranks' frames over the MAX elapsed
+    assert abs(out["value"] - 2 * 30 / (out["ms_per_step"] * 30 / 1e3)) < 1e-6 * out["value"]
