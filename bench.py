@@ -497,16 +497,20 @@ def analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world
     # --stats lists: the depth sort and the tile-id sort instantiate k_sort_scatter with different tile sizes)
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_frame"])
     dk = kernels[dom]
-    traffic = None
+    traffic = traffic_detail = None
     tpath = os.path.join(ROOT, "profiles", f"traffic_{a.workload}.json")
-    if os.path.exists(tpath):  # PMC pass of the same command (scripts/pmc_traffic.sh), bytes per launch
-        traffic = json.load(open(tpath)).get(dom)
+    if os.path.exists(tpath):  # PMC pass of the same command (scripts/pmc_traffic.py), bytes per launch
+        tj = json.load(open(tpath))
+        traffic = tj.get(dom)
+        # raw FETCH_SIZE / WRITE_SIZE, the kernel's access class and the calibrated read factor applied to it
+        traffic_detail = (tj.get("_detail") or {}).get(dom)
     valu = None
     vpath = os.path.join(ROOT, "profiles", f"valu_{a.workload}.json")
     if os.path.exists(vpath):  # PMC pass of the same command (scripts/pmc_valu.py): VALU issue accounting per launch
         valu = json.load(open(vpath)).get(dom)
     roofline = {"kernel": dom, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (dk["GBps"] / HBM_PEAK_GBS) if dk["GBps"] else None, "traffic": traffic,
+                "traffic_detail": traffic_detail,
                 "alg_bytes_per_launch": dk["alg_bytes_per_launch"], "avg_launch_ms": dk["avg_launch_ms"],
                 "launches_per_frame": dk["launches_per_frame"],
                 "event_interval_ms": dk["event_interval_ms"], "empty_launch_interval_ms": empty_ms,

@@ -97,6 +97,41 @@ def main():
         has &= px0 <= px1
         c = np.where(has, px1 // tile - px0 // tile + 1, 0).astype(np.int64)
         exact[sel] += c
+    # (c) the reference's ORIENTED QUAD (gaussian.wgsl:40-53: centre +- cut * v1 +- cut * v2, cut = sqrt(2 CUTOFF)), exact
+    #     polygon-vs-band x-range: no square roots per row, but looser than the ellipse (area 4 / pi)
+    r = np.sqrt(CUT_A)
+    a1x, a1y, a2x, a2y = m00 * r, m10 * r, m01 * r, m11 * r
+    vx = np.stack([cx + a1x + a2x, cx + a1x - a2x, cx - a1x - a2x, cx - a1x + a2x], 1)
+    vy = np.stack([cy + a1y + a2y, cy + a1y - a2y, cy - a1y - a2y, cy - a1y + a2y], 1)
+    quad = np.zeros(len(hv), dtype=np.int64)
+    for rr in range(maxh):
+        sel = idx[bh[idx] > rr]
+        if len(sel) == 0:
+            break
+        ty = ty0[sel] + rr
+        y0 = (ty * tile + 0.5)[:, None]
+        y1 = (np.minimum(ty * tile + tile - 1, H - 1) + 0.5)[:, None]
+        X, Y = vx[sel], vy[sel]
+        lo = np.full(len(sel), np.inf)
+        hi = np.full(len(sel), -np.inf)
+        inside = (Y >= y0) & (Y <= y1)
+        lo = np.minimum(lo, np.where(inside, X, np.inf).min(1))
+        hi = np.maximum(hi, np.where(inside, X, -np.inf).max(1))
+        for e in range(4):
+            xa, ya, xb, yb = X[:, e], Y[:, e], X[:, (e + 1) % 4], Y[:, (e + 1) % 4]
+            for yl in (y0[:, 0], y1[:, 0]):
+                with np.errstate(all="ignore"):
+                    t = (yl - ya) / (yb - ya)
+                ok_ = np.isfinite(t) & (t >= 0) & (t <= 1)
+                xi = xa + t * (xb - xa)
+                lo = np.minimum(lo, np.where(ok_, xi, np.inf))
+                hi = np.maximum(hi, np.where(ok_, xi, -np.inf))
+        px0 = np.maximum(np.ceil(lo - 0.5), 0)
+        px1 = np.minimum(np.floor(hi - 0.5), W - 1)
+        has = np.isfinite(lo) & (px0 <= px1)
+        c = np.where(has, np.minimum(px1 // tile, tx1[sel]) - np.maximum(px0 // tile, tx0[sel]) + 1, 0).astype(np.int64)
+        quad[sel] += np.maximum(c, 0)
+    print(f"D oriented quad {int(quad.sum())} ({quad.sum() / max(bbox_cnt.sum(), 1):.3f} of bbox)")
     V = int(vis.sum())
     Db, De = int(bbox_cnt.sum()), int(exact.sum())
     print(f"{name} {w}x{h} tile {tile}: visible {len(hv)}, with tiles {V}; D bbox {Db} ({Db / max(len(hv), 1):.2f}/splat), "

@@ -2,11 +2,18 @@
 
   python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
 
-Units and corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-reports exactly half of the bytes of a coalesced streaming read, so it is doubled.  Calibration on this code base:
-k_sort_tile_hist reads exactly 4*D bytes and reports 0.50 of them (dword loads, 256 B per wave instruction);
-k_blend writes exactly W*H*16 bytes and WRITE_SIZE reports 1.00 of them; kernels that write many short runs
-(radix scatter, emit) report ~1.2x their algorithmic write bytes (partial lines).
+Units and corrections.  FETCH_SIZE / WRITE_SIZE are in KiB.  What they count on gfx950 was CALIBRATED on kernels that move
+a known number of bytes (scripts/ubench/fetch_calib.hip, profiles/fetch_calibration.json, round 3):
+  * coalesced reads, 16 B or 4 B per lane alike: FETCH_SIZE reports exactly HALF of the bytes  -> read factor 2.0
+    (MI355X_MICROARCH.md, section HBM: 128-B requests tallied at 64 B);
+  * random gathers (4-B words, or the blend's 20-B Splat records): FETCH_SIZE is the number of 64-B lines requested x 64 B,
+    1.00 .. 1.10 of the lines the gathers touch -> read factor 1.0; the USEFUL bytes are 6 % (4 B) .. 28 % (20 B) of that;
+  * WRITE_SIZE is exact for coalesced stores and counts whole 32-B sectors for scattered ones (8 x the useful bytes of a
+    random 4-B store): it is the traffic, factor 1.0.
+Rounds 1-2 applied the factor 2 to every kernel; that doubled the blend's gather traffic (c3: "4.0 x the algorithmic
+bytes" was 2.4 x).  Each kernel label now carries its class and factor; a kernel that mixes a coalesced index stream with
+gathers (k_blend: 4 B of entry index per 20-B record) is priced as gathers, and the coalesced part it under-counts is
+bounded by `bytes_if_all_streaming`.
 """
 import csv
 import json
@@ -34,9 +41,9 @@ def label_of(name):
         kpt, bits = int(m.group(1)), int(m.group(3))
         which = "depth" if carry or (bits == 8 and m.group(2) == "false" and kpt == 4) else "tiles"
         return f"{which}:k_sort_scatter"
-    m = re.search(r"k_sort_tile_hist<(\d+)>", name)
-    if m:
-        return ("depth" if int(m.group(1)) == 4 else "sort") + ":k_sort_tile_hist"
+    m = re.search(r"k_sort_tile_hist<(\d+), (false|true)>", name)
+    if m:  # <KPT, KEY16>: 16-bit keys are the tile-id sort's
+        return ("tiles" if m.group(2) == "true" else "depth") + ":k_sort_tile_hist"
     return None
 
 
@@ -51,12 +58,23 @@ def per_label(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+# read factor by access pattern of the kernel's dominant fetch stream (profiles/fetch_calibration.json)
+GATHER_KERNELS = ("k_blend",)            # random 20-B record gathers dominate the fetches
+READ_FACTOR = {"stream": 2.0, "gather": 1.0}
+
+
 if __name__ == "__main__":
     fetch = per_label(sys.argv[1], "FETCH_SIZE")
     write = per_label(sys.argv[2], "WRITE_SIZE")
-    out = {}
+    out, detail = {}, {}
     for k in sorted(set(fetch) | set(write)):
-        out[k] = 2.0 * fetch.get(k, 0.0) * 1024.0 + write.get(k, 0.0) * 1024.0
-    detail = {k: {"FETCH_SIZE_KiB": fetch.get(k), "WRITE_SIZE_KiB": write.get(k)} for k in out}
-    json.dump({**out, "_raw": detail, "_formula": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 bytes per launch"}, open(sys.argv[3], "w"), indent=1)
+        cls = "gather" if k in GATHER_KERNELS else "stream"
+        f, w = fetch.get(k, 0.0) * 1024.0, write.get(k, 0.0) * 1024.0
+        out[k] = READ_FACTOR[cls] * f + w
+        detail[k] = {"FETCH_SIZE_bytes_raw": f, "WRITE_SIZE_bytes_raw": w, "class": cls, "read_factor": READ_FACTOR[cls],
+                     "write_factor": 1.0, "bytes": out[k], "bytes_if_all_streaming": 2.0 * f + w}
+    json.dump({**out, "_detail": detail,
+               "_formula": "read_factor * FETCH_SIZE + WRITE_SIZE (KiB -> bytes) per launch; read_factor 2.0 for coalesced "
+                           "streams, 1.0 for random gathers (calibrated: profiles/fetch_calibration.json)"},
+              open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out))

@@ -96,6 +96,20 @@ def test_sticky_error_bits_and_driver_retry(ws, ctx, oracle, tmp_path):
         assert r.errors()[0] & 1                               # sticky across the good frame ...
         assert r.errors(reset=True)[0] & 1 and r.errors()[0] == 0   # ... until reset
         assert np.array_equal(r.download_target(), good)
+        # the sticky word also survives a prepare() that FAILS (it used to read back as 0 until the next
+        # successful prepare, hiding the bits from ws_measure / bench.py)
+        r.set_tile_entry_capacity(max(4096, need // 3))
+        r.prepare(pc, sc.args)
+        r.render(pc)
+        assert r.errors()[0] & 1
+        import dataclasses
+        bad = dataclasses.replace(sc.args, viewport=(0, 0)) if dataclasses.is_dataclass(sc.args) else None
+        if bad is not None:
+            with pytest.raises(ws.WebSplatError):
+                r.prepare(pc, bad)
+            assert r.errors()[0] & 1
+        r.set_tile_entry_capacity(0)
+        r.errors(reset=True)
     finally:
         r.close()
         pc.close()

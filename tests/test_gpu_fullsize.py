@@ -219,6 +219,59 @@ def test_view_batch_matches_single_renders(ws, ctx, oracle):
         pc.close()
 
 
+@pytest.mark.parametrize("group,slots,compressed", [(2, 4, False), (4, 4, False), (4, 8, False), (3, 3, False), (2, 4, True)])
+def test_view_batch_shared_k1_draws_identical_frames(ws, oracle, monkeypatch, tmp_path, group, slots, compressed):
+    """WS_BATCH_K1=g: groups of g consecutive frames of a view batch share ONE K1 launch (k_preprocess_multi: the scene is
+    read once per group, each view's outputs go to its own renderer's scratch).  Per view nothing may change: the frames
+    are bit-identical to the ones a plain renderer draws, through ragged batch sizes (a tail that is drawn frame by
+    frame), repeated calls and views with different SH degrees."""
+    monkeypatch.setenv("WS_BATCH_K1", str(group))
+    c = ws.Context(0)
+    try:
+        if compressed:
+            a = synth.c3dgs_arrays(n=120_000, n_geometry=2048, n_sh=2048, seed=5, sh_deg=3, extent=1.0)
+            a["scaling_factor_zero_point"] = np.array(330, dtype=np.int32)
+            path = str(tmp_path / "b.npz")
+            synth.write_npz(path, a)
+            pc = ws.PointCloud.load_npz(c, path)
+            aabb = pc.bbox()
+            cams = synth.orbit_cameras(11, 640, 400, 700.0, 700.0, radius=3.0, height_off=0.5)
+        else:
+            sc = scenes.c2(ws, oracle, n=250_000, viewport=(640, 400))
+            pc = ws.PointCloud(c, sc.gpc)
+            aabb = sc.gpc.aabb
+            cams = synth.orbit_cameras(11, 640, 400, 640.0, 640.0)
+        views = []
+        for i, cj in enumerate(cams):
+            cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, 640, 400)
+            cam.fit_near_far(aabb)
+            views.append(ws.SplattingArgs(camera=cam, viewport=(640, 400), max_sh_deg=(3, 1, 2, 0)[i % 4]))
+        r = ws.GaussianRenderer(c, "rgba32float", 3, compressed)
+        alone = []
+        for v in views:
+            r.prepare(pc, v)
+            r.render(pc, background=(0.1, 0.2, 0.3, 1.0))
+            alone.append(r.download_target())
+        r.close()
+        batch = ws.ViewBatch(c, "rgba32float", 3, compressed, frames_in_flight=slots)
+        bufs = [c.malloc(640 * 400 * 16) for _ in views]
+        try:
+            for rep in range(2):   # 11 frames: full groups, then a tail; the second call starts mid-ring
+                batch.render(pc, views, bufs, 640 * 16, background=(0.1, 0.2, 0.3, 1.0))
+                batch.sync()
+                assert batch.errors() == 0
+                for i in range(len(views)):
+                    got = c.download(bufs[i], (400, 640, 4), np.float32)
+                    assert np.array_equal(got, alone[i]), (rep, i)
+        finally:
+            for b in bufs:
+                c.free(b)
+            batch.close()
+            pc.close()
+    finally:
+        c.close()
+
+
 # ---- full-size image parity on every BASELINE configuration -------------------------------------------------------
 # The f32 target is the parity configuration (the reference's bin/video.rs target); the tolerance is the stated one
 # (tests/scenes.py) and every pixel that uses the cut-off boundary allowance has to be PROVEN a boundary pixel

@@ -280,13 +280,41 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
                          void* const* d_targets, size_t row_pitch_bytes, const float background[4]) {
     if (!b || !pc || (!views && num_views) || (!d_targets && num_views)) return fail(WS_ERR_INVALID, "ws_view_batch_render: null argument");
     const size_t slots = b->renderers.size();
-    for (uint32_t i = 0; i < num_views; ++i) {
+    // WS_BATCH_K1=g: consecutive frames in groups of g share ONE K1 launch (the scene is read once per group instead of
+    // once per frame); groups are aligned to the slot ring, so with slots = 2 g one group's K1 overlaps the other's blends
+    size_t group = (size_t)b->ctx->batch_k1;
+    if (group > 1 && slots % group != 0) group = 1;
+    uint32_t i = 0;
+    while (i < num_views) {
         const size_t k = (size_t)(b->next % slots);
+        if (group > 1 && k % group == 0 && num_views - i >= group) {
+            ws_renderer* rs[K1_MAX_VIEWS];
+            hipStream_t ss[K1_MAX_VIEWS];
+            for (size_t j = 0; j < group; ++j) {
+                rs[j] = b->renderers[k + j];
+                ss[j] = b->streams[k + j];
+            }
+            int rc = ws_internal_prepare_group(rs, (uint32_t)group, pc, &views[i], ss);
+            if (rc == WS_ERR_UNSUPPORTED) {  // (timers, capture, a frame graph ...: every frame its own K1)
+                group = 1;
+                continue;
+            }
+            if (rc) return rc;
+            for (size_t j = 0; j < group; ++j) {
+                rc = ws_renderer_render(rs[j], pc, background, d_targets[i + j], row_pitch_bytes, ss[j]);
+                if (rc) return rc;
+            }
+            i += (uint32_t)group;
+            b->next += group;
+            continue;
+        }
+        // a ragged head (the ring is not at a group boundary) or tail, or no grouping: frame by frame
         // a target that an earlier frame of this call still writes must be on the same slot (same stream: ordered)
         int rc = ws_renderer_prepare(b->renderers[k], pc, &views[i], b->streams[k]);
         if (rc == WS_OK) rc = ws_renderer_render(b->renderers[k], pc, background, d_targets[i], row_pitch_bytes, b->streams[k]);
         if (rc) return rc;
         ++b->next;
+        ++i;
     }
     return WS_OK;
 }

@@ -171,6 +171,7 @@ struct ws_renderer {
     bool timers = false;
     KernelMarks marks;               // per-kernel events, timers level 2
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_group[2] = {nullptr, nullptr};  // grouped prepare of a view batch: "arena cleared" / "shared K1 done"
     bool ev_prepare_valid = false, ev_render_valid = false;
 };
 
@@ -372,6 +373,8 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
     ctx->blend_dma = env_int("WS_BLEND_DMA", 0) ? 1 : 0;
     ctx->blend_persist = env_int("WS_BLEND_PERSIST", 0) ? 1 : 0;
+    ctx->batch_k1 = env_int("WS_BATCH_K1", 1);
+    if (ctx->batch_k1 < 1 || ctx->batch_k1 > K1_MAX_VIEWS) ctx->batch_k1 = 1;
     {
         const char* fm = std::getenv("WS_FOOTPRINT");  // ellipse | rect (default)
         ctx->footprint = (fm && std::strcmp(fm, "ellipse") == 0) ? FP_ELLIPSE : FP_RECT_PACKED;
@@ -720,6 +723,8 @@ void ws_renderer_destroy(ws_renderer* r) {
     dfree(r->sticky);
     for (auto& e : r->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : r->ev_group)
+        if (e) (void)hipEventDestroy(e);
     r->marks.destroy();
     delete r;
 }
@@ -762,20 +767,27 @@ int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries) {
 
 // The frame's launch sequence behind prepare(): reset -> K1 -> depth sort -> binning -> tile-id sort.  Enqueued launch
 // by launch, or once under stream capture (ws_renderer_prepare replays the captured graph afterwards).
-static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params& kp, const K1Buffers& kb, hipStream_t stream) {
+// phase: FRAME_ALL = the whole sequence; FRAME_CLEAR = the arena memset only, FRAME_REST = everything behind K1 (a view
+// batch runs K1 for several renderers in ONE launch between the two: ws_internal_prepare_group).
+enum FramePhase { FRAME_ALL = 0, FRAME_CLEAR = 1, FRAME_REST = 2 };
+static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params& kp, const K1Buffers& kb, hipStream_t stream,
+                         int phase = FRAME_ALL) {
     int rc;
-    // GPURSSorter::record_reset_indirect_buffer (gpu_rs.rs:720-727): keys_size = 0, dispatch = 0 -- here ONE
-    // memset clears the counters, every ticket, both sorts' digit histograms and the tile ranges
-    WS_HIP(hipMemsetAsync(r->zero, 0, r->zero_bytes, stream));
     KernelMarks* km = r->marks.active ? &r->marks : nullptr;
-    if (km) km->begin(stream, true);
-    if (r->timers) WS_HIP(hipEventRecord(r->ev[0], stream));
-    if ((rc = launch_preprocess(kp, kb, pc->compressed, r->footprint_mode, stream))) return rc;
-    km_mark(km, pc->compressed ? "k_preprocess<compressed>" : "k_preprocess");
-    if (r->timers) WS_HIP(hipEventRecord(r->ev[1], stream));
-    if (km) {  // calibration interval between two kernels: the dispatch latency of a dependent launch
-        if ((rc = launch_empty(stream))) return rc;
-        km_mark(km, "_empty_launch");
+    if (phase != FRAME_REST) {
+        // GPURSSorter::record_reset_indirect_buffer (gpu_rs.rs:720-727): keys_size = 0, dispatch = 0 -- here ONE
+        // memset clears the counters, every ticket, both sorts' digit histograms and the tile ranges
+        WS_HIP(hipMemsetAsync(r->zero, 0, r->zero_bytes, stream));
+        if (phase == FRAME_CLEAR) return WS_OK;
+        if (km) km->begin(stream, true);
+        if (r->timers) WS_HIP(hipEventRecord(r->ev[0], stream));
+        if ((rc = launch_preprocess(kp, kb, pc->compressed, r->footprint_mode, stream))) return rc;
+        km_mark(km, pc->compressed ? "k_preprocess<compressed>" : "k_preprocess");
+        if (r->timers) WS_HIP(hipEventRecord(r->ev[1], stream));
+        if (km) {  // calibration interval between two kernels: the dispatch latency of a dependent launch
+            if ((rc = launch_empty(stream))) return rc;
+            km_mark(km, "_empty_launch");
+        }
     }
 
     const int cut = r->ctx->debug_cut;
@@ -888,7 +900,10 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     return WS_OK;
 }
 
-int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatting_args* args, void* stream_v) {
+// Validation, scratch, uniforms, buffers and the frame's look-back epoch: everything of prepare() in front of the first
+// launch.  Shared by ws_renderer_prepare and the view batch's grouped prepare.
+static int prepare_setup(ws_renderer* r, const ws_pointcloud* pc, const ws_splatting_args* args, hipStream_t stream,
+                         K1Params* kp_out, K1Buffers* kb_out) {
     if (!r || !pc || !args) return fail(WS_ERR_INVALID, "ws_renderer_prepare: null argument");
     if (pc->compressed != r->compressed)
         return fail(WS_ERR_INVALID, "ws_renderer_prepare: renderer and point cloud disagree on `compressed`");
@@ -908,7 +923,6 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         return fail(WS_ERR_INVALID, "ws_renderer_prepare: max_sh_deg exceeds the renderer's SH layout degree");
     if (pc->compressed && pc->sh_deg > r->sh_deg)
         return fail(WS_ERR_INVALID, "ws_renderer_prepare: compressed point cloud has a higher SH degree than the renderer was created for");
-    hipStream_t stream = static_cast<hipStream_t>(stream_v);
     r->prepared = false;
     int rc = renderer_ensure_scratch(r, pc->num_points, args->viewport[0], args->viewport[1]);
     if (rc) return rc;
@@ -967,6 +981,17 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         r->epoch = 1;
     }
     kp.epoch = r->epoch;
+    *kp_out = kp;
+    *kb_out = kb;
+    return WS_OK;
+}
+
+int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatting_args* args, void* stream_v) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    K1Params kp;
+    K1Buffers kb;
+    int rc = prepare_setup(r, pc, args, stream, &kp, &kb);
+    if (rc) return rc;
     const int cut_mode = r->ctx->debug_cut;
     // A captured frame graph (one hipGraphLaunch + one kernel-argument update instead of 22 launches + a memset on the host)
     // when the caller gave a real stream and no per-launch instrumentation is on.  The legacy NULL stream cannot be captured.
@@ -1038,6 +1063,57 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     r->last_stream = stream;
     return WS_OK;
 }
+
+}  // extern "C"
+
+// prepare() for a GROUP of renderers drawing different views of ONE scene (a view batch): each renderer's frame runs on
+// its own stream as usual, but K1 runs ONCE for the whole group (k_preprocess_multi: the scene is read from HBM once
+// instead of once per view), on the first renderer's stream, between "every arena is cleared" and "the rest of every
+// frame".  Returns WS_ERR_UNSUPPORTED (nothing enqueued, nothing changed) when the renderers cannot share a launch; the
+// caller then prepares them one by one.
+int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_pointcloud* pc, const ws_splatting_args* views,
+                              hipStream_t const* streams) {
+    if (!rs || !pc || !views || !streams || n < 2 || n > (uint32_t)K1_MAX_VIEWS) return WS_ERR_UNSUPPORTED;
+    for (uint32_t i = 0; i < n; ++i) {
+        ws_renderer* r = rs[i];
+        if (!r || !streams[i] || r->ctx != rs[0]->ctx || r->compressed != pc->compressed || r->timers || r->marks.active ||
+            r->capture || r->ctx->use_graph || r->ctx->debug_cut || r->ctx->sort_algo != 0 || r->ctx->depth_sort_adaptive)
+            return WS_ERR_UNSUPPORTED;
+        for (uint32_t j = 0; j < i; ++j)
+            if (rs[j] == r || streams[j] == streams[i]) return WS_ERR_UNSUPPORTED;
+    }
+    K1Params kp[K1_MAX_VIEWS];
+    K1Buffers kb[K1_MAX_VIEWS];
+    int rc;
+    for (uint32_t i = 0; i < n; ++i) {
+        if ((rc = prepare_setup(rs[i], pc, &views[i], streams[i], &kp[i], &kb[i]))) return rc;
+        for (int e = 0; e < 2; ++e)
+            if (!rs[i]->ev_group[e]) WS_HIP(hipEventCreateWithFlags(&rs[i]->ev_group[e], hipEventDisableTiming));
+    }
+    for (uint32_t i = 1; i < n; ++i)
+        if (rs[i]->footprint_mode != rs[0]->footprint_mode) {  // (cannot happen within one batch: same viewport class)
+            for (uint32_t k = 0; k < n; ++k)  // fall back in place: the set-up is done, finish every frame on its own
+                if ((rc = enqueue_frame(rs[k], pc, kp[k], kb[k], streams[k]))) return rc;
+            return WS_OK;
+        }
+    // every renderer's arena is cleared on its own stream (behind its previous frame); the shared K1 waits for all of them
+    for (uint32_t i = 0; i < n; ++i) {
+        if ((rc = enqueue_frame(rs[i], pc, kp[i], kb[i], streams[i], FRAME_CLEAR))) return rc;
+        if (i > 0) {
+            WS_HIP(hipEventRecord(rs[i]->ev_group[0], streams[i]));
+            WS_HIP(hipStreamWaitEvent(streams[0], rs[i]->ev_group[0], 0));
+        }
+    }
+    if ((rc = launch_preprocess_multi(kp, kb, n, pc->compressed, rs[0]->footprint_mode, streams[0]))) return rc;
+    WS_HIP(hipEventRecord(rs[0]->ev_group[1], streams[0]));
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i > 0) WS_HIP(hipStreamWaitEvent(streams[i], rs[0]->ev_group[1], 0));
+        if ((rc = enqueue_frame(rs[i], pc, kp[i], kb[i], streams[i], FRAME_REST))) return rc;
+    }
+    return WS_OK;
+}
+
+extern "C" {
 
 int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float background[4], void* d_rgba_out,
                        size_t row_pitch_bytes, void* stream_v) {

@@ -230,6 +230,15 @@ struct K1Buffers {
     uint32_t* key_range;         // FrameZero::key_range
 };
 int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, int footprint_mode, hipStream_t stream);
+// K1 of up to K1_MAX_VIEWS views of ONE scene in one launch (preprocess.hip k_preprocess_multi): the scene is read once
+constexpr int K1_MAX_VIEWS = 4;
+struct K1MultiArgs {
+    K1Params p[K1_MAX_VIEWS];
+    K1Buffers b[K1_MAX_VIEWS];
+    uint32_t nv;
+};
+int launch_preprocess_multi(const K1Params* p, const K1Buffers* b, uint32_t nv, bool compressed, int footprint_mode,
+                            hipStream_t stream);
 const void* preprocess_kernel_func(bool compressed, int footprint_mode);  // host-side kernel symbol (identifies K1's node in a captured graph)
 uint32_t preprocess_blocks(uint32_t n);
 
@@ -308,6 +317,12 @@ float host_f16_to_f32(uint16_t h);
 
 }  // namespace ws
 
+// grouped prepare of a view batch (ws_api.cpp): K1 once for up to K1_MAX_VIEWS renderers / views of one scene
+struct ws_renderer;
+struct ws_pointcloud;
+int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_pointcloud* pc, const ws_splatting_args* views,
+                              hipStream_t const* streams);
+
 // opaque handle definitions -------------------------------------------------------------------------
 struct ws_context {
     int device = 0;
@@ -319,6 +334,7 @@ struct ws_context {
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
     int footprint = 0;        // WS_FOOTPRINT=ellipse: FP_ELLIPSE (the default is FP_RECT_PACKED, FP_RECT_COUNT for wide viewports)
+    int batch_k1 = 1;         // WS_BATCH_K1=n: a view batch runs K1 once for groups of n frames (1 = every frame its own K1)
     int blend_persist = 0;    // WS_BLEND_PERSIST=1: k_blend_persist
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
     int blend_split = -1;     // WS_BLEND_SPLIT: 4x4 binning tiles composited by two 4x2 workgroups each; -1 = when tiles < 2 x CUs
