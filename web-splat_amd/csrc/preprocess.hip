@@ -780,8 +780,15 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess_multi
     for (int v = 0; v < K1_MAX_VIEWS; ++v)
         if ((uint32_t)v < nv) deg_max = max(deg_max, a.p[v].rs.max_sh_deg);
     constexpr uint32_t ANY = (1u << 0) | (1u << K1_ITEMS) | (1u << (2 * K1_ITEMS)) | (1u << (3 * K1_ITEMS));
-    auto store = [&](int v, int it, const SplatOut& so) {
-        const uint32_t slot = s_base[v] + s_cnt[v][it][wave] + ((rank_pack[v] >> (8 * it)) & 0xFFu);
+    // The loop over the views is NOT unrolled around the back-end maths: four inlined copies per item made 18 k
+    // instructions (146 KB of code against a 64-KB instruction cache) and the launch slower than four single-view ones.
+    // `v` is uniform, so the per-view values come from kernel arguments / LDS by index and the rank word by a select.
+    auto rank_of = [&](uint32_t v, int it) -> uint32_t {
+        const uint32_t w = v == 0u ? rank_pack[0] : (v == 1u ? rank_pack[1] : (v == 2u ? rank_pack[2] : rank_pack[3]));
+        return (w >> (8 * it)) & 0xFFu;
+    };
+    auto store = [&](uint32_t v, int it, const SplatOut& so) {
+        const uint32_t slot = s_base[v] + s_cnt[v][it][wave] + rank_of(v, it);
         uint32_t* sp = reinterpret_cast<uint32_t*>(a.b[v].splats + (size_t)slot * 20);
         sp[0] = so.w[0];
         sp[1] = so.w[1];
@@ -807,9 +814,9 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess_multi
 #pragma unroll
             for (int u = 0; u < K1_BACK_GROUP; ++u) {
                 const int it = grp + u;
-#pragma unroll
-                for (int v = 0; v < K1_MAX_VIEWS; ++v) {
-                    if ((uint32_t)v < nv && (vis_bits & (1u << (v * K1_ITEMS + it)))) {
+#pragma unroll 1
+                for (uint32_t v = 0; v < nv; ++v) {
+                    if (vis_bits & (1u << (v * K1_ITEMS + it))) {
                         SplatOut so;
                         k1_back_math<FPMODE>(a.p[v], fr[it], rb[u], &so);
                         store(v, it, so);
@@ -820,9 +827,9 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess_multi
     } else {
 #pragma unroll
         for (int it = 0; it < K1_ITEMS; ++it)
-#pragma unroll
-            for (int v = 0; v < K1_MAX_VIEWS; ++v)
-                if ((uint32_t)v < nv && (vis_bits & (1u << (v * K1_ITEMS + it)))) {
+#pragma unroll 1
+            for (uint32_t v = 0; v < nv; ++v)
+                if (vis_bits & (1u << (v * K1_ITEMS + it))) {
                     SplatOut so;
                     k1_back_compressed<FPMODE>(a.p[v], a.b[v], fr[it], &so);
                     store(v, it, so);

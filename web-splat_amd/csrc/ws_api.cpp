@@ -1106,6 +1106,8 @@ int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_point
     }
     if ((rc = launch_preprocess_multi(kp, kb, n, pc->compressed, rs[0]->footprint_mode, streams[0]))) return rc;
     WS_HIP(hipEventRecord(rs[0]->ev_group[1], streams[0]));
+    // (Measured and removed: starting the frames of a group one after another behind events, so that they do not run the
+    // same stage in lock-step -- 3781 instead of 5155 frames/s; every cross-stream wait costs more than the lock-step does.)
     for (uint32_t i = 0; i < n; ++i) {
         if (i > 0) WS_HIP(hipStreamWaitEvent(streams[i], rs[0]->ev_group[1], 0));
         if ((rc = enqueue_frame(rs[i], pc, kp[i], kb[i], streams[i], FRAME_REST))) return rc;
