@@ -35,12 +35,14 @@ def label_of(name):
         return "depth:k_dsort_hist"
     if "k_dsort_scatter" in name:
         return "depth:k_dsort_scatter"
-    m = re.search(r"k_sort_scatter<(?:false|true), (\d+), (false|true), (\d+)(?:, (false|true))?>", name)
-    if m:  # <LOOKBACK, KPT, RANGES, BITS, CARRY>: the depth sort carries the tile rectangles (CARRY); the tile-id sort does not
-        carry = m.group(4) == "true"
-        kpt, bits = int(m.group(1)), int(m.group(3))
-        which = "depth" if carry or (bits == 8 and m.group(2) == "false" and kpt == 4) else "tiles"
+    m = re.search(r"k_sort_scatter<(false|true), (\d+), (false|true), (\d+), (false|true)(?:, (false|true))?>", name)
+    if m:  # <LOOKBACK, KPT, RANGES, BITS, CARRY, KEY16>: the depth sort carries the footprint words (CARRY) with 32-bit keys;
+        # the tile-id sort has 16-bit keys and its last pass records the tile ranges
+        carry, key16, ranges = m.group(5) == "true", m.group(6) == "true", m.group(3) == "true"
+        which = "tiles" if (key16 or ranges) and not carry else "depth"
         return f"{which}:k_sort_scatter"
+    if "k_sort_col_scan" in name:
+        return "k_sort_col_scan"
     m = re.search(r"k_sort_tile_hist<(\d+), (false|true)>", name)
     if m:  # <KPT, KEY16>: 16-bit keys are the tile-id sort's
         return ("tiles" if m.group(2) == "true" else "depth") + ":k_sort_tile_hist"
