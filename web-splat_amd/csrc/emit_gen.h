@@ -52,8 +52,10 @@ __device__ __forceinline__ Geom load_geom(const Source& src, uint32_t store_idx)
 struct Slice {
     uint32_t e0, ne;        // first entry, number of entries
     uint32_t s_lo, ns;      // draw positions [s_lo, s_lo + ns) own them
-    bool in_lds;            // the offsets fit the LDS window (block-uniform)
+    bool in_lds;            // the offsets fit the LDS window (block-uniform); else they are read from global memory
     const uint32_t* goff;   // offsets + s_lo
+    // offset of the slice's position k (its first entry)
+    __device__ __forceinline__ uint32_t off_at(const uint32_t* s_off, uint32_t k) const { return in_lds ? s_off[k] : goff[k]; }
 };
 
 // All THREADS threads of the workgroup call this (it contains barriers).  d = total entries, v = visible splats.
@@ -69,16 +71,20 @@ __device__ __forceinline__ Slice slice_setup(const Source& src, uint32_t slice, 
     const uint32_t s_hi = (e1 < d) ? src.emit_start[slice + 1] : (v - 1u);
     // Positions that own entries of this slice number at most EMIT_TILE + 1, but visible splats with an EMPTY
     // tile rectangle (centre inside the 1.2x cull bounds, footprint off screen) can sit in between in any
-    // number: normally the offsets fit the LDS window, otherwise the search runs on global memory (rare).
+    // number.  Normally the offsets fit the LDS window; when they do not (slices of far, one-tile splats with empty ones
+    // in between: found in round 3 -- with 64-px binning tiles the first slices of every frame took the per-entry binary
+    // search on global memory that used to stand here, 12 dependent loads per entry, and k_bin_emit needed 24.6 us for
+    // HALF the entries it writes in 14.4) the owners are marked from global memory and nothing else changes.
     sl.ns = s_hi - sl.s_lo + 1u;
     sl.in_lds = sl.ns <= (uint32_t)EMIT_TILE + 2u;
     sl.goff = src.offsets + sl.s_lo;
-    if (sl.in_lds) {
-        for (uint32_t k = tid; k < sl.ns; k += THREADS) s_off[k] = sl.goff[k];
+    {
+        if (sl.in_lds)
+            for (uint32_t k = tid; k < sl.ns; k += THREADS) s_off[k] = sl.goff[k];
         for (uint32_t i = tid; i < (uint32_t)OWN_WORDS; i += THREADS) s_own[i] = 0u;
         __syncthreads();
         for (uint32_t k = tid; k < sl.ns; k += THREADS) {
-            const uint32_t o = s_off[k];
+            const uint32_t o = sl.off_at(s_off, k);
             const uint32_t f = o > sl.e0 ? o - sl.e0 : 0u;  // first entry of position k inside the slice
             if (f < sl.ne) atomicMax(&s_own[pad(f)], k);
         }
@@ -136,22 +142,10 @@ template <bool PACKED>
 __device__ __forceinline__ void entry(const Source& src, const Slice& sl, const uint32_t* s_off, const uint32_t* s_own,
                                       uint32_t el, uint32_t* key, uint32_t* val) {
     const uint32_t e = sl.e0 + el;
-    uint32_t lo;
-    if (sl.in_lds) {
-        lo = s_own[pad(el)];
-    } else {
-        // largest k in [0, ns) with off[k] <= e  (zero-footprint positions share their successor's offset and
-        // are skipped by taking the LAST such k)
-        uint32_t hi = sl.ns;
-        lo = 0;
-        while (hi - lo > 1u) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (sl.goff[mid] <= e) lo = mid; else hi = mid;
-        }
-    }
+    const uint32_t lo = s_own[pad(el)];  // the LAST position whose offset is <= e (zero-footprint positions share their successor's)
     const uint32_t pos = sl.s_lo + lo;
     *val = src.sorted_idx[pos];
-    const uint32_t k = e - (sl.in_lds ? s_off[lo] : sl.goff[lo]);
+    const uint32_t k = e - sl.off_at(s_off, lo);
     *key = PACKED ? tile_of_rect(src.fp_sorted[pos], k, src.tiles_x) : tile_of(src, load_geom(src, *val), k);
 }
 

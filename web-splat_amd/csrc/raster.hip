@@ -189,7 +189,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
     for (uint32_t slice = blockIdx.x; (uint64_t)slice * EMIT_TILE < d; slice += gridDim.x) {
         for (int k = tid; k < RADIX * EMIT_COPIES; k += BIN_THREADS) s_hist[k] = 0u;
         const emit::Slice sl = emit::slice_setup(src, slice, d, v, s_off, s_own, s_wmax);
-        if (sl.in_lds) {  // (block-uniform) the usual case
+        {
             // All EPT entries of a thread at once: owners from LDS, then their index gathers in flight together, then the
             // geometry words of their Splat records.  (Entry by entry, each one waited for its dependent loads before
             // the next one's were issued: 16 serial round trips per thread -- the whole duration of this kernel.)
@@ -215,23 +215,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
                 const uint32_t el = (uint32_t)tid + (uint32_t)j * BIN_THREADS;
                 if (el < sl.ne) {
                     const uint32_t e = sl.e0 + el;
-                    const uint32_t key = PACKED ? emit::tile_of_rect(rect[j], e - s_off[lo[j]], src.tiles_x)
-                                                : emit::tile_of(src, geom[j], e - s_off[lo[j]]);
+                    const uint32_t k = e - sl.off_at(s_off, lo[j]);
+                    const uint32_t key = PACKED ? emit::tile_of_rect(rect[j], k, src.tiles_x) : emit::tile_of(src, geom[j], k);
                     if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
                     else entry_keys[e] = key;
                     entry_vals[e] = val[j];
                     atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
                 }
-            }
-        } else {
-            for (uint32_t el = tid; el < sl.ne; el += BIN_THREADS) {
-                uint32_t key, val;
-                emit::entry<PACKED>(src, sl, s_off, s_own, el, &key, &val);
-                const uint32_t e = sl.e0 + el;
-                if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
-                else entry_keys[e] = key;
-                entry_vals[e] = val;
-                atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
             }
         }
         if (tile_hist) {  // digit counts of sort tile `slice` for the tile-id sort's first pass ([digit][tile])
@@ -490,7 +480,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         uint32_t code = 0xFFFFFFFFu;
         if (tx < p.tiles_x && ty < p.tiles_y) {
             code = tx | (ty << 16);
-            range = p.tile_ranges[(ty >> p.range_row_shift) * p.tiles_x + tx];
+            range = p.tile_ranges[(ty >> p.range_row_shift) * p.bin_tiles_x + (tx >> p.range_col_shift)];
             range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
         }
         s_range[tid] = range;
@@ -1365,6 +1355,8 @@ static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
     const uint32_t ntiles = p.tiles_x * p.tiles_y;
     if (ntiles == 0) return WS_OK;
+    if (p.range_col_shift && (variant != 0 || p.persist || p.debug_consumed || p.debug_walked))
+        return fail(WS_ERR_UNSUPPORTED, "blend: WS_BIN_SHIFT serves the default blend kernel only");
     if (variant == 2) {  // WS_BLEND_TARGET_PRECISION: back to front, destination rounded after every splat
         const uint32_t groups = ((ntiles + 7u) / 8u) * 8u * p.qw * p.qh;
         switch (p.format) {

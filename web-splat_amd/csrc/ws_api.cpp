@@ -291,7 +291,9 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     if ((rc = dmalloc(&r->evals_a, ne))) return rc;
     if ((rc = dmalloc(&r->evals_b, ne))) return rc;
     if ((rc = dmalloc(&r->emit_start, (size_t)r->entry_cap / EMIT_TILE + 4))) return rc;
-    const uint32_t tile_w = QUAD * r->ctx->tile_qw, tile_h = QUAD * r->ctx->tile_qh;
+    // binning tile = the blend's tile, or (WS_BIN_SHIFT=1, 4x4 shape only) a 2 x 2 block of them: four blend workgroups
+    // then share one binned list (half the entries to emit and sort, every entry staged by up to four workgroups)
+    const uint32_t tile_w = (QUAD * r->ctx->tile_qw) << r->ctx->bin_shift, tile_h = (QUAD * r->ctx->tile_qh) << r->ctx->bin_shift;
     r->tiles_x = (vw + tile_w - 1) / tile_w;
     r->tiles_y = (vh + tile_h - 1) / tile_h;
     if ((rc = dmalloc(&r->debug_consumed, (size_t)r->tiles_x * r->tiles_y))) return rc;
@@ -373,6 +375,7 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
     ctx->blend_dma = env_int("WS_BLEND_DMA", 0) ? 1 : 0;
     ctx->blend_persist = env_int("WS_BLEND_PERSIST", 0) ? 1 : 0;
+    ctx->bin_shift = (env_int("WS_BIN_SHIFT", 0) == 1 && ctx->tile_qw == 4 && ctx->tile_qh == 4) ? 1 : 0;
     ctx->batch_k1 = env_int("WS_BATCH_K1", 1);
     if (ctx->batch_k1 < 1 || ctx->batch_k1 > K1_MAX_VIEWS) ctx->batch_k1 = 1;
     {
@@ -865,6 +868,11 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     while ((1ull << tile_bits) < ntiles) ++tile_bits;
     int tile_passes = (tile_bits + RADIX_BITS - 1) / RADIX_BITS;
     int digit_bits = (tile_bits + tile_passes - 1) / tile_passes;
+    // A single pass (at most 256 tiles) would let EVERY sort workgroup end runs of EVERY tile: the last pass records the
+    // tile ranges with two atomics per (workgroup, tile) run, the whole range table is then 16 cache lines, and atomics on
+    // one line serialise -- measured 127 us for 247 tiles x 413 workgroups.  Two 6-bit passes instead: behind the first one
+    // a workgroup holds a handful of tiles.
+    if (tile_passes == 1 && ntiles > 64) digit_bits = 6;
     if (digit_bits < 6) digit_bits = 6;
     if (r->ctx->sort_algo == 1) {  // one-sweep cross-check path: 8-bit digits
         digit_bits = RADIX_BITS;
@@ -946,8 +954,8 @@ static int prepare_setup(ws_renderer* r, const ws_pointcloud* pc, const ws_splat
     kp.sh_deg_layout = (pc->sh_deg + 1) * (pc->sh_deg + 1);
     kp.tiles_x = r->tiles_x;
     kp.tiles_y = r->tiles_y;
-    kp.tile_w_log2 = r->ctx->tile_qw == 4 ? 5u : 4u;
-    kp.tile_h_log2 = r->ctx->tile_qh == 4 ? 5u : 4u;
+    kp.tile_w_log2 = (r->ctx->tile_qw == 4 ? 5u : 4u) + (uint32_t)r->ctx->bin_shift;
+    kp.tile_h_log2 = (r->ctx->tile_qh == 4 ? 5u : 4u) + (uint32_t)r->ctx->bin_shift;
     kp.znear = -kp.cam.proj[3 * 4 + 2] / kp.cam.proj[2 * 4 + 2];
     kp.zfar = -kp.cam.proj[3 * 4 + 2] / (kp.cam.proj[2 * 4 + 2] - 1.0f);
     // fade-in (preprocess.wgsl:196-203): dd = 5 |centre - xyz| / extend <= 10 because the centroid lies inside the
@@ -1148,13 +1156,21 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.num_cus = r->ctx->num_cus;
     bp.queue = r->zero ? r->zero->blend_queue : nullptr;
     bp.range_row_shift = 0;
+    bp.range_col_shift = 0;
+    bp.bin_tiles_x = r->tiles_x;
+    if (r->ctx->bin_shift) {  // blend tiles of QW x QH quadrants inside binning tiles twice that size
+        bp.tiles_x = (r->vw + QUAD * bp.qw - 1) / (QUAD * bp.qw);
+        bp.tiles_y = (r->vh + QUAD * bp.qh - 1) / (QUAD * bp.qh);
+        bp.range_row_shift = bp.range_col_shift = 1;
+    }
     // Two 512-thread workgroups (32x16 halves) per 32x32 binning tile, both reading the tile's list.  Automatic: when the
     // frame has fewer binning tiles than the chip holds 1024-thread blend workgroups (two per CU) -- small viewports --
     // the halves fill the chip and balance the long tiles (800x600, 0.5 M Gaussians: +24 % frames/s); above that the
     // doubled staging costs more with frames in flight than the finer synchronisation saves.
     const bool split = r->ctx->blend_split >= 0 ? r->ctx->blend_split != 0
                                                  : (r->tiles_x * r->tiles_y < 2u * (uint32_t)r->ctx->num_cus);
-    if (split && bp.qw == 4 && bp.qh == 4 && !r->capture && r->ctx->blend_variant == 0 && r->blend_mode == WS_BLEND_FAST) {
+    if (split && bp.qw == 4 && bp.qh == 4 && !r->capture && r->ctx->blend_variant == 0 && r->blend_mode == WS_BLEND_FAST &&
+        !r->ctx->bin_shift) {
         bp.qh = 2;
         bp.tiles_y = (r->vh + 15u) / 16u;
         bp.range_row_shift = 1;

@@ -287,6 +287,8 @@ struct BlendParams {
     int persist;                // k_blend_persist: resident workgroups draw tiles from per-XCD queues (4x4 tiles only)
     int num_cus;
     uint32_t* queue;            // FrameZero::blend_queue
+    uint32_t range_col_shift;   // (WS_BIN_SHIFT) the list of blend tile (tx, ty) is the binning tile's (tx >> col, ty >> row)
+    uint32_t bin_tiles_x;       // binning tiles per row (= tiles_x unless WS_BIN_SHIFT)
     uint32_t range_row_shift;   // 0, or 1 = "split" mode: tiles_y counts HALF binning tiles (32x16 px, 8 waves) and the list of
                                 //   blend tile (tx, ty) is the binning tile's (tx, ty >> 1): two workgroups share one list
     const FrameCounters* counters;  // this frame's counters: the error bits are folded into *sticky by the blend
@@ -335,6 +337,7 @@ struct ws_context {
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
     int footprint = 0;        // WS_FOOTPRINT=ellipse: FP_ELLIPSE (the default is FP_RECT_PACKED, FP_RECT_COUNT for wide viewports)
     int batch_k1 = 1;         // WS_BATCH_K1=n: a view batch runs K1 once for groups of n frames (1 = every frame its own K1)
+    int bin_shift = 0;        // WS_BIN_SHIFT=1: 64x64-px binning tiles under 32x32-px blend tiles (experiment)
     int blend_persist = 0;    // WS_BLEND_PERSIST=1: k_blend_persist
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
     int blend_split = -1;     // WS_BLEND_SPLIT: 4x4 binning tiles composited by two 4x2 workgroups each; -1 = when tiles < 2 x CUs
