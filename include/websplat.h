@@ -328,6 +328,11 @@ int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries);
  * (far -> near).  Any pointer may be NULL.  capacity = number of elements each array can hold. Syncs. */
 int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, uint32_t* keys,
                                uint32_t* src_index, uint32_t* sorted, uint32_t* num_visible);
+/* The binning tile the LAST prepared frame used: the context's tile (ws_context_tile_size) or, when the frame's splats span
+ * several tiles, 2 x 2 blocks of it -- decided per frame on the device from the tile counts K1 sums for both sizes (a pure
+ * function of the frame; WS_BIN_SHIFT=0 / 1 forces it off / on; frames in capture mode always use the context's tile).
+ * Four compositing workgroups then share one binned list: half the (tile, splat) entries to emit and sort.  Syncs. */
+int ws_renderer_binning_tile(ws_renderer* r, uint32_t* width, uint32_t* height);
 /* The binning tile in pixels: 32x32 by default (four 16x16 tiles -- 4x4 wave quadrants of 8x8 pixels -- sharing one
  * binned list), 32x16 or 16x16 with WS_TILE_SHAPE=4x2|2x2 at context creation (tuning; 2x2 is the literal
  * one-workgroup-per-16x16-tile form). */
@@ -344,17 +349,19 @@ int ws_debug_stage_splat(const uint32_t splat[5], float viewport_w, float viewpo
  * `capacity` are written.  tile_w / tile_h: 16 or 32. */
 int ws_debug_footprint(const uint32_t splat[3], float viewport_w, float viewport_h, uint32_t tile_w, uint32_t tile_h,
                        uint32_t capacity, uint32_t* tiles, uint32_t* count);
-/* tuning / analysis read-back: per tile, the length of its depth-ordered splat list and (capture mode)
- * how many of its entries the compositing pass walked before every pixel was saturated.  Syncs. */
+/* tuning / analysis read-back: per tile LIST (one per binning tile, ws_renderer_binning_tile; row-major over
+ * ceil(viewport / binning tile)), the length of the depth-ordered splat list and (capture mode, where the binning tile is
+ * the compositing tile) how many of its entries the compositing pass walked before every pixel was saturated.  Syncs. */
 int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t* list_len, uint32_t* consumed,
                                     uint32_t* num_tiles);
 /* analysis read-back (capture mode): walked[t * 17 + w] = staged records wave w of tile t composited (w < waves
  * per tile, 16 at the default tile), walked[t * 17 + 16] = sum over the tile's batches of the most any of its waves
  * composited in that batch -- the lock-step cost of the per-batch barriers.  Syncs. */
 int ws_renderer_download_wave_stats(ws_renderer* r, uint32_t tile_capacity, uint32_t* walked);
-/* parity read-back of the binning result: tile t's depth-ordered (far -> near) splat list is
- * entries[begin[t] .. end[t]) (store indices, as `sorted` of ws_renderer_download_frame). Any pointer may be NULL;
- * *num_entries = D.  Syncs. */
+/* parity read-back of the binning result: binning tile t's depth-ordered (far -> near) splat list is
+ * entries[begin[t] .. end[t]) (store indices, as `sorted` of ws_renderer_download_frame); t is row-major over
+ * ceil(viewport / binning tile) (ws_renderer_binning_tile; the tile count comes from ws_renderer_download_tile_stats).
+ * Any pointer may be NULL; *num_entries = D.  Syncs. */
 int ws_renderer_download_tile_lists(ws_renderer* r, uint32_t tile_capacity, uint32_t* begin, uint32_t* end,
                                     uint32_t entry_capacity, uint32_t* entries, uint32_t* num_entries);
 

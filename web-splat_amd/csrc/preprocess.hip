@@ -538,6 +538,7 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
     __shared__ uint32_t s_cnt[K1_ITEMS][K1_THREADS / 64];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_kmax[K1_THREADS / 64], s_kmin_inv[K1_THREADS / 64];
+    __shared__ uint32_t s_t32[K1_THREADS / 64], s_t64[K1_THREADS / 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -591,7 +592,10 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
         }
     }
     if (tid == 0) lb::st(b.block_status + bid, lb::pack(p.epoch, bid == 0 ? lb::FLAG_INCL : lb::FLAG_AGG, block_cnt));
-    if (tid == 0 && bid == 0) b.counters->epoch = p.epoch;  // for the later kernels of the frame (k_bin_prefix)
+    if (tid == 0 && bid == 0) {  // for the later kernels of the frame (k_bin_prefix, k_bin_emit, the blend)
+        b.counters->epoch = p.epoch;
+        b.counters->bin_request = FPMODE == FP_RECT_PACKED ? p.bin_request : (uint32_t)BIN_NEVER;
+    }
 
     // ---- back end, only for survivors --------------------------------------------------------------------
     SplatOut so[K1_ITEMS];
@@ -642,6 +646,25 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
             s_kmin_inv[wave] = kmin_inv;
         }
     }
+    // ---- the frame's footprint totals at both binning granularities (ws_internal.h bin_shift_decide) -----------------
+    if (FPMODE == FP_RECT_PACKED && p.bin_request == BIN_AUTO) {  // (uniform: only frames that let the device decide)
+        uint32_t t32 = 0u, t64 = 0u;
+#pragma unroll
+        for (int it = 0; it < K1_ITEMS; ++it)
+            if (vis[it]) {
+                t32 += rect_tiles(so[it].fp);
+                t64 += rect_tiles64(so[it].fp);
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            t32 += (uint32_t)__shfl_xor((int)t32, o, 64);
+            t64 += (uint32_t)__shfl_xor((int)t64, o, 64);
+        }
+        if (lane == 0) {
+            s_t32[wave] = t32;
+            s_t64[wave] = t64;
+        }
+    }
 
     // ---- ordered compaction, part 2: look-back (wave 0) and scatter ----------------------------------------
     if (wave == 0) {
@@ -665,6 +688,19 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
         uint32_t* kr = b.key_range + (bid & (KEY_RANGE_SLOTS - 1)) * KEY_RANGE_STRIDE;
         atomicMax(kr, kmax);
         atomicMax(kr + 1, kmin_inv);
+        if (FPMODE == FP_RECT_PACKED && p.bin_request == BIN_AUTO) {
+            uint32_t t32 = 0u, t64 = 0u;
+#pragma unroll
+            for (int w = 0; w < K1_THREADS / 64; ++w) {
+                t32 += s_t32[w];
+                t64 += s_t64[w];
+            }
+            if (t32) {  // (returnless; one pair per workgroup that has a visible splat with a footprint)
+                uint32_t* ts = b.counters->tile_sums + (bid & (TILE_SUM_SLOTS - 1)) * TILE_SUM_STRIDE;
+                atomicAdd(ts, t32);
+                atomicAdd(ts + 1, t64);
+            }
+        }
     }
     const uint32_t base = s_base;
 #pragma unroll
@@ -705,6 +741,7 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess_multi
     __shared__ uint32_t s_cnt[K1_MAX_VIEWS][K1_ITEMS][K1_THREADS / 64];  // visible per (view, item, wave); then exclusive offsets
     __shared__ uint32_t s_tot[K1_MAX_VIEWS];
     __shared__ uint32_t s_base[K1_MAX_VIEWS];
+    __shared__ uint32_t s_t32[K1_MAX_VIEWS], s_t64[K1_MAX_VIEWS];  // footprint totals per view (bin_shift_decide)
     const uint32_t nv = a.nv;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -763,7 +800,12 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess_multi
         const uint32_t epoch = a.p[v].epoch;
         if (lane == 0) {
             lb::st(a.b[v].block_status + bid, lb::pack(epoch, bid == 0 ? lb::FLAG_INCL : lb::FLAG_AGG, block_cnt));
-            if (bid == 0) a.b[v].counters->epoch = epoch;  // for the later kernels of that view's frame
+            if (bid == 0) {  // for the later kernels of that view's frame
+                a.b[v].counters->epoch = epoch;
+                a.b[v].counters->bin_request = FPMODE == FP_RECT_PACKED ? a.p[v].bin_request : (uint32_t)BIN_NEVER;
+            }
+            s_t32[v] = 0u;
+            s_t64[v] = 0u;
         }
         const uint32_t excl = lb::wave_lookback(a.b[v].block_status, bid, epoch, lane, &a.b[v].counters->overflow, 2u);
         if (lane == 0) {
@@ -797,6 +839,13 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess_multi
         sp[4] = so.w[4];
         a.b[v].keys[slot] = so.key;
         a.b[v].footprints[slot] = so.fp;
+        if (FPMODE == FP_RECT_PACKED) {  // (LDS atomics: a few per thread and view)
+            const uint32_t t32 = rect_tiles(so.fp);
+            if (t32) {
+                atomicAdd(&s_t32[v], t32);
+                atomicAdd(&s_t64[v], rect_tiles64(so.fp));
+            }
+        }
     };
     if (!COMPRESSED) {
         const uint32_t safe_idx = block_base < n ? block_base : 0u;
@@ -834,6 +883,14 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess_multi
                     k1_back_compressed<FPMODE>(a.p[v], a.b[v], fr[it], &so);
                     store(v, it, so);
                 }
+    }
+    if (FPMODE == FP_RECT_PACKED) {
+        __syncthreads();
+        if ((uint32_t)tid < nv && s_t32[tid]) {
+            uint32_t* ts = a.b[tid].counters->tile_sums + (blockIdx.x & (TILE_SUM_SLOTS - 1)) * TILE_SUM_STRIDE;
+            atomicAdd(ts, s_t32[tid]);
+            atomicAdd(ts + 1, s_t64[tid]);
+        }
     }
 }
 

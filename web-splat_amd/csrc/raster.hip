@@ -81,6 +81,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
     const uint32_t v = counters->num_visible;
     if ((uint64_t)blockIdx.x * BIN_ITEMS >= v) return;  // surplus workgroups leave before drawing a ticket
     const uint32_t epoch = counters->epoch;  // the frame's look-back epoch, left by K1
+    const bool coarse = packed && bin_shift_decide(counters) != 0u;  // the frame bins at twice the blend's tile size (ws_internal.h)
     const int tid = threadIdx.x;
     // Workgroup ids are handed out by an atomic ticket = START order: a workgroup only ever waits for workgroups that
     // already hold their slot.  (blockIdx order -- -DWS_BLOCKIDX_ORDER -- saves the ~11 ns the returning atomic costs
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
     const uint32_t bid = s_bid;
     const uint32_t nblocks = (v + BIN_ITEMS - 1) / BIN_ITEMS;
     const uint32_t base = bid * BIN_ITEMS;
+    if (bid == 0 && tid == 0) counters->bin_shift = coarse ? 1u : 0u;  // for k_bin_emit, the blend and the host
 
     // STRIPED arrangement for global memory (thread t owns draw positions base + k*256 + t: every load and store of
     // a wave is one contiguous run), BLOCKED arrangement for the scan (thread t owns BIN_IPT consecutive positions); the
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
 #pragma unroll
     for (int k = 0; k < BIN_IPT; ++k) {
         const uint32_t i = base + k * BIN_THREADS + tid;
-        cnt[k] = i < v ? (packed ? rect_tiles(r[k]) : r[k]) : 0u;
+        cnt[k] = i < v ? (packed ? (coarse ? rect_tiles64(r[k]) : rect_tiles(r[k])) : r[k]) : 0u;
         s_cnt[pad(k * BIN_THREADS + tid)] = cnt[k];
     }
     __syncthreads();
@@ -189,6 +191,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
     for (uint32_t slice = blockIdx.x; (uint64_t)slice * EMIT_TILE < d; slice += gridDim.x) {
         for (int k = tid; k < RADIX * EMIT_COPIES; k += BIN_THREADS) s_hist[k] = 0u;
         const emit::Slice sl = emit::slice_setup(src, slice, d, v, s_off, s_own, s_wmax);
+        // (the frame may bin at twice the blend's tile size: the same packed rectangles in units of 2 x 2 tiles)
+        const bool coarse = PACKED && src.counters->bin_shift != 0u;
+        const uint32_t tiles_x = coarse ? (src.tiles_x + 1u) >> 1 : src.tiles_x;
         {
             // All EPT entries of a thread at once: owners from LDS, then their index gathers in flight together, then the
             // geometry words of their Splat records.  (Entry by entry, each one waited for its dependent loads before
@@ -216,7 +221,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
                 if (el < sl.ne) {
                     const uint32_t e = sl.e0 + el;
                     const uint32_t k = e - sl.off_at(s_off, lo[j]);
-                    const uint32_t key = PACKED ? emit::tile_of_rect(rect[j], k, src.tiles_x) : emit::tile_of(src, geom[j], k);
+                    const uint32_t key = PACKED ? emit::tile_of_rect(coarse ? rect_coarse(rect[j]) : rect[j], k, tiles_x)
+                                                : emit::tile_of(src, geom[j], k);
                     if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
                     else entry_keys[e] = key;
                     entry_vals[e] = val[j];
@@ -302,6 +308,14 @@ inline uint32_t blend_tpw_log2(uint32_t tiles_x, uint32_t tiles_y, BlendShape sh
     const uint32_t want = (tiles_x * tiles_y > 16384u) ? 2u : 0u;
     const uint32_t most = sh.tbx_log2 + sh.tby_log2;
     return want < most ? want : most;
+}
+
+// Index of the binned list blend tile (tx, ty) composites: its own, the binning tile's it is a half of (split mode), or
+// -- when the frame binned at twice the blend's tile size (FrameCounters::bin_shift) -- the 2 x 2 block's it belongs to.
+__device__ __forceinline__ uint32_t tile_list_index(const BlendParams& p, uint32_t tx, uint32_t ty) {
+    const uint32_t s = p.counters->bin_shift;
+    const uint32_t btx = s ? (p.bin_tiles_x + 1u) >> 1 : p.bin_tiles_x;
+    return ((ty >> p.range_row_shift) >> s) * btx + (tx >> s);
 }
 
 template <int FORMAT>
@@ -480,7 +494,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         uint32_t code = 0xFFFFFFFFu;
         if (tx < p.tiles_x && ty < p.tiles_y) {
             code = tx | (ty << 16);
-            range = p.tile_ranges[(ty >> p.range_row_shift) * p.bin_tiles_x + (tx >> p.range_col_shift)];
+            range = p.tile_ranges[tile_list_index(p, tx, ty)];
             range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
         }
         s_range[tid] = range;
@@ -769,8 +783,8 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend_persi
         tk_pending = atomicAdd(q_ticket, 1u);
         const uint32_t c0 = tile_code(t0), c1 = tile_code(t1);
         uint2 r0 = make_uint2(0u, 0u), r1 = make_uint2(0u, 0u);
-        if (c0 < TILE_END) r0 = p.tile_ranges[(c0 >> 16) * p.tiles_x + (c0 & 0xFFFFu)];
-        if (c1 < TILE_END) r1 = p.tile_ranges[(c1 >> 16) * p.tiles_x + (c1 & 0xFFFFu)];
+        if (c0 < TILE_END) r0 = p.tile_ranges[tile_list_index(p, c0 & 0xFFFFu, c0 >> 16)];
+        if (c1 < TILE_END) r1 = p.tile_ranges[tile_list_index(p, c1 & 0xFFFFu, c1 >> 16)];
         s_tcode[0] = c0;
         s_traw[0][0] = r0.x;
         s_traw[0][1] = r0.y;
@@ -804,7 +818,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend_persi
         const uint32_t c2 = tile_code(tk_pending);
         s_tcode[slot_new] = c2;
         if (c2 < TILE_END) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(p.tile_ranges + ((c2 >> 16) * p.tiles_x + (c2 & 0xFFFFu)));
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(p.tile_ranges + tile_list_index(p, c2 & 0xFFFFu, c2 >> 16));
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&s_traw[slot_new][0], 4, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(src + 1), (lptr_t)&s_traw[slot_new][1], 4, 0, 0);
         }
@@ -1004,7 +1018,7 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
     const float qy_lo = (float)qy0 + 0.5f;
     const float W = (float)p.width, H = (float)p.height;
 
-    uint2 range = p.tile_ranges[tile];
+    uint2 range = p.tile_ranges[tile_list_index(p, tx, ty)];
     range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
     float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
     bool done = !inside;
@@ -1144,7 +1158,7 @@ __global__ __launch_bounds__(64) void k_blend_strict(const BlendParams p) {
     const float W = (float)p.width, H = (float)p.height;
     float d0 = quantize_target<FORMAT>(p.background[0]), d1 = quantize_target<FORMAT>(p.background[1]),
           d2 = quantize_target<FORMAT>(p.background[2]), d3 = quantize_target<FORMAT>(p.background[3]);
-    uint2 range = p.tile_ranges[tile];
+    uint2 range = p.tile_ranges[tile_list_index(p, tx, ty)];
     range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
     for (uint32_t lo = range.x; lo < range.y; lo += 64u) {  // far -> near: ascending position in the tile's list
         const uint32_t e = lo + (uint32_t)lane;
@@ -1355,8 +1369,6 @@ static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
     const uint32_t ntiles = p.tiles_x * p.tiles_y;
     if (ntiles == 0) return WS_OK;
-    if (p.range_col_shift && (variant != 0 || p.persist || p.debug_consumed || p.debug_walked))
-        return fail(WS_ERR_UNSUPPORTED, "blend: WS_BIN_SHIFT serves the default blend kernel only");
     if (variant == 2) {  // WS_BLEND_TARGET_PRECISION: back to front, destination rounded after every splat
         const uint32_t groups = ((ntiles + 7u) / 8u) * 8u * p.qw * p.qh;
         switch (p.format) {

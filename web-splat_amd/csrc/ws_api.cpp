@@ -291,9 +291,7 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     if ((rc = dmalloc(&r->evals_a, ne))) return rc;
     if ((rc = dmalloc(&r->evals_b, ne))) return rc;
     if ((rc = dmalloc(&r->emit_start, (size_t)r->entry_cap / EMIT_TILE + 4))) return rc;
-    // binning tile = the blend's tile, or (WS_BIN_SHIFT=1, 4x4 shape only) a 2 x 2 block of them: four blend workgroups
-    // then share one binned list (half the entries to emit and sort, every entry staged by up to four workgroups)
-    const uint32_t tile_w = (QUAD * r->ctx->tile_qw) << r->ctx->bin_shift, tile_h = (QUAD * r->ctx->tile_qh) << r->ctx->bin_shift;
+    const uint32_t tile_w = QUAD * r->ctx->tile_qw, tile_h = QUAD * r->ctx->tile_qh;
     r->tiles_x = (vw + tile_w - 1) / tile_w;
     r->tiles_y = (vh + tile_h - 1) / tile_h;
     if ((rc = dmalloc(&r->debug_consumed, (size_t)r->tiles_x * r->tiles_y))) return rc;
@@ -375,7 +373,10 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
     ctx->blend_dma = env_int("WS_BLEND_DMA", 0) ? 1 : 0;
     ctx->blend_persist = env_int("WS_BLEND_PERSIST", 0) ? 1 : 0;
-    ctx->bin_shift = (env_int("WS_BIN_SHIFT", 0) == 1 && ctx->tile_qw == 4 && ctx->tile_qh == 4) ? 1 : 0;
+    {
+        const char* bs = std::getenv("WS_BIN_SHIFT");  // 0 | 1 | auto (default): binning at twice the blend's tile size
+        ctx->bin_request = !bs ? BIN_AUTO : (std::strcmp(bs, "1") == 0 ? BIN_ALWAYS : (std::strcmp(bs, "0") == 0 ? BIN_NEVER : BIN_AUTO));
+    }
     ctx->batch_k1 = env_int("WS_BATCH_K1", 1);
     if (ctx->batch_k1 < 1 || ctx->batch_k1 > K1_MAX_VIEWS) ctx->batch_k1 = 1;
     {
@@ -954,8 +955,13 @@ static int prepare_setup(ws_renderer* r, const ws_pointcloud* pc, const ws_splat
     kp.sh_deg_layout = (pc->sh_deg + 1) * (pc->sh_deg + 1);
     kp.tiles_x = r->tiles_x;
     kp.tiles_y = r->tiles_y;
-    kp.tile_w_log2 = (r->ctx->tile_qw == 4 ? 5u : 4u) + (uint32_t)r->ctx->bin_shift;
-    kp.tile_h_log2 = (r->ctx->tile_qh == 4 ? 5u : 4u) + (uint32_t)r->ctx->bin_shift;
+    kp.tile_w_log2 = r->ctx->tile_qw == 4 ? 5u : 4u;
+    kp.tile_h_log2 = r->ctx->tile_qh == 4 ? 5u : 4u;
+    // Coarse binning (2 x 2 blend tiles per binning tile, decided per frame on the device: ws_internal.h bin_shift_decide) is
+    // offered to frames of the default 32x32 shape whose rectangles travel packed; parity tooling that reads per-tile
+    // lists back (capture mode) always sees the blend's own tiles.
+    kp.bin_request = (r->footprint_mode == FP_RECT_PACKED && !r->capture && r->ctx->tile_qw == 4 && r->ctx->tile_qh == 4)
+                         ? (uint32_t)r->ctx->bin_request : (uint32_t)BIN_NEVER;
     kp.znear = -kp.cam.proj[3 * 4 + 2] / kp.cam.proj[2 * 4 + 2];
     kp.zfar = -kp.cam.proj[3 * 4 + 2] / (kp.cam.proj[2 * 4 + 2] - 1.0f);
     // fade-in (preprocess.wgsl:196-203): dd = 5 |centre - xyz| / extend <= 10 because the centroid lies inside the
@@ -1156,21 +1162,14 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.num_cus = r->ctx->num_cus;
     bp.queue = r->zero ? r->zero->blend_queue : nullptr;
     bp.range_row_shift = 0;
-    bp.range_col_shift = 0;
     bp.bin_tiles_x = r->tiles_x;
-    if (r->ctx->bin_shift) {  // blend tiles of QW x QH quadrants inside binning tiles twice that size
-        bp.tiles_x = (r->vw + QUAD * bp.qw - 1) / (QUAD * bp.qw);
-        bp.tiles_y = (r->vh + QUAD * bp.qh - 1) / (QUAD * bp.qh);
-        bp.range_row_shift = bp.range_col_shift = 1;
-    }
     // Two 512-thread workgroups (32x16 halves) per 32x32 binning tile, both reading the tile's list.  Automatic: when the
     // frame has fewer binning tiles than the chip holds 1024-thread blend workgroups (two per CU) -- small viewports --
     // the halves fill the chip and balance the long tiles (800x600, 0.5 M Gaussians: +24 % frames/s); above that the
     // doubled staging costs more with frames in flight than the finer synchronisation saves.
     const bool split = r->ctx->blend_split >= 0 ? r->ctx->blend_split != 0
                                                  : (r->tiles_x * r->tiles_y < 2u * (uint32_t)r->ctx->num_cus);
-    if (split && bp.qw == 4 && bp.qh == 4 && !r->capture && r->ctx->blend_variant == 0 && r->blend_mode == WS_BLEND_FAST &&
-        !r->ctx->bin_shift) {
+    if (split && bp.qw == 4 && bp.qh == 4 && !r->capture && r->ctx->blend_variant == 0 && r->blend_mode == WS_BLEND_FAST) {
         bp.qh = 2;
         bp.tiles_y = (r->vh + 15u) / 16u;
         bp.range_row_shift = 1;
@@ -1203,11 +1202,34 @@ int ws_renderer_frame_stats(ws_renderer* r, ws_frame_stats* out) {
     if (!r->prepared) return fail(WS_ERR_STATE, "ws_renderer_frame_stats: no prepared frame");
     WS_HIP(hipStreamSynchronize(r->last_stream));
     FrameCounters fc;
-    { int rc_ = copy_d2h(&fc, r->counters, sizeof fc, r->last_stream); if (rc_) return rc_; }
+    { int rc_ = copy_d2h(&fc, r->counters, offsetof(FrameCounters, tile_sums), r->last_stream); if (rc_) return rc_; }
     out->num_visible = fc.num_visible;
     out->num_tile_entries = fc.num_entries;
     out->tile_entries_capacity = r->entry_cap;
     out->overflow = fc.overflow;
+    return WS_OK;
+}
+
+// Number of tile LISTS of the last prepared frame and the shift from blend tiles to binning tiles: the device decides per
+// frame (bin_shift_decide, k_bin_prefix) whether a list serves one blend tile or a 2x2 block of them.
+static int frame_lists(ws_renderer* r, uint32_t* shift, uint32_t* lists_x, uint32_t* lists_y) {
+    WS_HIP(hipStreamSynchronize(r->last_stream));
+    FrameCounters fc;
+    { int rc_ = copy_d2h(&fc, r->counters, offsetof(FrameCounters, tile_sums), r->last_stream); if (rc_) return rc_; }
+    const uint32_t s = fc.bin_shift;
+    *shift = s;
+    *lists_x = (r->tiles_x + s) >> s;
+    *lists_y = (r->tiles_y + s) >> s;
+    return WS_OK;
+}
+
+int ws_renderer_binning_tile(ws_renderer* r, uint32_t* width, uint32_t* height) {
+    if (!r || !width || !height) return fail(WS_ERR_INVALID, "ws_renderer_binning_tile: null argument");
+    if (!r->prepared) return fail(WS_ERR_STATE, "ws_renderer_binning_tile: no prepared frame");
+    uint32_t s, lx, ly;
+    { int rc_ = frame_lists(r, &s, &lx, &ly); if (rc_) return rc_; }
+    *width = (QUAD * r->ctx->tile_qw) << s;
+    *height = (QUAD * r->ctx->tile_qh) << s;
     return WS_OK;
 }
 
@@ -1271,7 +1293,9 @@ int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t*
                                     uint32_t* num_tiles) {
     if (!r) return fail(WS_ERR_INVALID, "ws_renderer_download_tile_stats: null renderer");
     if (!r->prepared) return fail(WS_ERR_STATE, "ws_renderer_download_tile_stats: no prepared frame");
-    const uint32_t nt = r->tiles_x * r->tiles_y;
+    uint32_t bs, lx, ly;
+    { int rc_ = frame_lists(r, &bs, &lx, &ly); if (rc_) return rc_; }
+    const uint32_t nt = lx * ly;  // one entry per LIST (= per binning tile; capture keeps them at the blend tile)
     if (num_tiles) *num_tiles = nt;
     if (!list_len && !consumed) return WS_OK;
     if (capacity < nt) return fail(WS_ERR_INVALID, "ws_renderer_download_tile_stats: capacity smaller than the tile count");
@@ -1304,7 +1328,9 @@ int ws_renderer_download_tile_lists(ws_renderer* r, uint32_t tile_capacity, uint
     ws_frame_stats st;
     int rc = ws_renderer_frame_stats(r, &st);
     if (rc) return rc;
-    const uint32_t nt = r->tiles_x * r->tiles_y;
+    uint32_t bs, lx, ly;
+    { int rc_ = frame_lists(r, &bs, &lx, &ly); if (rc_) return rc_; }
+    const uint32_t nt = lx * ly;  // one range per LIST (= per binning tile, ws_renderer_binning_tile)
     if (num_entries) *num_entries = st.num_tile_entries;
     if ((begin || end) && tile_capacity < nt) return fail(WS_ERR_INVALID, "ws_renderer_download_tile_lists: tile capacity too small");
     if (entries && entry_capacity < st.num_tile_entries)

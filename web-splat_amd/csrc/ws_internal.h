@@ -45,9 +45,19 @@ struct FrameCounters {
     uint32_t entries_needed; // D before clamping to the capacity (what a retry has to allocate)
     uint32_t epoch;          // look-back epoch of the frame, written by K1 (the only kernel whose arguments change per
                              // frame: later kernels read it here, so that a captured frame graph replays with ONE update)
-    uint32_t _pad[1];
+    uint32_t bin_request;    // written by K1: BIN_NEVER / BIN_AUTO / BIN_ALWAYS (the frame's request for coarse binning)
+    // --- second cache line: what the frame decided ---
+    uint32_t bin_shift;      // written by k_bin_prefix: 0 = the frame binned at the blend's tile size, 1 = at twice that
+    uint32_t _pad[15];
+    // --- the frame's footprint totals, summed by K1: TILE_SUM_SLOTS x {sum at the blend's tile size, sum at twice that
+    // size}, one 64-B line per slot.  Workgroup b adds its partial sums to slot b % 16 with two returnless atomics; all
+    // K1 workgroups retire within a few microseconds of each other, and ~1000 atomics on ONE address drain one after
+    // the other (~12 ns each: measured +13 us per frame), on 16 lines in 0.7 us.  k_bin_prefix adds the slots (bin_shift_decide).
+    uint32_t tile_sums[16 * 16];
 };
-static_assert(sizeof(FrameCounters) == 64, "FrameCounters layout");
+constexpr int TILE_SUM_SLOTS = 16;
+constexpr int TILE_SUM_STRIDE = 16;  // uint32 words per slot (64 B)
+static_assert(sizeof(FrameCounters) == 128 + TILE_SUM_SLOTS * TILE_SUM_STRIDE * 4, "FrameCounters layout");
 
 // Everything a frame needs zeroed lives in one contiguous arena: counters, the digit histograms of both
 // sorts, and the tile ranges (appended after this struct).
@@ -91,6 +101,42 @@ __host__ __device__ inline uint32_t rect_tiles(uint32_t r) {
     return r == RECT_EMPTY ? 0u : (((r >> 16) & 0xFFu) + 1u) * ((r >> 24) + 1u);
 }
 
+// ---- binning granularity, decided PER FRAME ON THE DEVICE -----------------------------------------------------------
+// The blend composites 32x32-px tiles (default shape).  Binning may use those tiles, or 2 x 2 blocks of them (64x64 px):
+// four blend workgroups then share one binned list -- half the (tile, splat) entries to emit and sort when splats span
+// several tiles, at the price of every entry being staged by up to four workgroups.  Measured (profiles/r03/bin64_*):
+// +16..+20 % frames/s where the rectangles shrink 2.07x (hd1m, c4), +3 % at 1.75x (c2), -14 % / -23 % at 1.14x / 1.10x
+// (c5, c3: pixel-sized splats).  K1 sums both tile counts while it writes the rectangles; the binning prefix derives
+// the decision from the two sums (a pure function of the frame: ranks and renderers agree), no host round trip.
+enum BinRequest { BIN_NEVER = 0, BIN_AUTO = 1, BIN_ALWAYS = 2 };
+constexpr uint32_t BIN64_RATIO_PERCENT = 185u;  // coarse binning when the sum at the blend's tile size >= 1.85 x the sum at twice that
+__host__ __device__ inline uint32_t rect_tiles64(uint32_t r) {
+    if (r == RECT_EMPTY) return 0u;
+    const uint32_t x0 = r & 0xFFu, y0 = (r >> 8) & 0xFFu, x1 = x0 + ((r >> 16) & 0xFFu), y1 = y0 + (r >> 24);
+    return ((x1 >> 1) - (x0 >> 1) + 1u) * ((y1 >> 1) - (y0 >> 1) + 1u);
+}
+// the packed rectangle in units of 2 x 2 tiles
+__host__ __device__ inline uint32_t rect_coarse(uint32_t r) {
+    const uint32_t x0 = r & 0xFFu, y0 = (r >> 8) & 0xFFu, x1 = x0 + ((r >> 16) & 0xFFu), y1 = y0 + (r >> 24);
+    return rect_pack(x0 >> 1, y0 >> 1, x1 >> 1, y1 >> 1);
+}
+// 0 = bin at the blend's tile size, 1 = at twice that.  k_bin_prefix -- the first kernel that needs the answer -- derives it
+// in every workgroup and leaves it in counters->bin_shift for the kernels behind it and for the host (32 loads per
+// workgroup were measurable in the blend: -2 % frames/s on c2 / c5).
+__host__ __device__ inline uint32_t bin_shift_decide(const FrameCounters* c) {
+    const uint32_t req = c->bin_request;
+    if (req == BIN_ALWAYS) return 1u;
+    if (req != BIN_AUTO) return 0u;
+    uint32_t sum32 = 0u, sum64 = 0u;  // (sums of at most 2^32 / 2^16 splats' tile counts would wrap: the ratio of a frame
+#pragma unroll                        //  that large is meaningless either way, and every reader wraps alike)
+    for (int sl = 0; sl < TILE_SUM_SLOTS; ++sl) {
+        sum32 += c->tile_sums[sl * TILE_SUM_STRIDE];
+        sum64 += c->tile_sums[sl * TILE_SUM_STRIDE + 1];
+    }
+    return ((uint64_t)sum32 * 100ull >= (uint64_t)sum64 * BIN64_RATIO_PERCENT && sum64 != 0u) ? 1u : 0u;
+}
+
+
 // ---- kernel parameter blocks (passed by value; the analogue of the reference's uniform buffers) ---
 struct K1Params {
     ws_camera_uniform cam;   // renderer.rs:290-306
@@ -103,6 +149,7 @@ struct K1Params {
     uint32_t epoch;          // look-back epoch of this frame (lookback.h)
     float znear, zfar;       // -proj[3][2]/proj[2][2], -proj[3][2]/(proj[2][2]-1)  (preprocess.wgsl:270-271)
     uint32_t fade_done;      // walltime is past every Gaussian's fade-in: scale_mod == 1 exactly
+    uint32_t bin_request;    // BinRequest of this frame (coarse binning never / decided on the device / always)
 };
 
 // uncompressed point cloud in HBM: eight planes of 16-B chunks, plane p of Gaussian i at
@@ -287,8 +334,7 @@ struct BlendParams {
     int persist;                // k_blend_persist: resident workgroups draw tiles from per-XCD queues (4x4 tiles only)
     int num_cus;
     uint32_t* queue;            // FrameZero::blend_queue
-    uint32_t range_col_shift;   // (WS_BIN_SHIFT) the list of blend tile (tx, ty) is the binning tile's (tx >> col, ty >> row)
-    uint32_t bin_tiles_x;       // binning tiles per row (= tiles_x unless WS_BIN_SHIFT)
+    uint32_t bin_tiles_x;       // binning tiles per row at the blend's tile size (the frame may bin at twice that: FrameCounters::bin_shift)
     uint32_t range_row_shift;   // 0, or 1 = "split" mode: tiles_y counts HALF binning tiles (32x16 px, 8 waves) and the list of
                                 //   blend tile (tx, ty) is the binning tile's (tx, ty >> 1): two workgroups share one list
     const FrameCounters* counters;  // this frame's counters: the error bits are folded into *sticky by the blend
@@ -337,7 +383,7 @@ struct ws_context {
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
     int footprint = 0;        // WS_FOOTPRINT=ellipse: FP_ELLIPSE (the default is FP_RECT_PACKED, FP_RECT_COUNT for wide viewports)
     int batch_k1 = 1;         // WS_BATCH_K1=n: a view batch runs K1 once for groups of n frames (1 = every frame its own K1)
-    int bin_shift = 0;        // WS_BIN_SHIFT=1: 64x64-px binning tiles under 32x32-px blend tiles (experiment)
+    int bin_request = 1;      // WS_BIN_SHIFT=0 | auto (default) | 1: BinRequest for frames that can use coarse binning
     int blend_persist = 0;    // WS_BLEND_PERSIST=1: k_blend_persist
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
     int blend_split = -1;     // WS_BLEND_SPLIT: 4x4 binning tiles composited by two 4x2 workgroups each; -1 = when tiles < 2 x CUs

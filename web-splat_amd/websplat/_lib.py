@@ -227,6 +227,7 @@ SIGNATURES = {
     "ws_renderer_download_tile_lists": (C.c_int, [_P, C.c_uint32, _P, _P, C.c_uint32, _P, _u32p]),
     "ws_renderer_enable_capture": (C.c_int, [_P, C.c_int]),
     "ws_renderer_set_blend_mode": (C.c_int, [_P, C.c_int]),
+    "ws_renderer_binning_tile": (C.c_int, [_P, _u32p, _u32p]),
     "ws_renderer_set_tile_entry_capacity": (C.c_int, [_P, C.c_uint64]),
     "ws_renderer_download_frame": (C.c_int, [_P, C.c_uint32, _P, _P, _P, _P, _u32p]),
     "ws_sorter_create": (C.c_int, [_P, C.c_uint32, _PP]),

@@ -601,6 +601,12 @@ class GaussianRenderer:
     def enable_capture(self, on=True):
         check(lib.ws_renderer_enable_capture(self.handle, int(on)))
 
+    def binning_tile(self):
+        """(width, height) in pixels of the binning tile the last prepared frame used (the device decides per frame)."""
+        w, h = C.c_uint32(), C.c_uint32()
+        check(lib.ws_renderer_binning_tile(self.handle, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
     def set_blend_mode(self, mode="fast"):
         """"fast" (front to back, early-out, one rounding at the store) or "target" (the reference's fixed-function blend
         literally: back to front, the destination rounded to the target's precision after every splat)."""
