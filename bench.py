@@ -470,7 +470,7 @@ def analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world
         "k_bin_prefix": V * (4 + 4),
         "k_bin_emit": V * 12 + D * 8,
         "tiles:k_sort_tile_hist": 4 * D, "tiles:k_sort_col_scan": None, "tiles:k_sort_hist": 4 * D,
-        "tiles:k_sort_scatter": (16 * D * (tile_passes - 1) + 12 * D) / tile_passes,
+        "tiles:k_sort_scatter": (16 * D * (tile_passes - 1) + 12 * D) / tile_passes,   # (re-priced below by launch count)
         "k_blend": D * 24 + w * h * 16,
     }
     # An event interval = event + dispatch overhead of a dependent launch + the kernel; rocprofv3 reports the kernel
@@ -480,6 +480,12 @@ def analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world
     # which the calibrated time matches rocprofv3 to 1 %); GBps_interval (nothing subtracted) is the lower bound.
     # Launches shorter than twice the empty interval are below what events can resolve: no calibrated duration
     # for them (their rocprofv3 durations are in profiles/).
+    # the tile-id sort is ONE counting pass up to 2048 binning tiles (no histogram launch, one scatter that reads
+    # (id, value) and writes the value), digit passes beyond: price the launches that actually ran
+    sc = per_kernel.get("tiles:k_sort_scatter")
+    if sc:
+        tile_passes = max(1, round(sc[1] / reps))
+        alg["tiles:k_sort_scatter"] = (16 * D * (tile_passes - 1) + 12 * D) / tile_passes
     empty = per_kernel.pop("_empty_launch", None)
     empty_ms = (empty[0] / empty[1]) if empty else 0.0
     kernels = {}
@@ -524,7 +530,10 @@ def analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world
                         "(pixel, splat) pair: what limits it is VALU issue and, on scenes whose tiles saturate after "
                         "one or two staged batches, the per-tile start-up latency (valu.issue_util, DESIGN.md 3.3); "
                         "early-out makes its real traffic a fraction of the algorithmic bytes"}
-    out["config"].update({"binning_tile": f"{tile_w}x{tile_h}", "avg_visible": V, "avg_tile_entries": D,
+    # the device picks the binning tile per frame (the compositing tile or 2 x 2 of them): D counts entries of THOSE lists
+    bin_w, bin_h = r.binning_tile()
+    out["config"].update({"binning_tile": f"{bin_w}x{bin_h}", "compositing_tile": f"{tile_w}x{tile_h}",
+                          "avg_visible": V, "avg_tile_entries": D,
                           "single_stream_fps": single_stream_fps})
     out["roofline"] = roofline
     out["kernels"] = kernels

@@ -610,3 +610,48 @@ def test_binning_granularity_is_decided_per_frame_on_the_device(ws, oracle, monk
         a, b = out[name, "0"][0], out[name, "1"][0]
         assert np.abs(a.astype(np.float64) - b.astype(np.float64)).max() <= 2.0 * 2.0 ** -14
         assert np.array_equal(out[name, "auto"][0], out[name, "1" if name == "big" else "0"][0])
+
+
+@pytest.mark.parametrize("viewport,n,bins", [((640, 400), 6000, 512), ((1920, 1080), 150_000, 2048), ((352, 288), 6000, 128),
+                                             ((256, 192), 6000, 0)])
+def test_single_pass_tile_sort_equals_the_digit_passes(ws, oracle, monkeypatch, viewport, n, bins):
+    """WS_TILE_SORT=wide: with at most 2048 binning tiles the tile-id sort is ONE stable counting pass over the whole tile id
+    (k_bin_emit leaves [sort tile][bin] counts, k_tile_col_scan_wide, k_tile_scatter_wide; the tile ranges are prefix sums
+    of the bin totals).  It must produce exactly what the default two digit passes produce: the same ranges, the same
+    entries in the same order -- hence the same image, bit for bit.  48 tiles (256x192) stay with the single 6-bit pass."""
+    rows = synth.scene_c2(n=n, seed=61) if n > 100_000 else synth.scene_c1(n=n, seed=61)
+    cj = (synth.orbit_cameras(8, viewport[0], viewport[1], 1500.0, 1500.0)[3] if n > 100_000 else synth.camera_c1(*viewport))
+    if n <= 100_000:
+        cj.fx = cj.fy = float(viewport[0])
+    out = {}
+    for mode in ("wide", "passes"):
+        if mode == "wide":
+            monkeypatch.setenv("WS_TILE_SORT", "wide")
+        else:
+            monkeypatch.delenv("WS_TILE_SORT", raising=False)
+        c = ws.Context(0)
+        gpc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
+        cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, *viewport)
+        cam.fit_near_far(gpc.aabb)
+        args = ws.SplattingArgs(camera=cam, viewport=viewport, max_sh_deg=3)
+        pc = ws.PointCloud(c, gpc)
+        r = ws.GaussianRenderer(c, "rgba32float", 3, False)
+        try:
+            r.enable_timers(2)
+            for _ in range(2):  # twice: the scratch (count rows, totals) is reused without being cleared
+                r.prepare(pc, args)
+                r.render(pc, background=(0.1, 0.2, 0.3, 1.0))
+            labels = [k for k, _ in r.kernel_times()]
+            st = r.frame_stats()
+            assert st["overflow"] == 0 and r.errors()[0] == 0 and st["num_tile_entries"] > 2048 * 2
+            out[mode] = (r.download_target(), r.tile_lists(), st, labels.count("tiles:k_sort_scatter"), r.binning_tile())
+        finally:
+            r.close()
+            pc.close()
+            c.close()
+    (img_w, (b_w, e_w, l_w), st_w, passes_w, bt_w), (img_p, (b_p, e_p, l_p), st_p, passes_p, bt_p) = out["wide"], out["passes"]
+    assert passes_w == 1 and passes_p == (2 if bins else 1)
+    assert bt_w == bt_p and st_w == st_p
+    assert np.array_equal(b_w, b_p) and np.array_equal(e_w, e_p)
+    assert np.array_equal(l_w, l_p)
+    assert np.array_equal(img_w, img_p)

@@ -172,16 +172,19 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
 // every slice (the tile-id sort's per-tile histogram of pass 0).  (Generating the entries inside the sort's first
 // pass instead -- no entry list in memory before it is half sorted -- was measured: the 12 B per entry saved did
 // not pay for generating everything twice, once to count and once to scatter.)
+// WIDE (the single-pass tile-id sort, sort.hip k_tile_scatter_wide): the whole tile id is the digit -- up to
+// TILE_SORT_WIDE_MAX_BINS counters per slice, written as ONE contiguous row tile_hist[slice][bin] (tile_hist_pitch = bins).
 constexpr int EMIT_COPIES = 2;
 
-template <bool PACKED>
+template <bool PACKED, bool WIDE>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src, uint32_t* __restrict__ entry_keys,
                                                          uint32_t* __restrict__ entry_vals,
                                                          uint32_t* __restrict__ tile_hist, uint32_t tile_hist_pitch,
                                                          uint32_t tile_hist_mask, int key16) {
+    constexpr int HIST_WORDS = WIDE ? TILE_SORT_WIDE_MAX_BINS : RADIX * EMIT_COPIES;
     __shared__ uint32_t s_off[emit::OFF_WORDS];
     __shared__ uint32_t s_own[emit::OWN_WORDS];
-    __shared__ uint32_t s_hist[RADIX * EMIT_COPIES];
+    __shared__ uint32_t s_hist[HIST_WORDS];
     __shared__ uint32_t s_wmax[BIN_THREADS / 64];
     const uint32_t d = src.counters->num_entries;
     const uint32_t v = src.counters->num_visible;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
     const uint32_t copy = (uint32_t)tid & (EMIT_COPIES - 1);
     // capped grid, workgroups stride over the slices (the host only knows the capacity, not D)
     for (uint32_t slice = blockIdx.x; (uint64_t)slice * EMIT_TILE < d; slice += gridDim.x) {
-        for (int k = tid; k < RADIX * EMIT_COPIES; k += BIN_THREADS) s_hist[k] = 0u;
+        for (int k = tid; k < (WIDE ? (int)tile_hist_pitch : RADIX * EMIT_COPIES); k += BIN_THREADS) s_hist[k] = 0u;
         const emit::Slice sl = emit::slice_setup(src, slice, d, v, s_off, s_own, s_wmax);
         // (the frame may bin at twice the blend's tile size: the same packed rectangles in units of 2 x 2 tiles)
         const bool coarse = PACKED && src.counters->bin_shift != 0u;
@@ -226,11 +229,16 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
                     if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
                     else entry_keys[e] = key;
                     entry_vals[e] = val[j];
-                    atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
+                    if (WIDE) atomicAdd(&s_hist[key], 1u);  // (key < tiles <= bins)
+                    else atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
                 }
             }
         }
-        if (tile_hist) {  // digit counts of sort tile `slice` for the tile-id sort's first pass ([digit][tile])
+        if (WIDE) {  // bin counts of sort tile `slice` for the single-pass tile-id sort ([tile][bin])
+            __syncthreads();
+            for (uint32_t k = (uint32_t)tid; k < tile_hist_pitch; k += BIN_THREADS)
+                tile_hist[(size_t)slice * tile_hist_pitch + k] = s_hist[k];
+        } else if (tile_hist) {  // digit counts of sort tile `slice` for the tile-id sort's first pass ([digit][tile])
             __syncthreads();
             uint32_t c = 0;
 #pragma unroll
@@ -1293,12 +1301,17 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     src.vh = b.vh;
     src.tile_w_log2 = b.tile_w_log2;
     src.tile_h_log2 = b.tile_h_log2;
-    if (b.footprint_mode == FP_RECT_PACKED)
-        hipLaunchKernelGGL(k_bin_emit<true>, dim3(blocks), dim3(BIN_THREADS), 0, stream, src, b.entry_keys, b.entry_vals,
-                           b.tile_hist, b.tile_hist_pitch, b.tile_hist_mask, b.key16);
-    else
-        hipLaunchKernelGGL(k_bin_emit<false>, dim3(blocks), dim3(BIN_THREADS), 0, stream, src, b.entry_keys, b.entry_vals,
-                           b.tile_hist, b.tile_hist_pitch, b.tile_hist_mask, b.key16);
+    if (b.tile_hist_wide && (!b.tile_hist || !b.key16 || b.tile_hist_pitch > (uint32_t)TILE_SORT_WIDE_MAX_BINS))
+        return fail(WS_ERR_INVALID, "bin emit: the single-pass tile sort needs its count rows, 16-bit keys and at most 2048 bins");
+#define WS_EMIT(PACKED_, WIDE_)                                                                                        \
+    hipLaunchKernelGGL((k_bin_emit<PACKED_, WIDE_>), dim3(blocks), dim3(BIN_THREADS), 0, stream, src, b.entry_keys,   \
+                       b.entry_vals, b.tile_hist, b.tile_hist_pitch, b.tile_hist_mask, b.key16)
+    if (b.footprint_mode == FP_RECT_PACKED) {
+        if (b.tile_hist_wide) WS_EMIT(true, true); else WS_EMIT(true, false);
+    } else {
+        if (b.tile_hist_wide) WS_EMIT(false, true); else WS_EMIT(false, false);
+    }
+#undef WS_EMIT
     WS_HIP(hipGetLastError());
     return WS_OK;
 }

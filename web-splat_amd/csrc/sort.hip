@@ -463,6 +463,175 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
 
 
 // =====================================================================================================================
+// Single-pass tile-id sort (ws_internal.h launch_tile_sort_wide): counts [tile][bins] -> column scan -> scatter.
+// =====================================================================================================================
+// Column scan.  One workgroup = 16 neighbouring bins (one 64-B line per tile row) x 64 runs of consecutive tiles: a wave's
+// load is four full lines.  Run sums -> exclusive prefix over the 64 runs of a bin (LDS) -> the run's offsets in place.
+constexpr int WIDE_SCAN_THREADS = 1024;
+__global__ __launch_bounds__(WIDE_SCAN_THREADS) void k_tile_col_scan_wide(const uint32_t* __restrict__ d_count, uint32_t n,
+                                                                         uint32_t tile_n, uint32_t* __restrict__ tile_sums,
+                                                                         uint32_t bins, uint32_t* __restrict__ hist) {
+    constexpr int RUNS = WIDE_SCAN_THREADS / 16;
+    __shared__ uint32_t s_run[RUNS][17];
+    const uint32_t count = device_count(d_count, n);
+    const uint32_t ntiles = (count + tile_n - 1) / tile_n;
+    const uint32_t dl = threadIdx.x & 15u, run = threadIdx.x >> 4;
+    const uint32_t d = blockIdx.x * 16u + dl;
+    const uint32_t per = (ntiles + RUNS - 1) / RUNS;  // block-uniform
+    const uint32_t t0 = run * per < ntiles ? run * per : ntiles;
+    const uint32_t t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    uint32_t* col = tile_sums + d;
+    uint32_t sum = 0;
+#pragma unroll 8
+    for (uint32_t t = t0; t < t1; ++t) sum += col[(size_t)t * bins];
+    s_run[run][dl] = sum;
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+#pragma unroll 8
+    for (int r = 0; r < RUNS; ++r) {
+        const uint32_t c = s_run[r][dl];
+        off += (uint32_t)r < run ? c : 0u;
+        total += c;
+    }
+#pragma unroll 8
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = col[(size_t)t * bins];
+        col[(size_t)t * bins] = off;
+        off += c;
+    }
+    if (run == 0) hist[d] = total;
+}
+
+// Scatter.  Thread i owns bins [8 i, 8 i + 8) for everything that is per bin and tile-independent (first output position
+// of the bin = exclusive prefix of the totals; workgroup 0 also writes the ranges from it).  Per tile: the bases of its bins
+// (bin base + the tile's column offset: two 16-B loads per thread), the ballot ranking of k_sort_scatter over BITS bits with
+// per-wave bin counters in LDS, the prefix of those counters over the waves, and the values go straight to their final
+// place: with up to 2048 bins a tile's 2048 pairs form runs of one or two, there is nothing for an LDS reorder to merge.
+template <int KPT, int BITS>
+__global__ __launch_bounds__(SORT_THREADS) void k_tile_scatter_wide(
+    const uint16_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ vals_out,
+    const uint32_t* __restrict__ d_count, uint32_t n, const uint32_t* __restrict__ hist,
+    const uint32_t* __restrict__ tile_off, uint2* __restrict__ ranges, uint32_t nranges) {
+    constexpr int TILE_N = SORT_THREADS * KPT;
+    constexpr int BINS = 1 << BITS;
+    constexpr int BPT = BINS / SORT_THREADS > 0 ? BINS / SORT_THREADS : 1;  // bins per thread (BITS >= 8), else one per thread < BINS
+    static_assert(BITS >= 7 && BITS <= TILE_SORT_WIDE_MAX_BITS, "single-pass tile sort: 7..11 bits");
+    // per-wave bin counters, two waves per word (a wave holds 64 * KPT <= 65535 pairs): 16 KB instead of 32 at 2048 bins
+    static_assert(WAVES == 4 && 64 * KPT * WAVES <= 0xFFFF, "packed wave counters");
+    __shared__ uint32_t s_wave_hist[WAVES / 2][BINS];
+    __shared__ uint32_t s_base[BINS];
+    __shared__ uint32_t s_tmp[WAVES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wsel = wave >> 1;
+    const uint32_t wsh = (uint32_t)(wave & 1) * 16u;
+    const uint32_t count = device_count(d_count, n);
+    const uint32_t ntiles = (count + TILE_N - 1) / TILE_N;
+    const bool owner = (uint32_t)tid * BPT < (uint32_t)BINS;  // (BITS == 7: threads 128.. own no bin)
+
+    uint32_t gbase[BPT];
+    {
+        uint32_t h[BPT];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            h[i] = owner ? hist[tid * BPT + i] : 0u;
+            sum += h[i];
+        }
+        uint32_t run = block_exclusive_scan(sum, s_tmp, nullptr);
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            gbase[i] = run;
+            const uint32_t d = (uint32_t)(tid * BPT + i);
+            if (blockIdx.x == 0 && owner && d < nranges && h[i]) ranges[d] = make_uint2(0xFFFFFFFFu - run, run + h[i]);
+            run += h[i];
+        }
+    }
+    const uint32_t lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xFFFFFFFFu;
+    const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
+
+    for (uint32_t L = blockIdx.x; (L >> 3) < ((ntiles + 7u) >> 3); L += gridDim.x) {
+        uint32_t t;
+        if (!xcd_tile(L, ntiles, &t)) continue;  // block-uniform
+        const uint32_t tile_base = t * TILE_N;
+        // ---- load (wave-striped: order inside the tile = (wave, j, lane)) ----
+        uint32_t key[KPT], val[KPT];
+        const uint32_t wave_base = tile_base + wave * (64 * KPT) + lane;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t pos = wave_base + j * 64;
+            key[j] = pos < count ? (uint32_t)keys_in[pos] : (uint32_t)(BINS - 1);  // padding: ranked behind the tile's own pairs
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t pos = wave_base + j * 64;
+            val[j] = pos < count ? vals_in[pos] : 0u;
+        }
+        if (owner) {
+            const uint32_t* row = tile_off + (size_t)t * BINS + tid * BPT;
+#pragma unroll
+            for (int i = 0; i < BPT; ++i) s_base[tid * BPT + i] = gbase[i] + row[i];
+        }
+#pragma unroll
+        for (int w = 0; w < WAVES / 2; ++w)
+#pragma unroll
+            for (int i = 0; i < (BINS + SORT_THREADS - 1) / SORT_THREADS; ++i)
+                if (BINS >= SORT_THREADS || tid < BINS) s_wave_hist[w][tid + i * SORT_THREADS] = 0u;
+        __syncthreads();
+        // ---- rank inside the wave (k_sort_scatter's three phases, BITS ballots per pair) ----
+        uint32_t info[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t d = key[j] & (uint32_t)(BINS - 1);
+            uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
+#pragma unroll
+            for (int bit = 0; bit < BITS; ++bit) {
+                const uint32_t B = (uint32_t)(-(int32_t)((d >> bit) & 1u));
+                const unsigned long long bal = __ballot(B != 0u);
+                mlo &= ~((uint32_t)bal ^ B);
+                mhi &= ~((uint32_t)(bal >> 32) ^ B);
+            }
+            const uint32_t below = (uint32_t)__popc(mlo & lt_lo) + (uint32_t)__popc(mhi & lt_hi);
+            const uint32_t leader = mlo ? (uint32_t)(__ffs((int)mlo) - 1) : 32u + (uint32_t)(__ffs((int)mhi) - 1);
+            const uint32_t cnt = (below == 0u) ? (uint32_t)(__popc(mlo) + __popc(mhi)) : 0u;
+            info[j] = below | (leader << 8) | (cnt << 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t prev[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t d = key[j] & (uint32_t)(BINS - 1);
+            prev[j] = 0u;
+            if (info[j] >> 16) prev[j] = (atomicAdd(&s_wave_hist[wsel][d], (info[j] >> 16) << wsh) >> wsh) & 0xFFFFu;
+        }
+        uint32_t rank[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) rank[j] = __shfl(prev[j], (int)((info[j] >> 8) & 63u), 64) + (info[j] & 63u);
+        __syncthreads();
+        // ---- per bin: exclusive prefix of the wave counters over the waves (bins tid, tid + 256, ...: conflict-free) ----
+#pragma unroll
+        for (int i = 0; i < (BINS + SORT_THREADS - 1) / SORT_THREADS; ++i) {
+            const int d = tid + i * SORT_THREADS;
+            if (BINS >= SORT_THREADS || tid < BINS) {
+                const uint32_t w01 = s_wave_hist[0][d], w23 = s_wave_hist[1][d];
+                const uint32_t c0 = w01 & 0xFFFFu, c1 = w01 >> 16, c2 = w23 & 0xFFFFu;
+                s_wave_hist[0][d] = c0 << 16;                              // wave 0: 0, wave 1: c0
+                s_wave_hist[1][d] = (c0 + c1) | ((c0 + c1 + c2) << 16);   // wave 2, wave 3
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t pos = wave_base + j * 64;
+            const uint32_t d = key[j] & (uint32_t)(BINS - 1);
+            if (pos < count) vals_out[s_base[d] + ((s_wave_hist[wsel][d] >> wsh) & 0xFFFFu) + rank[j]] = val[j];
+        }
+        __syncthreads();  // LDS is reused by the next tile
+    }
+}
+
+// =====================================================================================================================
 // Depth sort: three range-adaptive digit passes, two launches per pass (ws_internal.h, DepthSortScratch).
 // =====================================================================================================================
 struct DSortPlan {
@@ -1000,6 +1169,35 @@ int launch_key_minmax(const uint32_t* keys, const uint32_t* d_count, uint32_t n,
     uint32_t blocks = (n + SORT_THREADS * 16 - 1) / (SORT_THREADS * 16);
     if (blocks > 1024u) blocks = 1024u;
     hipLaunchKernelGGL(k_key_minmax, dim3(blocks), dim3(SORT_THREADS), 0, stream, keys, d_count, n, key_range);
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
+int launch_tile_sort_wide(const SortScratch& sc, const uint32_t* keys16, const uint32_t* vals, const uint32_t* d_count,
+                          uint32_t n, int bits, hipStream_t stream, KernelMarks* km, uint2* ranges, uint32_t nranges) {
+    if (n == 0) return WS_OK;
+    if (bits < 7) bits = 7;
+    const uint32_t bins = 1u << bits;
+    if (bits > TILE_SORT_WIDE_MAX_BITS || sc.wide_bins < bins || !sc.wide_hist || n > sc.cap || nranges > bins)
+        return fail(WS_ERR_INVALID, "tile sort: the single-pass form needs at most 2048 ids and scratch sized for them");
+    if (sort_tile_size(n) != (uint32_t)SORT_TILE) return fail(WS_ERR_INVALID, "tile sort: the single-pass form uses the large sort tile");
+    const uint32_t tiles = sort_grid((n + SORT_TILE - 1) / SORT_TILE);
+    hipLaunchKernelGGL(k_tile_col_scan_wide, dim3(bins / 16u), dim3(WIDE_SCAN_THREADS), 0, stream, d_count, n,
+                       (uint32_t)SORT_TILE, sc.tile_sums, bins, sc.wide_hist);
+    km_mark(km, "tiles:k_sort_col_scan");
+    const uint16_t* k16 = reinterpret_cast<const uint16_t*>(keys16);
+#define WS_WIDE(BITS_)                                                                                                 \
+    hipLaunchKernelGGL((k_tile_scatter_wide<SORT_KPT, BITS_>), dim3(tiles), dim3(SORT_THREADS), 0, stream, k16, vals,  \
+                       sc.vals_alt, d_count, n, sc.wide_hist, sc.tile_sums, ranges, nranges)
+    switch (bits) {
+        case 7: WS_WIDE(7); break;
+        case 8: WS_WIDE(8); break;
+        case 9: WS_WIDE(9); break;
+        case 10: WS_WIDE(10); break;
+        default: WS_WIDE(11); break;
+    }
+#undef WS_WIDE
+    km_mark(km, "tiles:k_sort_scatter");
     WS_HIP(hipGetLastError());
     return WS_OK;
 }

@@ -182,11 +182,13 @@ static void free_sort_scratch(SortScratch& sc, bool own_alt) {
     }
     dfree(sc.status);
     dfree(sc.tile_sums);
+    dfree(sc.wide_hist);
     sc = SortScratch();
 }
 
 // status words are zeroed ONCE here; afterwards the epoch tag makes stale words invisible (lookback.h)
-static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, bool one_sweep) {
+// wide_bins != 0: also room for the [tiles][wide_bins] count rows of the single-pass tile-id sort (launch_tile_sort_wide)
+static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, bool one_sweep, uint32_t wide_bins = 0) {
     sc.cap = cap;
     sc.tiles = (cap + SORT_TILE - 1) / SORT_TILE;
     if (sc.tiles == 0) sc.tiles = 1;
@@ -202,7 +204,15 @@ static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, bool 
     const uint32_t small_n = std::min<uint32_t>(cap, SORT_SMALL_MAX);
     const uint32_t small_tiles = (small_n + SORT_THREADS * SORT_KPT_SMALL - 1) / (SORT_THREADS * SORT_KPT_SMALL);
     sc.tiles_cap = std::max<uint32_t>(std::max<uint32_t>(small_tiles, sc.tiles), 1u);
-    if ((rc = dmalloc(&sc.tile_sums, (size_t)sc.tiles_cap * RADIX))) return rc;
+    size_t sum_words = (size_t)sc.tiles_cap * RADIX;
+    // (4 B x tiles x bins: 8 KiB per 2048 entries of capacity at 2048 bins, 1.3 x the entry lists themselves; beyond 1 GiB
+    // -- 250 M entries -- the tile sort stays with its digit passes)
+    if (wide_bins && (size_t)sc.tiles * wide_bins * sizeof(uint32_t) <= ((size_t)1 << 30)) {
+        sc.wide_bins = wide_bins;
+        sum_words = std::max(sum_words, (size_t)sc.tiles * wide_bins);
+        if ((rc = dmalloc(&sc.wide_hist, (size_t)wide_bins))) return rc;
+    }
+    if ((rc = dmalloc(&sc.tile_sums, sum_words))) return rc;
     return WS_OK;
 }
 
@@ -306,7 +316,17 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     r->sort_depth.keys_alt = r->keys_b;
     r->sort_depth.vals_alt = r->vals_b;
     r->sort_depth.hist = r->zero->depth_hist;
-    if ((rc = alloc_sort_scratch(r->sort_tiles, r->entry_cap, false, r->ctx->sort_algo == 1))) return rc;
+    // WS_TILE_SORT=wide: the tile-id sort is ONE counting pass when the viewport has at most 2048 binning tiles
+    uint32_t wide_bins = 0;
+    {
+        const uint32_t ntiles = r->tiles_x * r->tiles_y;
+        if (r->ctx->tile_sort_wide && r->ctx->sort_algo != 1 && ntiles > 64u && ntiles <= (uint32_t)TILE_SORT_WIDE_MAX_BINS &&
+            sort_tile_size(r->entry_cap) == (uint32_t)EMIT_TILE) {
+            wide_bins = 128u;
+            while (wide_bins < ntiles) wide_bins <<= 1;
+        }
+    }
+    if ((rc = alloc_sort_scratch(r->sort_tiles, r->entry_cap, false, r->ctx->sort_algo == 1, wide_bins))) return rc;
     r->sort_tiles.keys_alt = r->ekeys_b;
     r->sort_tiles.vals_alt = r->evals_b;
     r->sort_tiles.hist = r->zero->tile_hist;
@@ -363,6 +383,12 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->device = hip_device;
     WS_HIP(hipGetDeviceProperties(&ctx->props, hip_device));
     ctx->sort_algo = env_int("WS_SORT_ALGO", 0);
+    {   // WS_TILE_SORT=wide: ONE counting pass over the whole tile id up to 2048 binning tiles instead of two digit passes.
+        // Measured (profiles/r03/tile_sort_wide_ab_v20_summary.txt): one frame at a time +1..+5 % (three launches fewer), with
+        // frames in flight -0.5..-5 %: at 2048 bins the [sort tile][bin] count rows are as many bytes as the entries themselves.
+        const char* ts = std::getenv("WS_TILE_SORT");
+        ctx->tile_sort_wide = ts && std::strcmp(ts, "wide") == 0;
+    }
     if (const char* ds = std::getenv("WS_DEPTH_SORT")) ctx->depth_sort_adaptive = std::strcmp(ds, "adaptive") == 0;
     if (ctx->sort_algo == 1) ctx->depth_sort_adaptive = false;  // the one-sweep cross-check path is a generic-sorter path
     ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
@@ -880,6 +906,14 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
         tile_bits = tile_passes * RADIX_BITS;
     }
     bb.tile_hist_mask = (1u << digit_bits) - 1u;
+    // ONE counting pass over the whole tile id when the scratch was sized for it (at most 2048 binning tiles): the emit
+    // kernel leaves [sort tile][bin] counts, a column scan and a scatter follow -- two launches instead of five, the
+    // entries are read once, and the tile ranges are prefix sums of the bin totals (launch_tile_sort_wide)
+    const bool wide_sort = fused_hist && r->sort_tiles.wide_bins >= ntiles && ntiles > 64u && r->sort_tiles.wide_bins != 0u;
+    int wide_bits = 7;
+    while ((1u << wide_bits) < ntiles) ++wide_bits;
+    bb.tile_hist_wide = wide_sort ? 1 : 0;
+    if (wide_sort) bb.tile_hist_pitch = 1u << wide_bits;
     // tile ids fit 16 bits up to 65534 tiles (4096 x 4080 px): the key arrays of the tile sort then hold uint16_t
     const bool key16 = r->ctx->sort_algo != 1 && ntiles < 65535u;
     bb.key16 = key16 ? 1 : 0;
@@ -894,9 +928,14 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
         return WS_OK;
     }
     uint32_t *ek = nullptr, *evv = nullptr;
-    if ((rc = launch_sort_pairs(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap, 0,
-                                tile_bits, false, fused_hist, r->ctx->sort_algo, r->epoch, stream, &ek, &evv, km,
-                                "tiles:", r->tile_ranges, ntiles, digit_bits, key16)))
+    if (wide_sort) {
+        if ((rc = launch_tile_sort_wide(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap,
+                                        wide_bits, stream, km, r->tile_ranges, ntiles)))
+            return rc;
+        evv = r->sort_tiles.vals_alt;
+    } else if ((rc = launch_sort_pairs(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap, 0,
+                                       tile_bits, false, fused_hist, r->ctx->sort_algo, r->epoch, stream, &ek, &evv, km,
+                                       "tiles:", r->tile_ranges, ntiles, digit_bits, key16)))
         return rc;
     r->entries_sorted = evv;  // the last pass wrote the per-tile ranges instead of the sorted tile ids
     if (r->timers) {

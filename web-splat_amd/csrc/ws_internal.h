@@ -191,6 +191,10 @@ constexpr int SORT_KPT_SMALL = 4;                     // small inputs: 1024-key 
 constexpr uint32_t SORT_SMALL_MAX = WS_SORT_SMALL_MAX;  // host-side bound n up to which the small tile is used
 uint32_t sort_tile_size(uint32_t n);                  // tile size the scan path (algo 0) uses for bound n
 
+// Single-pass tile-id sort (launch_tile_sort_wide): the whole tile id is ONE digit of up to 11 bits.
+constexpr int TILE_SORT_WIDE_MAX_BITS = 11;
+constexpr int TILE_SORT_WIDE_MAX_BINS = 1 << TILE_SORT_WIDE_MAX_BITS;
+
 struct SortScratch {
     uint32_t* keys_alt = nullptr;     // ping-pong partner of the caller's key buffer   [cap]
     uint32_t* vals_alt = nullptr;     // ping-pong partner of the caller's value buffer [cap]
@@ -202,6 +206,8 @@ struct SortScratch {
     uint32_t cap = 0;
     uint32_t tiles = 0;               // ceil(cap / SORT_TILE): one-sweep status rows per pass
     uint32_t tiles_cap = 0;           // row pitch of tile_sums: the largest tile count any n <= cap can need
+    uint32_t wide_bins = 0;           // != 0: tile_sums also holds [tiles][wide_bins] rows (launch_tile_sort_wide)
+    uint32_t* wide_hist = nullptr;    // [wide_bins] totals per bin, written by the wide column scan
 };
 
 // Launch an ascending stable LSD radix sort of (key, value) pairs on `stream`.
@@ -222,6 +228,18 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                       int digit_bits = RADIX_BITS, bool key16 = false, uint32_t* aux = nullptr, uint32_t* aux_alt = nullptr);
 //   aux / aux_alt (scan path only): a 4-byte companion value per pair travels with the payload; the result lands where
 //     the payload lands (aux for an even pass count, aux_alt for an odd one).
+
+// ---- single-pass tile-id sort (sort.hip) ---------------------------------------------------------------------------
+// Stable counting sort of n (16-bit tile id, value) pairs whose ids are below `bins` = 2^bits <= 2048, in TWO launches:
+// the producer (k_bin_emit<., WIDE>) has left the per-tile bin counts in sc.tile_sums as [tile][bins] (tile = SORT_TILE
+// consecutive pairs); k_tile_col_scan_wide turns every column into exclusive offsets and writes the bin totals, and
+// k_tile_scatter_wide ranks each tile's pairs per bin (ballot match, as the digit passes do) and writes the VALUES only,
+// to sc.vals_alt.  The ranges of the ids in the sorted order are prefix sums of the totals: ranges[id] = (0xFFFFFFFF -
+// begin, end) for non-empty ids (zero on entry), no atomics.  Against the two 6-bit passes it replaces: 2 launches instead
+// of 5, the pairs are read once instead of twice and never written back as pairs -- but the count rows are 4 B x bins per
+// 2048 pairs, at 2048 bins as many bytes as the pairs: faster alone, slower with frames in flight (WS_TILE_SORT=wide).
+int launch_tile_sort_wide(const SortScratch& sc, const uint32_t* keys16, const uint32_t* vals, const uint32_t* d_count,
+                          uint32_t n, int bits, hipStream_t stream, KernelMarks* km, uint2* ranges, uint32_t nranges);
 
 // ---- depth sort: range-adaptive three-pass LSD sort of the frame's depth keys (sort.hip) ------------------------
 // Exactly the order of a stable ascending sort on the full 32-bit keys.  The keys of a frame occupy a narrow range
@@ -307,6 +325,7 @@ struct BinBuffers {
     uint32_t* tile_hist;         // nullptr, or the tile sort's tile_sums: emit workgroup m also writes the digit
     uint32_t tile_hist_pitch;    //   counts (first digit of the tile id) of sort tile m -> no histogram pass 0
     uint32_t tile_hist_mask;     //   (1 << digit bits of the tile sort) - 1
+    int tile_hist_wide;          // single-pass tile sort: tile_hist is [sort tile][bins], tile_hist_pitch = bins (<= 2048)
     int key16;                   // entry_keys holds uint16_t tile ids (fewer than 65535 tiles): 2 B less per entry
     uint32_t entry_cap;
     uint2* tile_ranges;          // [tiles] (begin, end) into the sorted entry list
@@ -383,6 +402,7 @@ struct ws_context {
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
     int footprint = 0;        // WS_FOOTPRINT=ellipse: FP_ELLIPSE (the default is FP_RECT_PACKED, FP_RECT_COUNT for wide viewports)
     int batch_k1 = 1;         // WS_BATCH_K1=n: a view batch runs K1 once for groups of n frames (1 = every frame its own K1)
+    bool tile_sort_wide = false; // WS_TILE_SORT=wide: single-pass tile-id sort up to 2048 binning tiles (launch_tile_sort_wide)
     int bin_request = 1;      // WS_BIN_SHIFT=0 | auto (default) | 1: BinRequest for frames that can use coarse binning
     int blend_persist = 0;    // WS_BLEND_PERSIST=1: k_blend_persist
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
