@@ -529,7 +529,10 @@ def analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world
                         "MFMA is unused and every kernel is priced against HBM; k_blend moves few bytes per "
                         "(pixel, splat) pair: what limits it is VALU issue and, on scenes whose tiles saturate after "
                         "one or two staged batches, the per-tile start-up latency (valu.issue_util, DESIGN.md 3.3); "
-                        "early-out makes its real traffic a fraction of the algorithmic bytes"}
+                        "early-out makes its real traffic a fraction of the algorithmic bytes.  D counts the entries of "
+                        "the frame's binned lists: a frame that bins at 64x64 (config.binning_tile) has half the entries "
+                        "of the same frame binned at the 32x32 compositing tile, so the same blend time prices at about "
+                        "half the fraction -- the frame got faster (fewer entries emitted and sorted), not the blend slower"}
     # the device picks the binning tile per frame (the compositing tile or 2 x 2 of them): D counts entries of THOSE lists
     bin_w, bin_h = r.binning_tile()
     out["config"].update({"binning_tile": f"{bin_w}x{bin_h}", "compositing_tile": f"{tile_w}x{tile_h}",
