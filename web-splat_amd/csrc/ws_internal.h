@@ -105,11 +105,14 @@ __host__ __device__ inline uint32_t rect_tiles(uint32_t r) {
 // The blend composites 32x32-px tiles (default shape).  Binning may use those tiles, or 2 x 2 blocks of them (64x64 px):
 // four blend workgroups then share one binned list -- half the (tile, splat) entries to emit and sort when splats span
 // several tiles, at the price of every entry being staged by up to four workgroups.  Measured (profiles/r03/bin64_*):
-// +16..+20 % frames/s where the rectangles shrink 2.07x (hd1m, c4), +3 % at 1.75x (c2), -14 % / -23 % at 1.14x / 1.10x
-// (c5, c3: pixel-sized splats).  K1 sums both tile counts while it writes the rectangles; the binning prefix derives
+// +16..+20 % frames/s where the rectangles shrink 2.07x (hd1m, c4), +3..+5 % at 1.75x (c2), -14 % / -23 % at 1.14x / 1.10x
+// (c5, c3: pixel-sized splats): the threshold sits just below the smallest ratio measured to win.  K1 sums both tile counts while it writes the rectangles; the binning prefix derives
 // the decision from the two sums (a pure function of the frame: ranks and renderers agree), no host round trip.
 enum BinRequest { BIN_NEVER = 0, BIN_AUTO = 1, BIN_ALWAYS = 2 };
-constexpr uint32_t BIN64_RATIO_PERCENT = 185u;  // coarse binning when the sum at the blend's tile size >= 1.85 x the sum at twice that
+#ifndef WS_BIN64_RATIO_PERCENT
+#define WS_BIN64_RATIO_PERCENT 170
+#endif
+constexpr uint32_t BIN64_RATIO_PERCENT = WS_BIN64_RATIO_PERCENT;  // coarse binning when the sum at the blend's tile size >= 1.70 x the sum at twice that
 __host__ __device__ inline uint32_t rect_tiles64(uint32_t r) {
     if (r == RECT_EMPTY) return 0u;
     const uint32_t x0 = r & 0xFFu, y0 = (r >> 8) & 0xFFu, x1 = x0 + ((r >> 16) & 0xFFu), y1 = y0 + (r >> 24);
