@@ -383,6 +383,7 @@ int ws_ply_rows_convert(const float* rows, uint32_t n, uint32_t sh_deg, void* ga
     const size_t row_len = 3 + 3 + 3 + (num_coefs - 1) * 3 + 1 + 3 + 4;
     uint8_t* gout = static_cast<uint8_t*>(gaussians_out);
     uint8_t* sout = static_cast<uint8_t*>(sh_out);
+    const ws::OmpQuietWorkers omp_quiet;  // (ws_internal.h: the region's workers sleep at once instead of spinning 200 ms)
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < static_cast<int64_t>(n); ++i) {
         const float* row = rows + static_cast<size_t>(i) * row_len;

@@ -155,6 +155,7 @@ static int ply_read_rows(const char* path, PlyHeader* h, uint32_t* sh_deg_out, s
     if (got != rows->size()) return fail(WS_ERR_IO, "ply: truncated vertex data");
     if (!h->little_endian) {
         uint32_t* w = reinterpret_cast<uint32_t*>(rows->data());
+        const ws::OmpQuietWorkers omp_quiet;  // (ws_internal.h: the region's workers sleep at once instead of spinning 200 ms)
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < (int64_t)rows->size(); ++i) w[i] = __builtin_bswap32(w[i]);
     }

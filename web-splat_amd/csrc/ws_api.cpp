@@ -531,6 +531,7 @@ int ws_pointcloud_create(ws_context* ctx, const ws_pointcloud_desc* d, ws_pointc
         const uint8_t* g = static_cast<const uint8_t*>(d->gaussians);
         const uint8_t* s = static_cast<const uint8_t*>(d->sh_coefs);
         uint32_t* st = staging.data();
+        const ws::OmpQuietWorkers omp_quiet;  // (ws_internal.h: the region's workers sleep at once instead of spinning 200 ms)
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < (int64_t)n; ++i) {
             const uint8_t* gi = g + (size_t)i * 28;
@@ -665,6 +666,7 @@ int ws_pointcloud_download(const ws_pointcloud* pc, void* gaussians, size_t gaus
     WS_HIP(hipMemcpy(st.data(), pc->planes, st.size() * 4, hipMemcpyDeviceToHost));
     uint8_t* g = static_cast<uint8_t*>(gaussians);
     uint8_t* s = static_cast<uint8_t*>(sh_coefs);
+    const ws::OmpQuietWorkers omp_quiet;  // (ws_internal.h: the region's workers sleep at once instead of spinning 200 ms)
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; ++i) {
         std::memcpy(g + (size_t)i * 28, st.data() + ((size_t)0 * n + i) * 4, 16);

@@ -8,7 +8,28 @@
 
 #include "websplat.h"
 
+#if defined(_OPENMP) && !defined(__HIP_DEVICE_COMPILE__)
+#include <omp.h>
+#endif
+
 namespace ws {
+
+// The library's host loops (scene re-layout, PLY row conversion) are OpenMP regions.  LLVM's OpenMP runtime keeps the
+// workers of a finished region SPINNING for KMP_BLOCKTIME -- 200 ms by default -- before they sleep; on a 128-thread host
+// that is 128 busy cores next to the thread that enqueues frames and to the HIP runtime's own threads.  Measured on the
+// MI355X box (scripts/slowmode_probe*.py): for ~0.2 s after a point cloud was created on another renderer's watch, four
+// frames in flight ran at 2 600 instead of 16 800 frames/s -- the "slow cells" of the N x resolution sweeps of rounds 2
+// and 3.  Every host function with a parallel region holds one of these: its workers go to sleep as the region ends.
+struct OmpQuietWorkers {
+    int saved = 0;
+#if defined(_OPENMP) && !defined(__HIP_DEVICE_COMPILE__)
+    OmpQuietWorkers() : saved(kmp_get_blocktime()) { kmp_set_blocktime(0); }
+    ~OmpQuietWorkers() { kmp_set_blocktime(saved); }
+#else
+    OmpQuietWorkers() {}
+    ~OmpQuietWorkers() {}
+#endif
+};
 
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const std::string& msg);
