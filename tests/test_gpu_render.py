@@ -559,7 +559,7 @@ def test_target_precision_blend_equals_the_oracles_per_blend_rounding(ws, ctx, o
 def test_binning_granularity_is_decided_per_frame_on_the_device(ws, oracle, monkeypatch):
     """K1 sums the tiles of every splat's rectangle at the blend's tile size and at twice that size; every later kernel
     derives the same decision from the two sums: bin at 64x64 (four 32x32 compositing workgroups share one list: half the
-    entries to emit and sort) when the rectangles shrink by 1.70x or more, else at 32x32.  The image is the same up to the
+    entries to emit and sort) when the rectangles shrink by 1.50x or more, else at 32x32.  The image is the same up to the
     early-out granularity, the oracle tolerance holds either way, WS_BIN_SHIFT=0 / 1 force the choice, capture mode always
     sees the blend's own tiles."""
     rng = np.random.default_rng(51)

@@ -127,13 +127,14 @@ __host__ __device__ inline uint32_t rect_tiles(uint32_t r) {
 // four blend workgroups then share one binned list -- half the (tile, splat) entries to emit and sort when splats span
 // several tiles, at the price of every entry being staged by up to four workgroups.  Measured (profiles/r03/bin64_*):
 // +16..+20 % frames/s where the rectangles shrink 2.07x (hd1m, c4), +3..+5 % at 1.75x (c2), -14 % / -23 % at 1.14x / 1.10x
-// (c5, c3: pixel-sized splats): the threshold sits just below the smallest ratio measured to win.  K1 sums both tile counts while it writes the rectangles; the binning prefix derives
+// (c5, c3: pixel-sized splats); an N x resolution sweep (profiles/r03/sweep_bin_auto_v24.json) has 64 px ahead (+1..+63 %) at
+// all ratios 1.75..2.63 and by +4 % on average (-3..+13 %) at 1.53: the threshold sits just below the smallest ratio measured to win.  K1 sums both tile counts while it writes the rectangles; the binning prefix derives
 // the decision from the two sums (a pure function of the frame: ranks and renderers agree), no host round trip.
 enum BinRequest { BIN_NEVER = 0, BIN_AUTO = 1, BIN_ALWAYS = 2 };
 #ifndef WS_BIN64_RATIO_PERCENT
-#define WS_BIN64_RATIO_PERCENT 170
+#define WS_BIN64_RATIO_PERCENT 150
 #endif
-constexpr uint32_t BIN64_RATIO_PERCENT = WS_BIN64_RATIO_PERCENT;  // coarse binning when the sum at the blend's tile size >= 1.70 x the sum at twice that
+constexpr uint32_t BIN64_RATIO_PERCENT = WS_BIN64_RATIO_PERCENT;  // coarse binning when the sum at the blend's tile size >= 1.50 x the sum at twice that
 __host__ __device__ inline uint32_t rect_tiles64(uint32_t r) {
     if (r == RECT_EMPTY) return 0u;
     const uint32_t x0 = r & 0xFFu, y0 = (r >> 8) & 0xFFu, x1 = x0 + ((r >> 16) & 0xFFu), y1 = y0 + (r >> 24);
