@@ -333,9 +333,10 @@ int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, 
  * function of the frame; WS_BIN_SHIFT=0 / 1 forces it off / on; frames in capture mode always use the context's tile).
  * Four compositing workgroups then share one binned list: half the (tile, splat) entries to emit and sort.  Syncs. */
 int ws_renderer_binning_tile(ws_renderer* r, uint32_t* width, uint32_t* height);
-/* The binning tile in pixels: 32x32 by default (four 16x16 tiles -- 4x4 wave quadrants of 8x8 pixels -- sharing one
- * binned list), 32x16 or 16x16 with WS_TILE_SHAPE=4x2|2x2 at context creation (tuning; 2x2 is the literal
- * one-workgroup-per-16x16-tile form). */
+/* The compositing tile in pixels (one workgroup of the blend): 32x32 by default (four 16x16 tiles -- 4x4 wave quadrants
+ * of 8x8 pixels -- sharing one binned list), 32x16 or 16x16 with WS_TILE_SHAPE=4x2|2x2 at context creation (tuning; 2x2 is
+ * the literal one-workgroup-per-16x16-tile form).  Lists are built per BINNING tile: this tile, or 2 x 2 of them when the
+ * frame decides so (ws_renderer_binning_tile). */
 int ws_context_tile_size(const ws_context* ctx, uint32_t* width, uint32_t* height);
 /* test hook, host only (no device work): the compositing pass's staging step for ONE (tile, splat) entry --
  * splat = the five 32-bit words of a 20-B Splat record (pointcloud.rs:352-358), tile origin in pixels ->
