@@ -311,6 +311,8 @@ def main():
     host_pg = None
     if dist is not None and dist.get_backend() == "nccl":
         dist.barrier()
+        if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: no hostname lookup (it may not resolve in a container)
         try:
             host_pg = dist.new_group(backend="gloo")
         except Exception as e:  # noqa: BLE001  (no usable interface for gloo: keep the RCCL barrier)
