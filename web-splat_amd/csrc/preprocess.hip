@@ -646,26 +646,6 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
             s_kmin_inv[wave] = kmin_inv;
         }
     }
-    // ---- the frame's footprint totals at both binning granularities (ws_internal.h bin_shift_decide) -----------------
-    if (FPMODE == FP_RECT_PACKED && p.bin_request == BIN_AUTO) {  // (uniform: only frames that let the device decide)
-        uint32_t t32 = 0u, t64 = 0u;
-#pragma unroll
-        for (int it = 0; it < K1_ITEMS; ++it)
-            if (vis[it]) {
-                t32 += rect_tiles(so[it].fp);
-                t64 += rect_tiles64(so[it].fp);
-            }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            t32 += (uint32_t)__shfl_xor((int)t32, o, 64);
-            t64 += (uint32_t)__shfl_xor((int)t64, o, 64);
-        }
-        if (lane == 0) {
-            s_t32[wave] = t32;
-            s_t64[wave] = t64;
-        }
-    }
-
     // ---- ordered compaction, part 2: look-back (wave 0) and scatter ----------------------------------------
     if (wave == 0) {
         // (measured: replacing the ordered look-back by one unordered atomicAdd per block does not change this kernel's
@@ -688,19 +668,6 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
         uint32_t* kr = b.key_range + (bid & (KEY_RANGE_SLOTS - 1)) * KEY_RANGE_STRIDE;
         atomicMax(kr, kmax);
         atomicMax(kr + 1, kmin_inv);
-        if (FPMODE == FP_RECT_PACKED && p.bin_request == BIN_AUTO) {
-            uint32_t t32 = 0u, t64 = 0u;
-#pragma unroll
-            for (int w = 0; w < K1_THREADS / 64; ++w) {
-                t32 += s_t32[w];
-                t64 += s_t64[w];
-            }
-            if (t32) {  // (returnless; one pair per workgroup that has a visible splat with a footprint)
-                uint32_t* ts = b.counters->tile_sums + (bid & (TILE_SUM_SLOTS - 1)) * TILE_SUM_STRIDE;
-                atomicAdd(ts, t32);
-                atomicAdd(ts + 1, t64);
-            }
-        }
     }
     const uint32_t base = s_base;
 #pragma unroll
@@ -716,6 +683,41 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
             b.keys[slot] = so[it].key;
             b.footprints[slot] = so[it].fp;
             if (b.src_index) b.src_index[slot] = block_base + it * K1_THREADS + tid;
+        }
+    }
+    // ---- the frame's footprint totals at both binning granularities (ws_internal.h bin_shift_decide) -----------------
+    if (FPMODE == FP_RECT_PACKED && p.bin_request == BIN_AUTO) {  // (uniform: only frames that let the device decide)
+        uint32_t t32 = 0u, t64 = 0u;
+#pragma unroll
+        for (int it = 0; it < K1_ITEMS; ++it)
+            if (vis[it]) {
+                t32 += rect_tiles(so[it].fp);
+                t64 += rect_tiles64(so[it].fp);
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            t32 += (uint32_t)__shfl_xor((int)t32, o, 64);
+            t64 += (uint32_t)__shfl_xor((int)t64, o, 64);
+        }
+        if (lane == 0) {
+            s_t32[wave] = t32;
+            s_t64[wave] = t64;
+        }
+    }
+    if (FPMODE == FP_RECT_PACKED && p.bin_request == BIN_AUTO) {  // (here, behind the stores: the kernel's registers are free)
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t t32 = 0u, t64 = 0u;
+#pragma unroll
+            for (int w = 0; w < K1_THREADS / 64; ++w) {
+                t32 += s_t32[w];
+                t64 += s_t64[w];
+            }
+            if (t32) {  // (returnless; one pair per workgroup that has a visible splat with a footprint)
+                uint32_t* ts = b.counters->tile_sums + (bid & (TILE_SUM_SLOTS - 1)) * TILE_SUM_STRIDE;
+                atomicAdd(ts, t32);
+                atomicAdd(ts + 1, t64);
+            }
         }
     }
 }
