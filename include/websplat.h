@@ -350,6 +350,14 @@ int ws_debug_stage_splat(const uint32_t splat[5], float viewport_w, float viewpo
  * `capacity` are written.  tile_w / tile_h: 16 or 32. */
 int ws_debug_footprint(const uint32_t splat[3], float viewport_w, float viewport_h, uint32_t tile_w, uint32_t tile_h,
                        uint32_t capacity, uint32_t* tiles, uint32_t* count);
+/* test hooks, host only: (1) the packed tile rectangle a splat carries through the depth sort (x0 | y0 << 8 | (w - 1) << 16 |
+ * (h - 1) << 24 in compositing tiles, 0xFFFFFFFF = lists no tile): the number of tiles it lists at the compositing tile and
+ * at 2 x 2 of them, and the same rectangle in units of 2 x 2 tiles -- the arithmetic K1, k_bin_prefix and k_bin_emit share;
+ * (2) the frame's binning decision from K1's per-slot sums of those two counts (request: 0 = never coarse, 1 = decide,
+ * 2 = always; nslots <= 16): *shift = 0 (lists per compositing tile) or 1 (per 2 x 2 of them). */
+int ws_debug_packed_rect(uint32_t rect, uint32_t* tiles, uint32_t* tiles_coarse, uint32_t* rect_coarse);
+int ws_debug_binning_decision(uint32_t request, const uint32_t* sums, const uint32_t* sums_coarse, uint32_t nslots,
+                              uint32_t* shift);
 /* tuning / analysis read-back: per tile LIST (one per binning tile, ws_renderer_binning_tile; row-major over
  * ceil(viewport / binning tile)), the length of the depth-ordered splat list and (capture mode, where the binning tile is
  * the compositing tile) how many of its entries the compositing pass walked before every pixel was saturated.  Syncs. */

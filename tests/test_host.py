@@ -277,3 +277,36 @@ def test_openmp_workers_sleep_after_a_host_region(ws):
         burn.append(time.process_time() - c0)
     # spinning workers would burn ~0.1 s per core (0.7 s on 8 cores); a sleeping team costs next to nothing
     assert min(burn) < 0.05, burn
+
+
+def test_packed_rectangle_at_both_binning_sizes(ws):
+    """The 4-byte word a splat carries through the depth sort is its tile rectangle; K1 sums its tile count at the compositing
+    tile and at 2 x 2 of them, the binning kernels read it in either unit (rect_tiles / rect_tiles64 / rect_coarse,
+    csrc/ws_internal.h).  Against a brute-force walk over the tiles."""
+    rng = np.random.default_rng(71)
+    cases = [(0, 0, 1, 1), (255, 255, 1, 1), (0, 0, 256, 256), (1, 1, 1, 1), (1, 0, 2, 3), (254, 3, 2, 2)]
+    for _ in range(3000):
+        x0, y0 = int(rng.integers(0, 256)), int(rng.integers(0, 256))
+        cases.append((x0, y0, int(rng.integers(1, 257 - x0)), int(rng.integers(1, 257 - y0))))
+    for x0, y0, w, h in cases:
+        rect = x0 | (y0 << 8) | ((w - 1) << 16) | ((h - 1) << 24)
+        if rect == 0xFFFFFFFF:   # the one rectangle whose word is the "no tile" marker: never produced (x0 = 255 has w = 1)
+            continue
+        tiles, coarse, rc = ws.packed_rect(rect)
+        cells = {(x >> 1, y >> 1) for x in range(x0, x0 + w) for y in range(y0, y0 + h)}
+        assert tiles == w * h and coarse == len(cells), (x0, y0, w, h)
+        cx0, cy0, cw, ch = rc & 0xFF, (rc >> 8) & 0xFF, ((rc >> 16) & 0xFF) + 1, (rc >> 24) + 1
+        assert {(x, y) for x in range(cx0, cx0 + cw) for y in range(cy0, cy0 + ch)} == cells
+    assert ws.packed_rect(0xFFFFFFFF) == (0, 0, 0xFFFFFFFF)
+
+
+def test_binning_decision_from_k1_sums(ws):
+    """bin_shift_decide: 2 x 2 binning iff the frame asks the device to decide and the summed tile counts shrink by 1.5x or
+    more; the sixteen slots K1's workgroups add into are folded first; never / always override."""
+    assert ws.binning_decision(1, [150], [100]) == 1
+    assert ws.binning_decision(1, [149], [100]) == 0
+    assert ws.binning_decision(1, [10] * 16, [7] * 16) == 0          # 160 : 112 = 1.43
+    assert ws.binning_decision(1, [10] * 15 + [18], [7] * 16) == 1   # 168 : 112 = 1.50
+    assert ws.binning_decision(1, [], []) == 0 and ws.binning_decision(1, [0], [0]) == 0   # an empty frame
+    assert ws.binning_decision(0, [1000], [100]) == 0 and ws.binning_decision(2, [100], [100]) == 1
+    assert ws.binning_decision(1, [4_000_000_000 // 16] * 16, [2_000_000_000 // 16] * 16) == 1   # sums near 2^32

@@ -439,6 +439,30 @@ int ws_debug_stage_splat(const uint32_t splat[5], float viewport_w, float viewpo
                              quadrant_mask);
 }
 
+int ws_debug_packed_rect(uint32_t rect, uint32_t* tiles, uint32_t* tiles_coarse, uint32_t* rect_coarse_out) {
+    if (!tiles || !tiles_coarse || !rect_coarse_out) return fail(WS_ERR_INVALID, "ws_debug_packed_rect: null argument");
+    *tiles = rect_tiles(rect);
+    *tiles_coarse = rect_tiles64(rect);
+    *rect_coarse_out = rect == RECT_EMPTY ? RECT_EMPTY : rect_coarse(rect);
+    return WS_OK;
+}
+
+int ws_debug_binning_decision(uint32_t request, const uint32_t* sums, const uint32_t* sums_coarse, uint32_t nslots,
+                              uint32_t* shift) {
+    if (!shift || (nslots && (!sums || !sums_coarse))) return fail(WS_ERR_INVALID, "ws_debug_binning_decision: null argument");
+    if (nslots > (uint32_t)TILE_SUM_SLOTS || request > (uint32_t)BIN_ALWAYS)
+        return fail(WS_ERR_INVALID, "ws_debug_binning_decision: at most 16 slots, request 0..2");
+    FrameCounters fc;
+    std::memset(&fc, 0, sizeof fc);
+    fc.bin_request = request;
+    for (uint32_t i = 0; i < nslots; ++i) {
+        fc.tile_sums[i * TILE_SUM_STRIDE] = sums[i];
+        fc.tile_sums[i * TILE_SUM_STRIDE + 1] = sums_coarse[i];
+    }
+    *shift = bin_shift_decide(&fc);
+    return WS_OK;
+}
+
 int ws_debug_footprint(const uint32_t splat[3], float viewport_w, float viewport_h, uint32_t tile_w, uint32_t tile_h,
                        uint32_t capacity, uint32_t* tiles, uint32_t* count) {
     if (!splat || !count || (capacity && !tiles)) return fail(WS_ERR_INVALID, "ws_debug_footprint: null argument");

@@ -159,6 +159,23 @@ def footprint_tiles(words, viewport, tile_size=(32, 32)):
     return out[:n.value]
 
 
+def packed_rect(rect):
+    """Test hook: (tiles, tiles at 2 x 2, the rectangle in units of 2 x 2 tiles) of a packed tile rectangle."""
+    t, tc, rc = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    check(lib.ws_debug_packed_rect(int(rect), C.byref(t), C.byref(tc), C.byref(rc)))
+    return t.value, tc.value, rc.value
+
+
+def binning_decision(request, sums, sums_coarse):
+    """Test hook: 0 / 1 = the frame bins at the compositing tile / at 2 x 2 of them, from K1's per-slot sums."""
+    n = len(sums)
+    a = (C.c_uint32 * max(n, 1))(*[int(x) for x in sums])
+    b = (C.c_uint32 * max(n, 1))(*[int(x) for x in sums_coarse])
+    sh = C.c_uint32()
+    check(lib.ws_debug_binning_decision(int(request), a, b, n, C.byref(sh)))
+    return sh.value
+
+
 class Context:
     def __init__(self, device: int = 0):
         h = C.c_void_p()
