@@ -36,6 +36,10 @@ def test_bench_one_rank_rccl_and_contract():
         assert key in out, key
     assert out["n_gpus"] == 1 and out["steps"] == 40 and out["warmup"] == 10 and out["value"] > 0
     assert out["config"]["workload"].startswith("c1:") and out["config"]["error_bits"] == 0
+    # the timed region is bracketed by host barriers (a gloo group beside the RCCL communicator) + device synchronize; the
+    # binning tile is what the device chose for the analysed frames (the compositing tile or 2 x 2 of them)
+    assert out["config"]["timing_barrier"].startswith(("host barrier (gloo group)", "nccl barrier"))
+    assert out["config"]["compositing_tile"] == "32x32" and out["config"]["binning_tile"] in ("32x32", "64x64")
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert abs(out["value"] - 40 / (out["ms_per_step"] * 40 / 1e3)) < 1e-6 * out["value"]
