@@ -133,14 +133,23 @@ def k1c_case(name):
 
 
 # ---- K6: vertex + fragment functions ----------------------------------------------------------------------------------
-def k6_fragments():
-    """For S splats of the k1_default fixture and the pixel centres of a window around each: vs_main's four vertices,
-    the interpolated screen_pos at the pixel, fs_main's premultiplied output (or discard)."""
-    k1 = np.load(os.path.join(HERE, "wgsl_k1_default.npz"))
+def k6_fragments(source="k1_default"):
+    """For S splats of a K1 fixture and the pixel centres of a window around each: vs_main's four vertices, the
+    interpolated screen_pos at the pixel, fs_main's premultiplied output (or discard).
+    source "k1_default": 48 random splats.  source "frame_opaque" (-> wgsl_k6_fragments_opaque.npz): every splat of that
+    fixture whose alpha is exactly 1.0 (wgsl_cases.opaque_rows) plus 10 random ones, and besides the thinned window EVERY
+    pixel centre within two pixels of the splat's centre -- the fragments that reach `min(0.99, .)` (gaussian.wgsl:65)."""
+    k1 = np.load(os.path.join(HERE, "wgsl_%s.npz" % source))
     w, h = (int(x) for x in k1["viewport"])
     splats = k1["splats"]
     rng = np.random.default_rng(5)
-    pick = np.sort(rng.choice(len(splats), size=48, replace=False))
+    dense = source != "k1_default"
+    if dense:
+        alpha_one = np.nonzero(splats.view(np.uint16).reshape(len(splats), -1)[:, 9] == 0x3C00)[0]
+        others = np.setdiff1d(np.arange(len(splats)), alpha_one)
+        pick = np.sort(np.concatenate([alpha_one, rng.choice(others, size=10, replace=False)]))
+    else:
+        pick = np.sort(rng.choice(len(splats), size=48, replace=False))
     m = W.Module(shader("gaussian.wgsl"))
     m.bind("points_2d", splats.tobytes())
     m.bind("indices", np.arange(len(splats), dtype=np.uint32).tobytes())
@@ -169,8 +178,14 @@ def k6_fragments():
             continue
         stride = max(1, int(np.sqrt(len(xs) * len(ys) / 60.0)))
         color = vo[0].f["color"]
-        for y in ys[::stride]:
-            for x in xs[::stride]:
+        pixels = [(x, y) for y in ys[::stride] for x in xs[::stride]]
+        if dense:  # every pixel centre within two pixels of the splat's centre (the mean of the quad's corners)
+            cx, cy = px.mean(), py.mean()
+            near = [(x, y) for y in range(int(cy) - 2, int(cy) + 3) for x in range(int(cx) - 2, int(cx) + 3)
+                    if 0 <= x < w and 0 <= y < h]
+            pixels = sorted(set(pixels) | set(near), key=lambda q: (q[1], q[0]))
+        for (x, y) in pixels:
+            if True:
                 ndc = np.array([(x + 0.5) / w * 2.0 - 1.0, 1.0 - (y + 0.5) / h * 2.0])
                 st = Ainv @ (ndc - P[0])
                 sp = Q[0] + dQ @ st
@@ -310,6 +325,7 @@ for c in wgsl_cases.K1C_CASES:
 CASES["k6_fragments"] = k6_fragments
 for c in wgsl_cases.FRAME_CASES:
     CASES[c] = (lambda c=c: frame(c))
+CASES["k6_fragments_opaque"] = lambda: k6_fragments("frame_opaque")   # (reads wgsl_frame_opaque.npz: generated after it)
 CASES["sort_small"] = lambda: sort_case(700, 11)
 CASES["sort_two_blocks"] = lambda: sort_case(5000, 12)
 

@@ -27,7 +27,12 @@ MUTATIONS = {
     "cull z <= 0 -> z < 0": ("preprocess.wgsl", "z <= 0.", "z < 0.", "k1_"),
     "K1c T=J*W": ("preprocess_compressed.wgsl", "let T = W * J;", "let T = J * W;", "k1c_"),
     "K1c cull z < 0 -> z <= 0": ("preprocess_compressed.wgsl", "z < 0.", "z <= 0.", "k1c_"),
+    # the draw (gaussian.wgsl:59-67): fixtures k6_fragments, k6_fragments_opaque, frame, frame_opaque
+    "alpha clamp 0.99 -> 0.98": ("gaussian.wgsl", "min(0.99, exp(-a) * in.color.a)", "min(0.98, exp(-a) * in.color.a)", ("k6_", "frame")),
+    "cut-off 2 CUTOFF -> 1.9 CUTOFF": ("gaussian.wgsl", "if a > 2. * CUTOFF", "if a > 1.9 * CUTOFF", ("k6_", "frame")),
 }
+# arrays of a fixture that are OUTPUTS of the shader text (inputs -- seeded scenes, uniforms -- cannot move)
+OUTPUT_KEYS = ("splats", "keys", "num_visible", "src_index", "frag_out", "frag_keep", "image", "fragments")
 
 
 def changed_files(mutation, only=None):
@@ -52,7 +57,7 @@ def changed_files(mutation, only=None):
             z = np.load(os.path.join(HERE, "wgsl_%s.npz" % case))
             try:
                 fresh = fn()
-                diff = any(not np.array_equal(np.asarray(fresh[k]), z[k]) for k in ("splats", "keys", "num_visible", "src_index"))
+                diff = any(not np.array_equal(np.asarray(fresh[k]), z[k]) for k in OUTPUT_KEYS if k in z.files)
             except Exception as e:  # noqa: BLE001  (a mutation may make a case fail outright: that is a change)
                 diff = True
             (moved if diff else same).append(case)

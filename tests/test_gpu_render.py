@@ -102,7 +102,8 @@ def test_single_splat_analytic(ws, ctx, oracle):
     row = np.zeros((1, 62), dtype=np.float32)
     row[0, 0:3] = [0.5, 0.0, 0.0]
     row[0, 6:9] = [1.0, 0.5, -0.5]
-    row[0, 54] = 2.0                      # opacity logit
+    row[0, 54] = 14.0                     # opacity logit: sigmoid = 1 - 8e-7, alpha = 1.0 as f16 -> the four pixel centres
+                                          # around the splat's centre have exp(-a) * alpha > 0.99: the clamp is reached
     row[0, 55:58] = np.log(0.05)          # isotropic scale
     row[0, 58:62] = [1, 0, 0, 0]
     cj = synth.look_at_camera(0, [0.5, 0.0, -2.0], [0.5, 0, 0], 128, 128, 256.0, 256.0)
@@ -124,6 +125,7 @@ def test_single_splat_analytic(ws, ctx, oracle):
         want = np.where(a <= 2 * 2.3539888583335364, np.minimum(0.99, np.exp(-a) * f[9]), 0.0)
         assert np.abs(img[..., 3] - want).max() < 1e-5
         assert (img[..., 3] == 0).sum() == (want == 0).sum()
+        assert f[9] == 1.0 and (want == 0.99).sum() >= 4 and (img[..., 3] == np.float32(0.99)).sum() == (want == 0.99).sum()
         lam = 0.5 * (M[0, 0] ** 2 + M[1, 0] ** 2)  # eigenvalue of the screen covariance
         sigma_px = 0.05 * 256.0 / 2.0              # sigma * f / z
         assert np.isclose(lam, sigma_px ** 2 + 0.3, rtol=2e-3)  # + dilation kernel (preprocess.wgsl:238-240)

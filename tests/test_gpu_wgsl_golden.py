@@ -78,13 +78,16 @@ def test_k1c_matches_the_reference_shader(ws, ctx, case):
         pc.close()
 
 
-def test_fragments_equal_the_reference_shader(ws, ctx, oracle):
+@pytest.mark.parametrize("fixture,source,scene", [("k6_fragments", "k1_default", "default"),
+                                                  ("k6_fragments_opaque", "frame_opaque", "frame_opaque")])
+def test_fragments_equal_the_reference_shader(ws, ctx, oracle, fixture, source, scene):
     """gaussian.wgsl vs_main + fs_main from source, for 48 splats at ~4000 pixel centres, against k_blend drawing the same
     Gaussian ALONE (a one-point cloud with the scene's bounding box, centre and camera, so K1 emits the same Splat record):
-    after one splat on a transparent target a pixel holds exactly the fragment's premultiplied output."""
-    z = load("k6_fragments")
-    k1 = load("k1_default")
-    sc = wgsl_cases.k1_scene(ws, oracle, "default")
+    after one splat on a transparent target a pixel holds exactly the fragment's premultiplied output.
+    `k6_fragments_opaque`: alpha = 1.0 splats sampled around their centres -- the fragments that reach `min(0.99, .)`."""
+    z = load(fixture)
+    k1 = load(source)
+    sc = wgsl_cases.k1_scene(ws, oracle, scene)
     w, h = sc.viewport
     keep = z["frag_keep"].astype(bool)
     a = (z["frag_screen_pos"].astype(np.float64) ** 2).sum(axis=1)
@@ -126,7 +129,9 @@ def test_fragments_equal_the_reference_shader(ws, ctx, oracle):
             checked += int(both.sum())
     finally:
         r.close()
-    assert checked > 800, checked
+    assert checked > (800 if fixture == "k6_fragments" else 300), checked
+    if fixture == "k6_fragments_opaque":
+        assert (z["frag_out"][keep, 3] == np.float32(0.99)).sum() >= 40
 
 
 @pytest.mark.parametrize("case", wgsl_cases.FRAME_CASES)
