@@ -126,6 +126,33 @@ def test_c5_compressed_4k_vs_oracle(ws, ctx, oracle, tmp_path):
                                "f32_target_vs_oracle_f32": {"max_abs": mx, "mean_abs": mean, "boundary_pixels_proven": nb}}
         _write_report()
         assert ok, msg
+        # GATED as on the uncompressed configurations (_full_parity): the target-precision blend -- the destination rounded
+        # after every splat, what the reference's blender leaves in an Rgba8Unorm (bin/measure.rs:184) or Rgba16Float
+        # (bin/render.rs:154) target -- against the oracle's per-blend modes composited from the library's own records
+        strict = {}
+        for f, mode in (("rgba16float", 1), ("rgba8unorm", 2)):
+            rt = ws.GaussianRenderer(ctx, f, 3, True)
+            try:
+                rt.set_blend_mode("target")
+                rt.prepare(pc, args)
+                rt.render(pc)
+                got = rt.download_target()
+                fr = rt.download_frame()
+                assert rt.errors()[0] == 0
+            finally:
+                rt.close()
+            want = oracle.render(fr["splats"], fr["sorted"], viewport[0], viewport[1], (0, 0, 0, 0), mode)
+            if mode == 1:
+                lsb = scenes.half_ulp_diff(got.view(np.uint16), want.astype(np.float16).view(np.uint16)).astype(np.int64)
+            else:
+                lsb = np.abs(got.astype(np.int64) - np.rint(want * 255.0).astype(np.int64))
+            strict[f] = {"max_lsb": int(lsb.max()), "values_off_by_1": int((lsb == 1).sum()),
+                         "values_off_by_more": int((lsb > 1).sum()), "values": int(lsb.size)}
+        _REPORT["c5/view1"]["target_precision_blend_vs_oracle_per_blend"] = strict
+        _write_report()
+        for f, g in strict.items():
+            allowed = 4 * max(4, int(scenes.BOUNDARY_PIXEL_FRACTION * viewport[0] * viewport[1]))
+            assert g["values_off_by_1"] <= 1e-3 * g["values"] and g["values_off_by_more"] <= allowed, ("c5", f, g)
     finally:
         r.close()
         pc.close()

@@ -270,7 +270,9 @@ def test_ply_file_roundtrip(ws, ctx, oracle, tmp_path):
                                  {"WS_TILE_SHAPE": "4x4", "WS_BLEND_TPW_LOG2": "1"},
                                  {"WS_TILE_SHAPE": "4x2", "WS_BLEND_TPW_LOG2": "2"},
                                  {"WS_DEPTH_SORT": "adaptive"}, {"WS_DEPTH_SORT": "adaptive", "WS_TILE_SHAPE": "2x2"},
-                                 {"WS_BLEND_SPLIT": "1"}, {"WS_BLEND_SPLIT": "0"}])
+                                 {"WS_BLEND_SPLIT": "1"}, {"WS_BLEND_SPLIT": "0"},
+                                 {"WS_BLEND_DMA": "1"}, {"WS_BLEND_DMA": "1", "WS_BLEND_TPW_LOG2": "2"},
+                                 {"WS_DEPTH_SORT": "onesweep"}, {"WS_DEPTH_SORT": "coop"}, {"WS_DEPTH_SORT": "scan"}])
 def test_cross_check_paths(ws, oracle, env, monkeypatch):
     """The alternative implementations kept as cross-checks (one-sweep look-back sort, range-adaptive three-pass depth
     sort, wave-per-quadrant blend) and
@@ -287,6 +289,47 @@ def test_cross_check_paths(ws, oracle, env, monkeypatch):
             _assert_close(img, ref, proof=sc.proof(ofr_))
             assert stats["overflow"] == 0
         finally:
+            pc.close()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("env", [{"WS_BLEND_DMA": "1"}, {"WS_BLEND_DMA": "1", "WS_BLEND_TPW_LOG2": "2"},
+                                 {"WS_DEPTH_SORT": "onesweep"}, {"WS_DEPTH_SORT": "coop"}, {"WS_DEPTH_SORT": "scan"}])
+@pytest.mark.parametrize("kind", ["c2", "c3"])
+def test_switched_paths_draw_the_default_image_bit_for_bit(ws, ctx, oracle, env, kind, monkeypatch):
+    """Switches that change HOW a frame is computed, not WHAT (the LDS-DMA staging of the blend had no test; the
+    depth-sort forms): the image, the visible count and the entry count equal the default path's bit for bit, on a scene
+    of multi-tile splats and on one of pixel-sized splats, and again for a second render() of the same prepared frame
+    (the staging buffers / status words of the first are reused)."""
+    if kind == "c2":
+        rows, viewport = synth.scene_c2(n=200_000, seed=21), (1283, 721)
+        cj = synth.orbit_cameras(8, viewport[0], viewport[1], 900.0, 900.0)[3]
+    else:
+        rows, viewport = synth.scene_c3(n=300_000, seed=22), (640, 480)
+        cj = synth.look_at_camera(0, [0.0, 0.0, -9.0], [0, 0, 0], viewport[0], viewport[1], 520.0, 520.0)
+    sc = scenes.Scene(ws, oracle, rows, 3, cj, viewport)
+    pc, want, st0 = _render(ws, ctx, sc)
+    pc.close()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = ws.Context(0)
+    try:
+        pc = ws.PointCloud(c, sc.gpc)
+        r = ws.GaussianRenderer(c, "rgba32float", 3, False)
+        try:
+            for frame in range(2):
+                r.prepare(pc, sc.args)
+                r.render(pc)
+                img = r.download_target()
+                st = r.frame_stats()
+                assert st["num_visible"] == st0["num_visible"] and st["num_tile_entries"] == st0["num_tile_entries"]
+                assert st["overflow"] == 0 and r.errors()[0] == 0
+                assert np.array_equal(img, want), (env, kind, frame, float(np.abs(img - want).max()))
+                r.render(pc)   # the same prepared frame once more
+                assert np.array_equal(r.download_target(), want), (env, kind, frame, "second render")
+        finally:
+            r.close()
             pc.close()
     finally:
         c.close()

@@ -708,253 +708,6 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     if (DMA) wait_vector_loads();  // a prefetch the tile did not consume must have landed before the workgroup's LDS is released
 }
 
-// ---- k_blend_persist: persistent workgroups, tiles from per-XCD queues, every prefetch through LDS-DMA ---------------
-// k_blend pays, per tile, a chain of three dependent round trips before the first record is decoded (tile range -> entry
-// indices -> Splat records), twice per CU at a time, four rounds on the 1080p frame; and the hardware deals tiles to
-// workgroup slots in a fixed order.  Here 2 x CUs workgroups stay resident and DRAW tiles from eight queues (one per XCD:
-// workgroup b runs on XCD b % 8 and takes the 64x64-px blocks of that XCD in the order k_blend's static mapping uses), and
-// the chain is pulled ahead of the compositing by three tiles:
-//   while tile k is composited   its later batches are prefetched as in k_blend<DMA>,
-//                                the first batch of tile k+1 lands in the other raw buffer (its range is known),
-//                                the range of tile k+2 lands in LDS (its ticket is known),
-//                                the ticket of tile k+3 is drawn.
-// All of it is issued from the first staging step of tile k, right behind its s_waitcnt vmcnt(0), and none of it holds a
-// VGPR while in flight except the ticket (one register of thread 0): the round-2 attempt at this form failed on exactly
-// those registers under the 64-VGPR cap.  The queue words live in the frame's zero arena; the last workgroup of
-// an XCD to leave resets them, so that render() can be called again without another prepare().
-constexpr uint32_t TILE_OUTSIDE = 0xFFFFFFFFu;  // a slot of a 64x64 block beyond the image: nothing to draw
-constexpr uint32_t TILE_END = 0xFFFFFFFEu;      // the queue is exhausted
-
-template <int FORMAT, int QW, int QH>
-__global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend_persist(const BlendParams p) {
-    constexpr int NW = QW * QH;
-    constexpr int NT = 64 * NW;
-    constexpr int STAGE = NT < WS_BLEND_STAGE_MAX ? NT : WS_BLEND_STAGE_MAX;
-    constexpr int SLOTS = STAGE + 1;
-    constexpr int TW = 8 * QW, TH = 8 * QH;
-    constexpr int LCAP = STAGE < 512 ? STAGE : 512;
-    static_assert(LCAP % 256 == 0, "sub-round layout of the quadrant masks");
-
-    __shared__ float4 s_rec[2 * SLOTS];
-    __shared__ __attribute__((aligned(16))) uint16_t s_m[STAGE];
-    __shared__ __attribute__((aligned(16))) uint32_t s_list[NW][LCAP + 16];
-    __shared__ __attribute__((aligned(16))) u32x4_t s_raw4[2 * STAGE];
-    __shared__ uint32_t s_raw1[2 * STAGE];
-    __shared__ uint32_t s_alive[2];
-    // ring of three tiles: code (tx | ty << 16, TILE_OUTSIDE, TILE_END), then the two RAW words of tile_ranges[tile]
-    // (0xFFFFFFFF - begin, end; (0, 0) = empty) as the LDS-DMA leaves them
-    __shared__ uint32_t s_tcode[3];
-    __shared__ uint32_t s_traw[3][2];
-
-    if (blockIdx.x == 0 && threadIdx.x == 0 && p.sticky) {  // as in k_blend
-        const uint32_t bits = p.counters->overflow;
-        if (bits) atomicOr(p.sticky, bits);
-    }
-    const BlendShape shape = blend_shape(QW, QH);
-    const uint32_t xcd = blockIdx.x & 7u;
-    uint32_t* const q_ticket = p.queue + xcd * 16u;        // one 64-B line per counter
-    uint32_t* const q_exit = p.queue + 128u + xcd * 16u;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int qx = wave % QW, qy = wave / QW;
-    const float lx = (float)(qx * 8 + (lane & 7)) + 0.5f;
-    const float ly = (float)(qy * 8 + (lane >> 3)) + 0.5f;
-    const uint32_t qbit = 1u << wave;
-    const bool stager = NT == STAGE || tid < STAGE;  // wave-uniform
-    const float W = (float)p.width, H = (float)p.height;
-    uint32_t* my_list = s_list[wave];
-    const uint32_t wslot = (uint32_t)wave * 64u;
-
-    // ticket j of this XCD's queue -> tile code (one tile per ticket: k_blend's block mapping with one tile per workgroup)
-    auto tile_code = [&](uint32_t j) -> uint32_t {
-        if (j >= (1u << 24)) return TILE_END;
-        const BlendBlock b = blend_block_of(j * 8u + xcd, p.tiles_x, p.tiles_y, shape, 0u);
-        if (!b.valid) return TILE_END;
-        const uint32_t tx = (b.bx << shape.tbx_log2) + (b.w & ((1u << shape.tbx_log2) - 1u));
-        const uint32_t ty = (b.by << shape.tby_log2) + (b.w >> shape.tbx_log2);
-        return (tx < p.tiles_x && ty < p.tiles_y) ? (tx | (ty << 16)) : TILE_OUTSIDE;
-    };
-    auto range_of = [&](uint32_t slot) -> uint2 {  // decoded range of ring slot `slot`
-        const uint32_t c = s_tcode[slot];
-        uint2 r = make_uint2(0u, 0u);
-        if (c < TILE_END) {
-            const uint32_t rx = s_traw[slot][0], ry = s_traw[slot][1];
-            r = make_uint2(ry ? 0xFFFFFFFFu - rx : 0u, ry);
-        }
-        return r;
-    };
-
-    // ---- prologue: three tickets, the ranges of the first two tiles (thread 0), the null record ----------------------
-    uint32_t tk_pending = 0u;  // thread 0: the ticket of the tile after the next two (lands while a tile is composited)
-    if (tid == 0) {
-        const uint32_t t0 = atomicAdd(q_ticket, 1u), t1 = atomicAdd(q_ticket, 1u);
-        tk_pending = atomicAdd(q_ticket, 1u);
-        const uint32_t c0 = tile_code(t0), c1 = tile_code(t1);
-        uint2 r0 = make_uint2(0u, 0u), r1 = make_uint2(0u, 0u);
-        if (c0 < TILE_END) r0 = p.tile_ranges[tile_list_index(p, c0 & 0xFFFFu, c0 >> 16)];
-        if (c1 < TILE_END) r1 = p.tile_ranges[tile_list_index(p, c1 & 0xFFFFu, c1 >> 16)];
-        s_tcode[0] = c0;
-        s_traw[0][0] = r0.x;
-        s_traw[0][1] = r0.y;
-        s_tcode[1] = c1;
-        s_traw[1][0] = r1.x;
-        s_traw[1][1] = r1.y;
-        s_tcode[2] = TILE_END;
-        s_rec[STAGE] = make_float4(0.0f, 0.0f, 1.0e9f, 0.0f);  // the null record: a' = 1e18, never inside the cut-off
-        s_rec[SLOTS + STAGE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    __syncthreads();
-    uint32_t rbuf = 0u;  // raw buffer (slot offset 0 or STAGE) the current tile stages out of
-    if (stager) {
-        const uint2 r0 = range_of(0u);
-        if (r0.y > r0.x) blend_gather_lds(p, blend_entry_idx<STAGE>(p, r0, r0.y, tid), s_raw4 + wslot, s_raw1 + wslot);
-    }
-
-    for (uint32_t k = 0u;; ++k) {
-    const uint32_t slot_cur = k % 3u, slot_nxt = (k + 1u) % 3u, slot_new = (k + 2u) % 3u;
-    const uint32_t code = s_tcode[slot_cur];
-    if (code == TILE_END) break;  // block-uniform
-    const uint2 range = range_of(slot_cur);
-    uint2 range_nt = make_uint2(0u, 0u);  // non-empty: the next tile's first batch is still to be requested
-    if (stager) {
-        const uint2 rn = range_of(slot_nxt);
-        if (rn.y > rn.x) range_nt = rn;
-    }
-    bool advance = tid == 0;  // thread 0: the queue is still to be advanced in this tile (range of tile k+2, ticket of k+3)
-    // thread 0 only, behind an s_waitcnt vmcnt(0): tk_pending has landed
-    auto advance_queue = [&]() {
-        const uint32_t c2 = tile_code(tk_pending);
-        s_tcode[slot_new] = c2;
-        if (c2 < TILE_END) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(p.tile_ranges + tile_list_index(p, c2 & 0xFFFFu, c2 >> 16));
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&s_traw[slot_new][0], 4, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + 1), (lptr_t)&s_traw[slot_new][1], 4, 0, 0);
-        }
-        tk_pending = atomicAdd(q_ticket, 1u);
-        advance = false;
-    };
-
-    if (code != TILE_OUTSIDE) {  // block-uniform
-    const uint32_t tx = code & 0xFFFFu, ty = code >> 16;
-    const uint32_t px = tx * TW + qx * 8 + (lane & 7);
-    const uint32_t py = ty * TH + qy * 8 + (lane >> 3);
-    const bool inside = px < p.width && py < p.height;
-    float T = inside ? 1.0f : 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    const float tile_x0 = (float)(tx * TW), tile_y0 = (float)(ty * TH);
-    uint32_t hi = range.y;
-    uint32_t idx_next = 0u;
-    if (stager && range.y > range.x)
-        idx_next = blend_entry_idx<STAGE>(p, range, range.y - range.x > (uint32_t)STAGE ? range.y - (uint32_t)STAGE : range.x, tid);
-    uint32_t bpar = 0u;
-    while (hi > range.x) {
-        const uint32_t nb = (hi - range.x) < (uint32_t)STAGE ? (hi - range.x) : (uint32_t)STAGE;
-        const uint32_t hi_next = hi - nb;
-        if (stager) {
-            uint32_t mask = 0u;
-            uint32_t idx_nt = 0u;
-            const bool fetch_nt = range_nt.y > range_nt.x;  // (first batch of this tile only: cleared below)
-            wait_vector_loads();  // this wave's LDS-DMA of the batch, its index loads, thread 0's ticket: all landed
-            if (fetch_nt) idx_nt = blend_entry_idx<STAGE>(p, range_nt, range_nt.y, tid);  // consumed behind the decode
-            if (tid == 0) s_alive[bpar] = 0u;
-            RawSplat raw;
-            raw.a = s_raw4[rbuf + (uint32_t)tid];
-            raw.w4 = s_raw1[rbuf + (uint32_t)tid];
-            if ((uint32_t)tid < nb) {
-                const stage::Staged s = stage::decode<QW, QH>(raw.a.x, raw.a.y, raw.a.z, raw.a.w, raw.w4, W, H, tile_x0,
-                                                              tile_y0, CUT_A2);
-                mask = s.mask;
-                s_rec[tid] = make_float4(s.i00, s.i01, s.c0, s.i10);
-                s_rec[SLOTS + tid] = make_float4(s.i11, s.c1, __uint_as_float(raw.a.w), __uint_as_float(raw.w4));
-            }
-            s_m[((uint32_t)tid / LCAP) * LCAP + ((uint32_t)tid & 63u) * (LCAP / 64) + (((uint32_t)tid % LCAP) >> 6)] = (uint16_t)mask;
-            if (advance) advance_queue();
-            if (fetch_nt) {
-                blend_gather_lds(p, idx_nt, s_raw4 + (rbuf ^ (uint32_t)STAGE) + wslot, s_raw1 + (rbuf ^ (uint32_t)STAGE) + wslot);
-                range_nt = make_uint2(0u, 0u);
-            }
-            blend_gather_lds(p, idx_next, s_raw4 + rbuf + wslot, s_raw1 + rbuf + wslot);
-            idx_next = blend_entry_idx<STAGE>(p, range, hi_next - range.x > (uint32_t)STAGE ? hi_next - (uint32_t)STAGE : range.x, tid);
-        }
-        wg_barrier_keep_loads();
-        for (uint32_t sub = 0; sub < nb && __ballot(T >= T_MIN) != 0ull; sub += (uint32_t)LCAP) {
-            const uint2* mp = reinterpret_cast<const uint2*>(s_m + sub + (uint32_t)lane * (LCAP / 64));
-            uint32_t n = 0;
-            uint32_t slot16 = (sub + (uint32_t)lane) * 16u;
-            asm volatile("" : "+v"(slot16));
-#pragma unroll
-            for (int h = 0; h < LCAP / 256; ++h) {
-                const uint2 mm = mp[h];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = h * 4 + q;
-                    const uint32_t word = (q & 2) ? mm.y : mm.x;
-                    const bool t = (word & (qbit << ((q & 1) * 16))) != 0u;
-                    const unsigned long long bal = __ballot(t);
-                    const uint32_t pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    if (t) my_list[pos] = slot16 + (uint32_t)r * 1024u;
-                    n += (uint32_t)__popcll(bal);
-                }
-            }
-            if (n > 0u) {
-                if (lane < 4 && ((n + (uint32_t)lane) >> 2) == (n >> 2) && (n & 3u)) my_list[n + lane] = (uint32_t)STAGE * 16u;  // pad to x4
-                const uint32_t n4 = (n + 3u) >> 2;
-                const uint4* lp = reinterpret_cast<const uint4*>(my_list);
-                uint4 o = lp[0];
-                uint4 on = lp[n4 > 1u ? 1u : 0u];
-                BlendRec cur = blend_load_rec<SLOTS>(s_rec, o.x);
-                for (uint32_t g = 0; g < n4; ++g) {
-                    const BlendRec r1 = blend_load_rec<SLOTS>(s_rec, o.y);
-                    blend_composite(cur, lx, ly, T, cr, cg, cb);
-                    const BlendRec r2 = blend_load_rec<SLOTS>(s_rec, o.z);
-                    blend_composite(r1, lx, ly, T, cr, cg, cb);
-                    const BlendRec r3 = blend_load_rec<SLOTS>(s_rec, o.w);
-                    blend_composite(r2, lx, ly, T, cr, cg, cb);
-                    cur = blend_load_rec<SLOTS>(s_rec, on.x);
-                    blend_composite(r3, lx, ly, T, cr, cg, cb);
-                    if (__ballot(T >= T_MIN) == 0ull) break;
-                    o = on;
-                    on = lp[g + 2u < n4 ? g + 2u : n4 - 1u];
-                }
-            }
-        }
-        hi = hi_next;
-        const bool wave_alive = __ballot(T >= T_MIN) != 0ull;
-        if (lane == 0 && wave_alive) s_alive[bpar] = 1u;
-        wg_barrier_keep_loads();
-        const bool all_done = s_alive[bpar] == 0u;
-        bpar ^= 1u;
-        if (all_done) break;
-    }
-    {
-        const uint32_t sx = tx * TW + (uint32_t)lx, sy = ty * TH + (uint32_t)ly;
-        if (sx < p.width && sy < p.height)
-            store_pixel<FORMAT>(p, sx, sy, cr + p.background[0] * T, cg + p.background[1] * T, cb + p.background[2] * T,
-                                (1.0f - T) + p.background[3] * T);
-    }
-    }  // tile inside the image
-    // a tile without a staged batch (empty list, or a block slot beyond the image) still has to feed the pipeline
-    if (stager && (range_nt.y > range_nt.x || advance)) {
-        wait_vector_loads();
-        if (advance) advance_queue();
-        if (range_nt.y > range_nt.x)
-            blend_gather_lds(p, blend_entry_idx<STAGE>(p, range_nt, range_nt.y, tid), s_raw4 + (rbuf ^ (uint32_t)STAGE) + wslot,
-                             s_raw1 + (rbuf ^ (uint32_t)STAGE) + wslot);
-    }
-    if (wave == 0) wait_vector_loads();  // thread 0's range DMA for tile k+2 is in LDS before anybody reads the ring slot
-    rbuf ^= (uint32_t)STAGE;
-    wg_barrier_keep_loads();  // the staging buffers and the ring slot are handed to the next tile
-    }  // tiles
-
-    wait_vector_loads();  // prefetches nobody consumed, thread 0's last ticket: landed before the LDS / the queue are released
-    if (tid == 0) {
-        const uint32_t wgs = gridDim.x >> 3;
-        if (atomicAdd(q_exit, 1u) == wgs - 1u) {  // the last workgroup of this XCD: every ticket draw of the launch has returned
-            atomicExch(q_ticket, 0u);
-            atomicExch(q_exit, 0u);
-        }
-    }
-}
-
 // ---- k_blend_q: one WAVE per 8x8 quadrant, no LDS, no barriers -------------------------------------------
 // Measured on MI355X (profiles/): the 256-thread kernel above is bound by the serial latency of one tile (two
 // barriers per 256-splat batch, three dependent LDS reads per splat), not by VALU (26 % busy) or LDS bandwidth.
@@ -1316,30 +1069,6 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     return WS_OK;
 }
 
-// persistent form (k_blend_persist): 2 workgroups per CU, or fewer when the frame has fewer tiles
-static int launch_blend_persist(const BlendParams& p, hipStream_t stream) {
-    const BlendShape sh = blend_shape(4, 4);
-    uint32_t grid = blend_grid_blocks(p.tiles_x, p.tiles_y, sh, 0u);
-    const uint32_t slots = 2u * (uint32_t)p.num_cus;
-    if (grid > slots) grid = slots;
-    grid = ((grid + 7u) / 8u) * 8u;
-    switch (p.format) {
-        case WS_FORMAT_RGBA32_FLOAT:
-            hipLaunchKernelGGL((k_blend_persist<WS_FORMAT_RGBA32_FLOAT, 4, 4>), dim3(grid), dim3(1024), 0, stream, p);
-            break;
-        case WS_FORMAT_RGBA16_FLOAT:
-            hipLaunchKernelGGL((k_blend_persist<WS_FORMAT_RGBA16_FLOAT, 4, 4>), dim3(grid), dim3(1024), 0, stream, p);
-            break;
-        case WS_FORMAT_RGBA8_UNORM:
-            hipLaunchKernelGGL((k_blend_persist<WS_FORMAT_RGBA8_UNORM, 4, 4>), dim3(grid), dim3(1024), 0, stream, p);
-            break;
-        default:
-            return fail(WS_ERR_INVALID, "blend: unknown colour format");
-    }
-    WS_HIP(hipGetLastError());
-    return WS_OK;
-}
-
 template <int QW, int QH>
 static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
     const BlendShape sh = blend_shape(QW, QH);
@@ -1418,8 +1147,6 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
         WS_HIP(hipGetLastError());
         return WS_OK;
     }
-    if (p.persist && p.queue && p.qw == 4u && p.qh == 4u && p.range_row_shift == 0u && !p.debug_consumed && !p.debug_walked)
-        return launch_blend_persist(p, stream);
     if (p.qw == 2u && p.qh == 2u) return launch_blend_shape<2, 2>(p, stream);
     if (p.qw == 4u && p.qh == 2u) return launch_blend_shape<4, 2>(p, stream);
     if (p.qw == 4u && p.qh == 4u) return launch_blend_shape<4, 4>(p, stream);

@@ -398,7 +398,6 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->use_graph = env_int("WS_GRAPH", 0);
     ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
     ctx->blend_dma = env_int("WS_BLEND_DMA", 0) ? 1 : 0;
-    ctx->blend_persist = env_int("WS_BLEND_PERSIST", 0) ? 1 : 0;
     {
         const char* bs = std::getenv("WS_BIN_SHIFT");  // 0 | 1 | auto (default): binning at twice the blend's tile size
         ctx->bin_request = !bs ? BIN_AUTO : (std::strcmp(bs, "1") == 0 ? BIN_ALWAYS : (std::strcmp(bs, "0") == 0 ? BIN_NEVER : BIN_AUTO));
@@ -811,6 +810,10 @@ int ws_renderer_set_blend_mode(ws_renderer* r, int mode) {
 
 int ws_renderer_enable_capture(ws_renderer* r, int enable) {
     if (!r) return fail(WS_ERR_INVALID, "ws_renderer_enable_capture: null renderer");
+    // Whether a frame bins coarse (64-px lists) is latched at prepare() from the capture state, and the capture blend's
+    // per-tile read-backs are sized by that frame's lists: a frame prepared under the other state must not be drawn or
+    // read back under this one -- the caller prepares again.
+    if (r->capture != (enable != 0)) r->prepared = false;
     r->capture = enable != 0;
     return WS_OK;
 }
@@ -1160,6 +1163,9 @@ int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_point
             return WS_ERR_UNSUPPORTED;
         for (uint32_t j = 0; j < i; ++j)
             if (rs[j] == r || streams[j] == streams[i]) return WS_ERR_UNSUPPORTED;
+        // the only argument check of prepare_setup that answers WS_ERR_UNSUPPORTED: made here, BEFORE any renderer of the
+        // group is touched, so that "unsupported" keeps meaning "nothing enqueued, nothing changed" 
+        if (views[i].max_sh_deg > 3) return fail(WS_ERR_INVALID, "ws_view_batch_render: max_sh_deg > 3");
     }
     K1Params kp[K1_MAX_VIEWS];
     K1Buffers kb[K1_MAX_VIEWS];
@@ -1223,9 +1229,7 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
     bp.lds_pad_kb = r->ctx->blend_lds_pad_kb;
     bp.dma = r->ctx->blend_dma;
-    bp.persist = r->ctx->blend_persist;
     bp.num_cus = r->ctx->num_cus;
-    bp.queue = r->zero ? r->zero->blend_queue : nullptr;
     bp.range_row_shift = 0;
     bp.bin_tiles_x = r->tiles_x;
     // Two 512-thread workgroups (32x16 halves) per 32x32 binning tile, both reading the tile's list.  Automatic: when the

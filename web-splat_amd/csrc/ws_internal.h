@@ -10,6 +10,10 @@
 
 #if defined(_OPENMP) && !defined(__HIP_DEVICE_COMPILE__)
 #include <omp.h>
+// kmp_get_blocktime / kmp_set_blocktime are extensions of LLVM's (and Intel's) OpenMP runtime: only there
+#if defined(__clang__) && defined(KMP_VERSION_MAJOR)
+#define WS_HAVE_KMP_BLOCKTIME 1
+#endif
 #endif
 
 namespace ws {
@@ -20,9 +24,12 @@ namespace ws {
 // MI355X box (scripts/slowmode_probe*.py): for ~0.2 s after a point cloud was created on another renderer's watch, four
 // frames in flight ran at 2 600 instead of 16 800 frames/s -- the "slow cells" of the N x resolution sweeps of rounds 2
 // and 3.  Every host function with a parallel region holds one of these: its workers go to sleep as the region ends.
+// Side effect: the block time is a per-thread control variable of the CALLING thread; a parallel region the same thread
+// starts concurrently (it cannot: the guard lives on its stack) would see 0.  Other threads' regions are unaffected.  With
+// another OpenMP runtime (libgomp) the guard is a no-op.
 struct OmpQuietWorkers {
     int saved = 0;
-#if defined(_OPENMP) && !defined(__HIP_DEVICE_COMPILE__)
+#if defined(WS_HAVE_KMP_BLOCKTIME)
     OmpQuietWorkers() : saved(kmp_get_blocktime()) { kmp_set_blocktime(0); }
     ~OmpQuietWorkers() { kmp_set_blocktime(saved); }
 #else
@@ -94,7 +101,6 @@ struct FrameZero {
     uint32_t depth_hist[4 * RADIX];
     uint32_t tile_hist[4 * RADIX];
     uint32_t key_range[KEY_RANGE_SLOTS * KEY_RANGE_STRIDE];
-    uint32_t blend_queue[2 * 8 * 16];  // k_blend_persist: per XCD a tile ticket and an exit counter, one 64-B line each
     // uint2 tile_ranges[tiles] follows
 };
 
@@ -375,9 +381,7 @@ struct BlendParams {
     int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
     int lds_pad_kb;             // tuning: extra (unused) dynamic LDS per workgroup, limits workgroups per CU
     int dma;                    // stage the Splat records with gfx950's LDS-DMA (global_load_lds) instead of through VGPRs
-    int persist;                // k_blend_persist: resident workgroups draw tiles from per-XCD queues (4x4 tiles only)
     int num_cus;
-    uint32_t* queue;            // FrameZero::blend_queue
     uint32_t bin_tiles_x;       // binning tiles per row at the blend's tile size (the frame may bin at twice that: FrameCounters::bin_shift)
     uint32_t range_row_shift;   // 0, or 1 = "split" mode: tiles_y counts HALF binning tiles (32x16 px, 8 waves) and the list of
                                 //   blend tile (tx, ty) is the binning tile's (tx, ty >> 1): two workgroups share one list
@@ -429,7 +433,6 @@ struct ws_context {
     int batch_k1 = 1;         // WS_BATCH_K1=n: a view batch runs K1 once for groups of n frames (1 = every frame its own K1)
     bool tile_sort_wide = false; // WS_TILE_SORT=wide: single-pass tile-id sort up to 2048 binning tiles (launch_tile_sort_wide)
     int bin_request = 1;      // WS_BIN_SHIFT=0 | auto (default) | 1: BinRequest for frames that can use coarse binning
-    int blend_persist = 0;    // WS_BLEND_PERSIST=1: k_blend_persist
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
     int blend_split = -1;     // WS_BLEND_SPLIT: 4x4 binning tiles composited by two 4x2 workgroups each; -1 = when tiles < 2 x CUs
     int num_cus = 256;
