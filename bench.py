@@ -167,6 +167,50 @@ def cpu_baseline(gpc, arg, viewport, budget_s=20.0):
                       f"{oracle.num_threads()} threads, oracle built {flags}"}
 
 
+def _physical_cores(cpus):
+    """The logical CPUs of `cpus` grouped by physical core, cores ordered by (package, core id): SMT siblings stay together,
+    so that two ranks never share a core.  Falls back to one group per logical CPU when sysfs does not say."""
+    groups = {}
+    for c in sorted(cpus):
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            key = (int(open(base + "physical_package_id").read()), int(open(base + "core_id").read()))
+        except (OSError, ValueError):
+            key = (0, c)
+        groups.setdefault(key, []).append(c)
+    return [groups[k] for k in sorted(groups)]
+
+
+def pin_host_share(local_rank, local_world):
+    """Eight ranks on one node share its host cores: each rank builds the scene with an OpenMP team, then runs ONE enqueue
+    thread (~65 % busy at 7000 frames/s) beside the HIP runtime's helper threads.  Left alone, every rank's team spans every
+    core and the enqueue threads migrate between them.  Rank r of w takes the r-th of w equal slices of the PHYSICAL cores
+    this process may run on (taskset / cgroup respected), all SMT siblings included, and sizes its OpenMP team to the slice;
+    must run before torch / the library load (OMP_NUM_THREADS is read when the OpenMP runtime starts).
+    -> (cpus of the share, note)"""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None, "affinity not available on this platform"
+    if os.environ.get("WS_BENCH_PIN", "1") == "0":
+        return allowed, "WS_BENCH_PIN=0: not pinned"
+    if local_world <= 1:
+        os.environ.setdefault("OMP_NUM_THREADS", str(len(allowed)))
+        return allowed, f"one rank: all {len(allowed)} allowed CPUs"
+    cores = _physical_cores(allowed)
+    if len(cores) < local_world:
+        return allowed, f"{len(cores)} cores for {local_world} ranks: not pinned"
+    lo, hi = local_rank * len(cores) // local_world, (local_rank + 1) * len(cores) // local_world
+    share = sorted(c for g in cores[lo:hi] for c in g)
+    os.sched_setaffinity(0, share)
+    try:  # (a smaller team asked for by the caller stays)
+        want = min(int(os.environ.get("OMP_NUM_THREADS", len(share))), len(share))
+    except ValueError:
+        want = len(share)
+    os.environ["OMP_NUM_THREADS"] = str(max(want, 1))
+    return share, f"rank-local share: physical cores {lo}..{hi - 1} of {len(cores)} ({len(share)} logical CPUs), OMP_NUM_THREADS={os.environ['OMP_NUM_THREADS']}"
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -233,6 +277,10 @@ def main():
                     help="frames in flight per GPU: one renderer (private scratch) + one HIP stream each "
                          "(the views of a batch are independent; 1 = strictly one frame at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="the default run (hd1m, one GPU) also times c3 -- the largest single-GPU configuration, where the "
+                         "HBM fractions of the sort and K1 mean something -- for ~200 frames and reports it under "
+                         "\"secondary\"; this switch leaves it out")
     ap.add_argument("--no-dist", action="store_true", help="skip the one-rank RCCL communicator at N = 1")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo: the collectives run on host tensors (tests: several ranks sharing ONE GPU, where RCCL refuses "
@@ -252,6 +300,8 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    host_cpus, host_note = pin_host_share(int(os.environ.get("LOCAL_RANK", "0")),
+                                          int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
     import torch
     dist, rank, local_rank, world, dist_note = init_distributed(a, torch)
     if a.single_device:
@@ -317,6 +367,11 @@ def main():
             host_pg = dist.new_group(backend="gloo")
         except Exception as e:  # noqa: BLE001  (no usable interface for gloo: keep the RCCL barrier)
             print(f"[bench] gloo group for the host barrier failed ({e!r}); using the RCCL barrier", file=sys.stderr)
+        # every rank must bracket the timed region with the SAME collective: the host group is used only if every rank has it
+        ok = torch.tensor([1.0 if host_pg is not None else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() < 1.0:
+            host_pg = None
 
     def barrier():
         device_sync()
@@ -359,9 +414,9 @@ def main():
     # words collect tile-entry overflow and look-back time-outs of ALL frames since the batch was created
     err_bits = batch.errors()
     if dist is not None:
-        t = torch.tensor([elapsed, float(err_bits)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(err_bits), t_enq], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # RCCL: the only collective, off the data path
-        elapsed, err_bits = float(t[0].item()), int(t[1].item())
+        elapsed, err_bits, t_enq = float(t[0].item()), int(t[1].item()), float(t[2].item())
     if err_bits:
         raise SystemExit(f"[bench] INVALID RUN: device-side error bits 0x{err_bits:x} in the timed frames (bit 0 = tile-entry "
                          "list overflow: entries were dropped; bits 1-3 = look-back time-out) -- no result line is printed")
@@ -378,6 +433,10 @@ def main():
                                    f"{len(views)} views sharded view i -> rank i mod N, {nstreams} frame(s) in flight per GPU",
                        "gaussians": n, "width": w, "height": h, "views": len(views), "frames_in_flight": nstreams,
                        "error_bits": err_bits, "collective": dist_note,
+                       # the host side of the timed region (MAX over ranks): what one enqueue thread spent submitting the K
+                       # frames; host_bound = that thread, not the GPU, set the pace
+                       "host_enqueue_ms_per_frame": t_enq / a.steps * 1e3, "host_bound": bool(t_enq > 0.8 * elapsed),
+                       "host_cpus": len(host_cpus) if host_cpus else None, "host_affinity": host_note,
                        "timing_barrier": ("none (one process, --no-dist)" if dist is None else
                                           "host barrier (gloo group) + device synchronize, both sides" if host_pg is not None
                                           else f"{dist.get_backend()} barrier + device synchronize, both sides")},
@@ -411,6 +470,8 @@ def main():
                                                   "distinct_images": len(set(got[0]))}
     if rank == 0 and not a.dry_run:
         analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world)
+        if world == 1 and a.workload == "hd1m" and not a.no_secondary:
+            out["secondary"] = {"c3": secondary(a, ws, ctx, torch, "c3", nstreams)}
     barrier()
     if dist is not None and a.dry_run:
         got = [None] * world
@@ -427,6 +488,74 @@ def main():
     if out is not None:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     os.close(result_fd)
+
+
+def secondary(a, ws, ctx, torch, workload, nstreams, frames=200):
+    """The same measurement on a second workload, rank 0 of a one-GPU run only, after the headline's timed region: `frames`
+    frames in flight between two device synchronisations, then analyse() -- one frame at a time, per-kernel event times.
+    -> the compact block of the result line's "secondary" (the full kernel table of that workload: --workload c3)."""
+    import argparse
+    gpc, views, viewport, _ = build_workload(ws, workload, 8)
+    w, h = viewport
+    pc = ws.PointCloud(ctx, gpc)
+    batch = ws.ViewBatch(ctx, a.format, gpc.sh_deg, gpc.compressed, nstreams)
+    tdtype = {"rgba32float": torch.float32, "rgba16float": torch.float16, "rgba8unorm": torch.uint8}[a.format]
+    targets = [torch.empty((h, w, 4), dtype=tdtype, device="cuda") for _ in range(nstreams)]
+    packed = ws.ViewBatch.pack_views(views)
+    import ctypes as C
+
+    def plan(first, count):
+        arr = (type(packed[0]) * count)()
+        ptrs = (C.c_void_p * count)()
+        for j in range(count):
+            arr[j] = packed[(first + j) % len(views)]
+            ptrs[j] = targets[(first + j) % nstreams].data_ptr()
+        return arr, ptrs
+    pitch = w * batch.texel_bytes
+    warm, timed = plan(0, 4 * nstreams), plan(4 * nstreams, frames)
+    batch.render(pc, warm[0], warm[1], pitch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    batch.render(pc, timed[0], timed[1], pitch)
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    err = batch.errors()
+    r = ws.GaussianRenderer(ctx, a.format, gpc.sh_deg, gpc.compressed)
+
+    def frame(i):
+        r.prepare(pc, views[i % len(views)])
+        r.render(pc, target_ptr=targets[0].data_ptr())
+    sub = {"config": {}}
+    a2 = argparse.Namespace(**vars(a))
+    a2.workload, a2.steps, a2.no_cpu_baseline = workload, frames, True
+    analyse(a2, ws, ctx, pc, gpc, r, frame, views, views, viewport, sub, 1)
+    r.close()
+    batch.close()
+    pc.close()
+    if err:
+        return {"error_bits": err}
+    k = sub["kernels"]
+    V = sub["config"]["avg_visible"]
+    depth_ms = sum(v["ms_per_frame"] for lbl, v in k.items() if lbl.startswith("depth:"))
+    k1 = k.get("k_preprocess") or k.get("k_preprocess<compressed>") or {}
+    rf = sub["roofline"]
+    return {"workload": f"{workload}: {gpc.num_points} Gaussians, {w}x{h}, {nstreams} frame(s) in flight", "frames": frames,
+            "value": frames / elapsed, "unit": "frames/s", "ms_per_step": elapsed / frames * 1e3,
+            "single_stream_fps": sub["config"]["single_stream_fps"], "host_enqueue_ms_per_frame": t_enq / frames * 1e3,
+            "binning_tile": sub["config"]["binning_tile"], "avg_visible": V, "avg_tile_entries": sub["config"]["avg_tile_entries"],
+            "roofline": {"kernel": rf["kernel"], "frac": rf["frac"], "achieved": rf["achieved"], "peak": rf["peak"],
+                         "alg_bytes": rf["alg_bytes_per_launch"], "avg_launch_ms": rf["avg_launch_ms"], "traffic": rf["traffic"]},
+            "kernels": {
+                # 68 V: four passes x (8 B in + 8 B out) + one more key read (SURVEY 8d, the reference's sorter shape)
+                "depth sort": {"launches_per_frame": sum(v["launches_per_frame"] for lbl, v in k.items() if lbl.startswith("depth:")),
+                               "ms_per_frame": depth_ms, "alg_bytes": 68 * V,
+                               "GBps": (68 * V / (depth_ms * 1e-3) / 1e9) if depth_ms else None,
+                               "frac": (68 * V / (depth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if depth_ms else None},
+                "K1": {"ms_per_frame": k1.get("ms_per_frame"), "alg_bytes": k1.get("alg_bytes_per_launch"),
+                       "GBps": k1.get("GBps"), "frac": (k1["GBps"] / HBM_PEAK_GBS) if k1.get("GBps") else None}},
+            "note": "event intervals minus the empty-launch interval, one frame in flight (as roofline); the rocprofv3 "
+                    "durations of the same workload are under profiles/"}
 
 
 def analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world):

@@ -43,6 +43,70 @@ def test_bench_one_rank_rccl_and_contract():
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert abs(out["value"] - 40 / (out["ms_per_step"] * 40 / 1e3)) < 1e-6 * out["value"]
+    # the host side of the timed region is always on the record (round-3 verdict: an 8-GPU run that comes back sub-linear
+    # must say whether the enqueue threads kept up)
+    cfg = out["config"]
+    assert cfg["host_enqueue_ms_per_frame"] > 0 and isinstance(cfg["host_bound"], bool) and cfg["host_cpus"] >= 1
+    assert "secondary" not in out      # (only the default workload carries the c3 block)
+
+
+def _cpu_groups():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench._physical_cores(sorted(os.sched_getaffinity(0)))
+
+
+def test_bench_secondary_c3_block():
+    """The default invocation (hd1m, one GPU) also times c3 -- the largest single-GPU configuration -- and reports it
+    under "secondary" with the roofline of its dominant kernel and the HBM fractions of the depth sort and K1."""
+    p, out = _bench(["--steps", "200", "--warmup", "20", "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    c3 = out["secondary"]["c3"]
+    assert c3["workload"].startswith("c3: 5000000 Gaussians, 1920x1080") and c3["frames"] == 200
+    assert c3["value"] > 100 and c3["single_stream_fps"] > 100 and c3["avg_visible"] > 4_000_000
+    assert c3["roofline"]["kernel"] and 0 < c3["roofline"]["frac"] < 1
+    for name in ("depth sort", "K1"):
+        assert 0 < c3["kernels"][name]["frac"] < 1, (name, c3["kernels"][name])
+    assert out["config"]["workload"].startswith("hd1m:") and out["value"] > 1000
+
+
+def test_bench_holds_its_rate_on_an_eighth_of_the_host(tmp_path):
+    """Eight ranks share one node's host: each gets an eighth of the cores (bench.py pins itself: pin_host_share) while the
+    other seven ranks' threads keep theirs busy.  Emulated on the one-GPU box: the hd1m line under `taskset` to the first
+    eighth of the physical cores, with burner threads spinning on ALL the other cores, against the same line with the whole
+    host to itself.  The rate must hold (within 7 %: run-to-run spread is +-2 %), and the record says the host was not
+    the limit."""
+    cores = _cpu_groups()
+    if len(cores) < 16:
+        pytest.skip("fewer than 16 physical cores: an eighth of the host is not a meaningful share")
+    mine = sorted(c for g in cores[: len(cores) // 8] for c in g)
+    others = sorted(c for g in cores[len(cores) // 8:] for c in g)
+    burn = str(tmp_path / "cpu_burn")
+    subprocess.run(["gcc", "-O2", "-pthread", os.path.join(ROOT, "scripts", "ubench", "cpu_burn.c"), "-o", burn], check=True)
+    args = ["--steps", "1500", "--warmup", "50", "--no-cpu-baseline", "--no-secondary"]
+    p0, free = _bench(args)
+    assert p0.returncode == 0, p0.stderr[-3000:]
+    burner = subprocess.Popen([burn, "600", *map(str, others)], stdout=subprocess.PIPE, text=True)
+    try:
+        burner.stdout.readline()   # "burning N cpus": the threads run
+        e = dict(os.environ)
+        p = subprocess.run(["taskset", "-c", ",".join(map(str, mine)), sys.executable, os.path.join(ROOT, "bench.py"), *args],
+                           capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    finally:
+        burner.kill()
+        burner.wait()
+    assert p.returncode == 0, p.stderr[-3000:]
+    shared = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    rep = {"whole_host": {"fps": free["value"], "host_enqueue_ms_per_frame": free["config"]["host_enqueue_ms_per_frame"],
+                          "host_cpus": free["config"]["host_cpus"]},
+           "eighth_with_burners": {"fps": shared["value"], "host_enqueue_ms_per_frame": shared["config"]["host_enqueue_ms_per_frame"],
+                                   "host_cpus": shared["config"]["host_cpus"], "burner_cpus": len(others)}}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "host_contention.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert shared["config"]["host_cpus"] == len(mine)
+    assert shared["config"]["host_bound"] is False, rep
+    assert shared["value"] >= 0.93 * free["value"], rep
 
 
 def test_bench_real_scene_hook(tmp_path):
