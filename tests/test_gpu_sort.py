@@ -8,18 +8,26 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[1, 0, "depth"], ids=["onesweep", "reduce_scan", "depth3pass"])
+@pytest.fixture(scope="module", params=[1, 0, "depth", "depth:onesweep", "depth:coop"],
+                ids=["onesweep", "reduce_scan", "depth3pass", "depth_fat_onesweep", "depth_fat_coop"])
 def sort_ctx(ws, request):
-    """Three paths to the same contract: the generic sorter's one-sweep and reduce-then-scan cross-tile prefixes, and
-    the renderer's range-adaptive three-pass depth sort (ws_sorter_sort_depth)."""
-    old = os.environ.get("WS_SORT_ALGO")
-    os.environ["WS_SORT_ALGO"] = str(request.param) if request.param != "depth" else "0"
+    """Five paths to the same contract: the generic sorter's one-sweep and reduce-then-scan cross-tile prefixes, and the
+    renderer's depth sorts behind ws_sorter_sort_depth -- the range-adaptive three-pass form and the fat-tile one-sweep
+    (round 4), as per-pass launches and as ONE launch with device-wide barriers (WS_DEPTH_SORT selects; inputs beyond
+    the fat form's 2 M pairs fall back to the three-pass form)."""
+    depth = isinstance(request.param, str)
+    env = {"WS_SORT_ALGO": "0" if depth else str(request.param)}
+    if depth and ":" in request.param:
+        env["WS_DEPTH_SORT"] = request.param.split(":")[1]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     c = ws.Context(0)
-    c.depth_mode = request.param == "depth"
-    if old is None:
-        del os.environ["WS_SORT_ALGO"]
-    else:
-        os.environ["WS_SORT_ALGO"] = old
+    c.depth_mode = depth
+    for k, v in old.items():
+        if v is None:
+            del os.environ[k]
+        else:
+            os.environ[k] = v
     yield c
     c.close()
 
@@ -52,7 +60,8 @@ def _check(ws, ctx, oracle, keys, count=None):
         assert np.array_equal(p[m:], np.arange(m, n, dtype=np.uint32))
 
 
-SIZES = [1, 2, 63, 64, 65, 255, 256, 3840, 4095, 4096, 4097, 8192, 12289, 100_000, 1_000_003]
+SIZES = [1, 2, 63, 64, 65, 255, 256, 1023, 1024, 1025, 3840, 4095, 4096, 4097, 8192, 12289, 100_000, 131_072, 131_073, 524_288,
+         524_289, 1_000_003, 1_048_576, 1_048_577, 2_097_152, 2_097_153]
 
 
 @pytest.mark.parametrize("n", SIZES)

@@ -85,6 +85,11 @@ void KernelMarks::mark(const char* what) {
 
 using namespace ws;
 
+// depth sort of a context that does not say otherwise (WS_DEPTH_SORT): decided by measurement, profiles/r04/
+#ifndef WS_DEPTH_SORT_DEFAULT
+#define WS_DEPTH_SORT_DEFAULT DS_SCAN
+#endif
+
 // small per-sort zero arena of a stand-alone sorter: tickets, error word, digit histograms
 struct SorterZero {
     uint32_t tickets[4];
@@ -92,12 +97,14 @@ struct SorterZero {
     uint32_t _pad[3];
     uint32_t hist[4 * RADIX];
     uint32_t key_range[KEY_RANGE_SLOTS * KEY_RANGE_STRIDE];  // depth mode: filled by k_key_minmax
+    uint32_t fat_barrier[9 * 16];                            // single-launch depth sort: barrier state
 };
 
 struct ws_sorter {
     ws_context* ctx = nullptr;
     SortScratch sc;
     DepthSortScratch ds;   // ws_sorter_sort_depth
+    FatSortScratch fat;    // ws_sorter_sort_depth of a context whose depth sort is the fat-tile one-sweep (status: own allocation)
     uint32_t* aux_alt = nullptr;
     SorterZero* zero = nullptr;
     uint32_t epoch = 0;
@@ -131,6 +138,7 @@ struct ws_renderer {
     SortScratch sort_depth, sort_tiles;
     DepthSortScratch dsort;          // range-adaptive three-pass depth sort (WS_DEPTH_SORT=adaptive only; the default is the
                                      // generic 4 x 8-bit sorter, sort_depth); allocated only when that path is selected
+    FatSortScratch fat;              // fat-tile one-sweep depth sort (WS_DEPTH_SORT=onesweep | coop): chunk-count rows
     uint32_t* fp_sorted = nullptr;  // where the last frame's draw-ordered footprint words are
     int footprint_mode = FP_RECT_PACKED;  // of the current scratch (chosen by the viewport and WS_FOOTPRINT)
     uint32_t epoch = 0;
@@ -241,6 +249,8 @@ static void renderer_free_scratch(ws_renderer* r) {
     dfree(r->dsort.status);
     dfree(r->dsort.totals);
     r->dsort = DepthSortScratch();
+    dfree(r->fat.status);
+    r->fat = FatSortScratch();
     dfree(r->src_index);
     dfree(r->k1_status);
     dfree(r->bin_status);
@@ -334,7 +344,7 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     r->sort_tiles.tickets = r->counters->sort_ticket + 4;
     r->sort_depth.error = &r->counters->overflow;
     r->sort_tiles.error = &r->counters->overflow;
-    if (r->ctx->depth_sort_adaptive) {  // scratch of the cross-check depth sort: per-tile / per-group digit offsets,
+    if (r->ctx->depth_sort_mode == DS_ADAPTIVE) {  // scratch of the cross-check depth sort: per-tile / per-group digit offsets,
                                         // look-back words (zeroed once; epoch-tagged afterwards)
         DepthSortScratch& ds = r->dsort;
         ds.cap = n ? n : 1;
@@ -350,6 +360,21 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
         ds.key_range = r->zero->key_range;
         ds.tickets = r->counters->sort_ticket;  // [0..2]; the tile sort uses [4..7]
         ds.error = &r->counters->overflow;
+    }
+    if (r->ctx->depth_sort_mode == DS_ONESWEEP || r->ctx->depth_sort_mode == DS_COOP) {
+        FatSortScratch& fs = r->fat;
+        fs.cap = n ? n : 1;
+        if ((rc = dmalloc(&fs.status, fat_sort_status_words()))) return rc;
+        WS_HIP(hipMemset(fs.status, 0, fat_sort_status_words() * sizeof(uint64_t)));
+        fs.keys_alt = r->keys_b;
+        fs.vals_alt = r->vals_b;
+        fs.aux_alt = r->fpw_b;
+        fs.hist = r->zero->depth_hist;
+        fs.tickets = r->counters->sort_ticket;  // [0..3]; the tile sort uses [4..7]
+        fs.barrier = r->zero->fat_barrier;
+        fs.d_epoch = &r->counters->epoch;       // written by K1 every frame: a captured frame graph replays with it
+        fs.error = &r->counters->overflow;
+        fs.grid_request = r->ctx->dsort_fat_grid;
     }
     r->cap_points = n;
     r->vw = vw;
@@ -389,8 +414,15 @@ int ws_context_create(int hip_device, ws_context** out) {
         const char* ts = std::getenv("WS_TILE_SORT");
         ctx->tile_sort_wide = ts && std::strcmp(ts, "wide") == 0;
     }
-    if (const char* ds = std::getenv("WS_DEPTH_SORT")) ctx->depth_sort_adaptive = std::strcmp(ds, "adaptive") == 0;
-    if (ctx->sort_algo == 1) ctx->depth_sort_adaptive = false;  // the one-sweep cross-check path is a generic-sorter path
+    ctx->depth_sort_mode = WS_DEPTH_SORT_DEFAULT;
+    if (const char* ds = std::getenv("WS_DEPTH_SORT")) {
+        if (std::strcmp(ds, "adaptive") == 0) ctx->depth_sort_mode = DS_ADAPTIVE;
+        else if (std::strcmp(ds, "onesweep") == 0) ctx->depth_sort_mode = DS_ONESWEEP;
+        else if (std::strcmp(ds, "coop") == 0) ctx->depth_sort_mode = DS_COOP;
+        else if (std::strcmp(ds, "scan") == 0 || std::strcmp(ds, "classic") == 0) ctx->depth_sort_mode = DS_SCAN;
+    }
+    ctx->dsort_fat_grid = env_int("WS_DSORT_FAT_GRID", 0);
+    if (ctx->sort_algo == 1) ctx->depth_sort_mode = DS_SCAN;  // the one-sweep cross-check path is a generic-sorter path
     ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
     ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
@@ -859,7 +891,17 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     // depth sort: V (key, store index) pairs, values start as iota (preprocess.wgsl:274), the splat's footprint word
     // (packed tile rectangle, or tile count) rides along as a companion value.  Default: the generic 4 x 8-bit sorter (GPURSSorter's shape);
     // WS_DEPTH_SORT=adaptive: three range-adaptive digit passes (launch_depth_sort; measured: no faster).
-    if (!r->ctx->depth_sort_adaptive) {
+    const bool fat_sort = (r->ctx->depth_sort_mode == DS_ONESWEEP || r->ctx->depth_sort_mode == DS_COOP) && r->fat.status &&
+                          fat_sort_grid(pc->num_points, r->ctx->num_cus, r->fat.grid_request) != 0u;
+    if (fat_sort) {
+        // fat-tile one-sweep (sort.hip k_dsort_fat): four 8-bit passes A -> B -> A -> B -> A, everything ends where it started
+        if ((rc = launch_depth_sort_fat(r->fat, r->keys_a, r->vals_a, r->fpw_a, &r->counters->num_visible, pc->num_points, true,
+                                        r->ctx->depth_sort_mode == DS_COOP, r->epoch, r->ctx->num_cus, stream, km)))
+            return rc;
+        r->sorted_idx = r->vals_a;
+        r->sorted_keys = r->keys_a;
+        r->fp_sorted = r->fpw_a;
+    } else if (!(r->ctx->depth_sort_mode == DS_ADAPTIVE)) {
         const bool carry = r->ctx->sort_algo != 1;  // (the one-sweep cross-check path gathers the footprint words afterwards)
         uint32_t *sk = nullptr, *sv = nullptr;
         if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
@@ -1056,6 +1098,7 @@ static int prepare_setup(ws_renderer* r, const ws_pointcloud* pc, const ws_splat
         WS_HIP(hipMemsetAsync(r->k1_status, 0, ((size_t)preprocess_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
         WS_HIP(hipMemsetAsync(r->bin_status, 0, ((size_t)bin_prefix_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
         if (r->dsort.status) WS_HIP(hipMemsetAsync(r->dsort.status, 0, depth_sort_group_words() * sizeof(uint64_t), stream));
+        if (r->fat.status) WS_HIP(hipMemsetAsync(r->fat.status, 0, fat_sort_status_words() * sizeof(uint64_t), stream));
         if (r->ctx->sort_algo == 1) {
             WS_HIP(hipMemsetAsync(r->sort_depth.status, 0, 4 * (size_t)r->sort_depth.tiles * RADIX * sizeof(uint64_t), stream));
             WS_HIP(hipMemsetAsync(r->sort_tiles.status, 0, 4 * (size_t)r->sort_tiles.tiles * RADIX * sizeof(uint64_t), stream));
@@ -1078,7 +1121,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     // A captured frame graph (one hipGraphLaunch + one kernel-argument update instead of 22 launches + a memset on the host)
     // when the caller gave a real stream and no per-launch instrumentation is on.  The legacy NULL stream cannot be captured.
     const bool use_graph = r->ctx->use_graph && stream != nullptr && !r->marks.active && !r->timers && !r->capture &&
-                           cut_mode == 0 && r->ctx->sort_algo == 0 && !r->ctx->depth_sort_adaptive;
+                           cut_mode == 0 && r->ctx->sort_algo == 0 && !(r->ctx->depth_sort_mode == DS_ADAPTIVE);
     if (!use_graph) return enqueue_frame(r, pc, kp, kb, stream);
     ws_renderer::FrameGraph& g = r->fg;
     if (!(g.valid && g.pc == pc && g.generation == r->scratch_generation)) {
@@ -1159,7 +1202,7 @@ int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_point
     for (uint32_t i = 0; i < n; ++i) {
         ws_renderer* r = rs[i];
         if (!r || !streams[i] || r->ctx != rs[0]->ctx || r->compressed != pc->compressed || r->timers || r->marks.active ||
-            r->capture || r->ctx->use_graph || r->ctx->debug_cut || r->ctx->sort_algo != 0 || r->ctx->depth_sort_adaptive)
+            r->capture || r->ctx->use_graph || r->ctx->debug_cut || r->ctx->sort_algo != 0 || (r->ctx->depth_sort_mode == DS_ADAPTIVE))
             return WS_ERR_UNSUPPORTED;
         for (uint32_t j = 0; j < i; ++j)
             if (rs[j] == r || streams[j] == streams[i]) return WS_ERR_UNSUPPORTED;
@@ -1476,6 +1519,22 @@ int ws_sorter_create(ws_context* ctx, uint32_t max_n, ws_sorter** out) {
         ds.key_range = s->zero->key_range;
         ds.tickets = s->zero->tickets;
         ds.error = &s->zero->error;
+        if (rc == WS_OK && (ctx->depth_sort_mode == DS_ONESWEEP || ctx->depth_sort_mode == DS_COOP)) {
+            FatSortScratch& fs = s->fat;
+            fs.cap = max_n;
+            rc = dmalloc(&fs.status, fat_sort_status_words());
+            if (rc == WS_OK && (hipMemset(fs.status, 0, fat_sort_status_words() * sizeof(uint64_t)) != hipSuccess ||
+                                hipDeviceSynchronize() != hipSuccess))
+                rc = fail(WS_ERR_HIP, "ws_sorter_create: look-back word initialisation failed");
+            fs.keys_alt = s->sc.keys_alt;
+            fs.vals_alt = s->sc.vals_alt;
+            fs.aux_alt = s->aux_alt;
+            fs.hist = s->zero->hist;
+            fs.tickets = s->zero->tickets;
+            fs.barrier = s->zero->fat_barrier;
+            fs.error = &s->zero->error;
+            fs.grid_request = ctx->dsort_fat_grid;
+        }
     }
     if (rc != WS_OK) {
         ws_sorter_destroy(s);
@@ -1494,6 +1553,7 @@ void ws_sorter_destroy(ws_sorter* s) {
     dfree(s->ds.status);
     dfree(s->ds.totals);
     dfree(s->aux_alt);
+    dfree(s->fat.status);
     free_sort_scratch(s->sc, true);
     delete s;
 }
@@ -1529,12 +1589,17 @@ int ws_sorter_sort_depth(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, ui
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (++s->epoch == 0) {
         WS_HIP(hipMemsetAsync(s->ds.status, 0, depth_sort_group_words() * sizeof(uint64_t), stream));
+        if (s->fat.status) WS_HIP(hipMemsetAsync(s->fat.status, 0, fat_sort_status_words() * sizeof(uint64_t), stream));
         if (s->ctx->sort_algo == 1)
             WS_HIP(hipMemsetAsync(s->sc.status, 0, 4 * (size_t)s->sc.tiles * RADIX * sizeof(uint64_t), stream));
         s->epoch = 1;
     }
     WS_HIP(hipMemsetAsync(s->zero, 0, sizeof(SorterZero), stream));
     if (n == 0) return WS_OK;
+    // a context whose frames sort with the fat-tile one-sweep (WS_DEPTH_SORT=onesweep | coop): the same kernels, in place
+    if (s->fat.status && fat_sort_grid(n, s->ctx->num_cus, s->fat.grid_request) != 0u)
+        return launch_depth_sort_fat(s->fat, d_keys, d_payload, d_aux, d_count, n, false, s->ctx->depth_sort_mode == DS_COOP,
+                                     s->epoch, s->ctx->num_cus, stream, nullptr);
     int rc = launch_key_minmax(d_keys, d_count, n, s->zero->key_range, stream);
     if (rc) return rc;
     rc = launch_depth_sort(s->ds, d_keys, d_payload, d_aux, d_count, n, false, s->epoch, stream, nullptr);

@@ -101,6 +101,7 @@ struct FrameZero {
     uint32_t depth_hist[4 * RADIX];
     uint32_t tile_hist[4 * RADIX];
     uint32_t key_range[KEY_RANGE_SLOTS * KEY_RANGE_STRIDE];
+    uint32_t fat_barrier[9 * 16];  // single-launch depth sort (WS_DEPTH_SORT=coop): state of its device-wide barriers (grid_barrier.h)
     // uint2 tile_ranges[tiles] follows
 };
 
@@ -305,6 +306,34 @@ int launch_depth_sort(const DepthSortScratch& sc, uint32_t* keys, uint32_t* vals
                       uint32_t n, bool implicit_iota, uint32_t epoch, hipStream_t stream, KernelMarks* km = nullptr);
 // stand-alone use (ws_sorter in depth mode): reduce the key range of arbitrary input into key_range (zero on entry)
 // out[i] = src[idx[i]] for i < count (the classic depth-sort path brings the rectangles into draw order with it)
+// ---- fat-tile one-sweep depth sort (sort.hip k_dsort_fat) -----------------------------------------------------------
+// The same result as launch_sort_pairs over bits 0..32 with a companion value: four 8-bit passes, A -> B -> A -> B -> A, the
+// sorted arrays end where they started.  At most FAT_MAX_GRID workgroups of 1024 threads rank chunks of up to 8192 pairs;
+// the cross-chunk prefix is a consumer-side sum over epoch-tagged count rows (no chain).  Per-pass launches (one histogram
+// launch + four) or, coop = true, ONE launch with device-wide barriers between the passes (needs grid <= CUs resident).
+constexpr uint32_t FAT_MAX_GRID = 256;
+constexpr uint32_t FAT_CHUNK_MAX = 1024u * 8u;
+struct FatSortScratch {
+    uint32_t* keys_alt = nullptr;   // [cap] ping-pong partners
+    uint32_t* vals_alt = nullptr;
+    uint32_t* aux_alt = nullptr;
+    uint32_t* hist = nullptr;       // [4][256] digit totals, zero on entry
+    uint64_t* status = nullptr;     // [4][FAT_MAX_GRID][256] epoch-tagged chunk counts (zeroed once)
+    uint32_t* tickets = nullptr;    // [4] chunk dispensers, zero on entry
+    uint32_t* barrier = nullptr;    // 9 x 16 words, zero on entry (coop)
+    const uint32_t* d_epoch = nullptr;  // != nullptr: the epoch is read from device memory (a captured frame graph replays)
+    uint32_t* error = nullptr;      // OR-ed with 8 when a spin times out
+    uint32_t cap = 0;
+    int grid_request = 0;           // tuning (WS_DSORT_FAT_GRID): workgroups, 0 = automatic
+};
+size_t fat_sort_status_words();
+// workgroups the fat sort uses for bound n on a part with num_cus CUs; 0 = n is beyond what this form handles (the caller
+// takes the scan path)
+uint32_t fat_sort_grid(uint32_t n, int num_cus, int grid_request);
+int launch_depth_sort_fat(const FatSortScratch& sc, uint32_t* keys, uint32_t* vals, uint32_t* aux, const uint32_t* d_count,
+                          uint32_t n, bool implicit_iota, bool coop, uint32_t epoch, int num_cus, hipStream_t stream,
+                          KernelMarks* km = nullptr);
+
 int launch_gather_u32(const uint32_t* src, const uint32_t* idx, const uint32_t* d_count, uint32_t n, uint32_t* out,
                       hipStream_t stream);
 int launch_copy_counted(const uint32_t* s0, uint32_t* d0, const uint32_t* s1, uint32_t* d1, const uint32_t* s2, uint32_t* d2,
@@ -420,11 +449,20 @@ int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_point
                               hipStream_t const* streams);
 
 // opaque handle definitions -------------------------------------------------------------------------
+// The depth sort of a frame (V keys + store index + footprint word):
+//   DS_SCAN      four 8-bit passes of tile histograms -> column scan -> scatter: 12 launches (round 1-3 default)
+//   DS_ADAPTIVE  three range-adaptive passes, two launches each (round 2; cross-check)
+//   DS_ONESWEEP  fat-tile one-sweep: one histogram launch + one launch per pass (round 4)
+//   DS_COOP      the same kernels as ONE launch with device-wide barriers between the passes (round 4, measured variant)
+// Inputs beyond the fat forms' capacity (FAT_MAX_GRID x 8192 pairs) take DS_SCAN.
+enum DepthSortMode { DS_SCAN = 0, DS_ADAPTIVE = 1, DS_ONESWEEP = 2, DS_COOP = 3 };
+
 struct ws_context {
     int device = 0;
     hipDeviceProp_t props;
     int sort_algo = 0;    // 0 = tile histograms -> column scan -> scatter (default), 1 = one-sweep (look-back)
-    bool depth_sort_adaptive = false;  // WS_DEPTH_SORT=adaptive: three range-adaptive digit passes (sort.hip; cross-check)
+    int depth_sort_mode = 0;  // DepthSortMode, WS_DEPTH_SORT = scan | adaptive | onesweep | coop
+    int dsort_fat_grid = 0;   // WS_DSORT_FAT_GRID (tuning): workgroups of the fat-tile depth sort, 0 = automatic
     int blend_variant = 0;
     int debug_cut = 0;        // WS_DEBUG_CUT (analysis): 0 = whole frame
     int blend_tpw_log2 = -1;  // WS_BLEND_TPW_LOG2: tiles per blend workgroup = 2^n (tuning); -1 = automatic
