@@ -399,6 +399,18 @@ def main():
             submit(plan(i_pre, 16))
             i_pre += 16
             torch.cuda.synchronize()
+        # A scene that needs more (tile, splat) entries than the automatic capacity: the overflowed warm-up frames left their
+        # demand in the renderers' sticky words; reading them here makes the next prepare() allocate it (never in the timed
+        # region, whose frames are checked below and invalidate the run if they drop anything).
+        for _ in range(3):
+            if not (batch.errors(reset=True) & 1):
+                break
+            submit(plan(i_pre, 2 * nstreams))
+            i_pre += 2 * nstreams
+            torch.cuda.synchronize()
+        frame(0)
+        if r.errors(reset=True)[0] & 1:
+            frame(0)
     if a.warmup:
         submit(plan(0, a.warmup))
     timed = plan(a.warmup, a.steps)

@@ -481,7 +481,10 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     // back to back can be checked once at the end (ws_renderer_errors / ws_view_batch_errors).
     if (blockIdx.x == 0 && threadIdx.x == 0 && p.sticky) {
         const uint32_t bits = p.counters->overflow;
-        if (bits) atomicOr(p.sticky, bits);
+        if (bits) {
+            atomicOr(p.sticky, bits);
+            if (bits & 1u) atomicMax(p.sticky + 1, p.counters->entries_needed);  // what a retry (or the next prepare) allocates
+        }
     }
     const BlendShape shape = blend_shape(QW, QH);
     const BlendBlock blk = blend_block_of(blockIdx.x, p.tiles_x, p.tiles_y, shape, tpw_log2);
@@ -760,7 +763,10 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
     const uint32_t b = blockIdx.x;
     if (b == 0 && threadIdx.x == 0 && p.sticky) {  // as in k_blend
         const uint32_t bits = p.counters->overflow;
-        if (bits) atomicOr(p.sticky, bits);
+        if (bits) {
+            atomicOr(p.sticky, bits);
+            if (bits & 1u) atomicMax(p.sticky + 1, p.counters->entries_needed);  // what a retry (or the next prepare) allocates
+        }
     }
     const uint32_t xcd = b & 7u, j = b >> 3;
     const uint32_t nq = p.qw * p.qh;
@@ -902,7 +908,10 @@ __global__ __launch_bounds__(64) void k_blend_strict(const BlendParams p) {
     const uint32_t b = blockIdx.x;
     if (b == 0 && threadIdx.x == 0 && p.sticky) {  // as in k_blend
         const uint32_t bits = p.counters->overflow;
-        if (bits) atomicOr(p.sticky, bits);
+        if (bits) {
+            atomicOr(p.sticky, bits);
+            if (bits & 1u) atomicMax(p.sticky + 1, p.counters->entries_needed);  // what a retry (or the next prepare) allocates
+        }
     }
     const uint32_t xcd = b & 7u, j = b >> 3;
     const uint32_t nq = p.qw * p.qh;

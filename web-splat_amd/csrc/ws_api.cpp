@@ -142,7 +142,9 @@ struct ws_renderer {
     uint32_t* fp_sorted = nullptr;  // where the last frame's draw-ordered footprint words are
     int footprint_mode = FP_RECT_PACKED;  // of the current scratch (chosen by the viewport and WS_FOOTPRINT)
     uint32_t epoch = 0;
-    uint32_t* sticky = nullptr;      // device error word that survives the per-frame memset (ws_renderer_errors)
+    uint32_t* sticky = nullptr;      // two device words that survive the per-frame memset (ws_renderer_errors): [0] error bits
+                                     // of all frames since the last reset, [1] the largest entries_needed of an overflowed frame
+    uint32_t needed_seen = 0;        // host copy of [1]: the automatic entry capacity grows to it at the next prepare()
 
     // The frame's launch sequence of prepare() (memset + 21 kernels), captured once per (point cloud, scratch) and replayed:
     // only K1's arguments change from frame to frame (camera / settings uniforms, epoch).  A ring of executable graphs,
@@ -276,12 +278,14 @@ static void renderer_free_scratch(ws_renderer* r) {
 static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint32_t vh) {
     uint64_t want_cap = r->entry_cap_request;
     if (want_cap == 0) {
-        // automatic: 24 tile entries per Gaussian at ~1 Mpixel, growing with the pixel count (a splat's footprint in
-        // tiles scales with the resolution: the 24 M entries of 1 M Gaussians overflowed at 3840x2160), at least 8 M.
-        // 16 B per entry: 1.2 M Gaussians at 1200x799 -> 0.46 GB, 1 M at 4K -> 3.3 GB; 288 GB of HBM make this a
-        // non-issue, ws_renderer_set_tile_entry_capacity overrides it, and an overflow is always flagged.
+        // automatic: 4 tile entries per Gaussian at ~1 Mpixel, growing with the pixel count (a splat's footprint in tiles
+        // scales with the resolution), at least 8 M: twice what the BASELINE scenes need at the 32-px tile (hd1m 4.1 per
+        // Gaussian at 2.2 Mpixel, c3 1.2), 16 B per entry -- c3 0.7 GB instead of the 4.1 GB of rounds 1-3 (24 per Gaussian;
+        // round-3 verdict).  The safety net: an overflow is always flagged, the blend leaves the overflowed frame's demand
+        // in the sticky words, and once a read-back (ws_renderer_errors) has seen it the next prepare() allocates 1.25 x that.
         const double mpix = (double)vw * (double)vh / (1200.0 * 800.0);
-        want_cap = std::max<uint64_t>(8ull << 20, (uint64_t)(24.0 * (double)n * std::max(1.0, mpix)));
+        want_cap = std::max<uint64_t>(8ull << 20, (uint64_t)(4.0 * (double)n * std::max(1.0, mpix)));
+        if (r->needed_seen) want_cap = std::max<uint64_t>(want_cap, (uint64_t)r->needed_seen + r->needed_seen / 4 + 4096);
     }
     // look-back words carry 30-bit counts (lookback.h): keep D below 2^30
     want_cap = std::min<uint64_t>(want_cap, (1ull << 30) - 2 * EMIT_TILE);
@@ -794,8 +798,8 @@ int ws_renderer_create(ws_context* ctx, ws_color_format format, uint32_t sh_deg,
             return fail(WS_ERR_HIP, "ws_renderer_create: hipEventCreate failed");
         }
     }
-    if (hipMalloc(reinterpret_cast<void**>(&r->sticky), sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(r->sticky, 0, sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&r->sticky), 2 * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(r->sticky, 0, 2 * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         ws_renderer_destroy(r);
         return fail(WS_ERR_HIP, "ws_renderer_create: error word allocation failed");
     }
@@ -1353,7 +1357,10 @@ int ws_renderer_errors(ws_renderer* r, uint32_t* bits, uint32_t* entries_needed,
     // The sticky word outlives failed prepare() calls and scratch reallocations (both clear `prepared`): bits that earlier
     // frames left must not disappear behind them.  Only the per-frame counter needs a prepared frame.
     WS_HIP(hipStreamSynchronize(r->last_stream));
-    { int rc_ = copy_d2h(bits, r->sticky, sizeof(uint32_t), r->last_stream); if (rc_) return rc_; }
+    uint32_t both[2] = {0u, 0u};
+    { int rc_ = copy_d2h(both, r->sticky, sizeof(both), r->last_stream); if (rc_) return rc_; }
+    *bits = both[0];
+    if (both[1] > r->needed_seen) r->needed_seen = both[1];  // an overflowed frame's demand: the next prepare() allocates it
     if (entries_needed && r->prepared && r->counters) { int rc_ = copy_d2h(entries_needed, &r->counters->entries_needed, sizeof(uint32_t), r->last_stream); if (rc_) return rc_; }
     if (reset && *bits) {
         WS_HIP(hipMemsetAsync(r->sticky, 0, sizeof(uint32_t), r->last_stream));
