@@ -101,7 +101,7 @@ if [[ $WHAT == *prof* ]]; then
   for N in ${PROF_VARIANTS:-$(echo $VARIANTS | awk '{print $NF}' | cut -d= -f1)}; do
     for W in ${PROF_WORKLOADS:-$WORKLOADS}; do
       rm -rf $OUT/prof_${N}_$W
-      env $(venv $(vspec $N)) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${N}_$W -o prof -- python bench.py --steps 60 --warmup 10 --streams 1 --workload $W --no-cpu-baseline --no-dist > $OUT/prof_${N}_$W.log 2>&1; echo "prof $W ($N) exit=$?" >> $OUT/summary.txt
+      env $(venv $(vspec $N)) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${N}_$W -o prof -- python bench.py --steps 60 --warmup 10 --streams 1 --workload $W --no-cpu-baseline --no-secondary --no-dist > $OUT/prof_${N}_$W.log 2>&1; echo "prof $W ($N) exit=$?" >> $OUT/summary.txt
       python scripts/frame_timeline.py $OUT/prof_${N}_$W/prof_kernel_trace.csv > $OUT/${W}_${N}_frame_timeline.txt 2>&1
       cp $OUT/prof_${N}_$W/prof_kernel_stats.csv $OUT/${W}_${N}_kernel_stats.csv 2>/dev/null
       find $OUT/prof_${N}_$W -name "*kernel_trace*" -size +4M -delete
