@@ -181,6 +181,22 @@ def _physical_cores(cpus):
     return [groups[k] for k in sorted(groups)]
 
 
+def cpu_quota():
+    """CPUs' worth of run time the container's cgroup grants per period (cgroup v2 cpu.max, v1 cfs quota), or None: a box
+    may show 256 CPUs in its affinity mask and still be throttled to 16 (the one-GPU boxes of this build are)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def pin_host_share(local_rank, local_world):
     """Eight ranks on one node share its host cores: each rank builds the scene with an OpenMP team, then runs ONE enqueue
     thread (~65 % busy at 7000 frames/s) beside the HIP runtime's helper threads.  Left alone, every rank's team spans every
@@ -194,9 +210,11 @@ def pin_host_share(local_rank, local_world):
         return None, "affinity not available on this platform"
     if os.environ.get("WS_BENCH_PIN", "1") == "0":
         return allowed, "WS_BENCH_PIN=0: not pinned"
+    quota = cpu_quota()
+    team_cap = max(1, int(quota / max(local_world, 1))) if quota else None   # a team beyond the quota is only throttled
     if local_world <= 1:
-        os.environ.setdefault("OMP_NUM_THREADS", str(len(allowed)))
-        return allowed, f"one rank: all {len(allowed)} allowed CPUs"
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(len(allowed), team_cap) if team_cap else len(allowed)))
+        return allowed, f"one rank: all {len(allowed)} allowed CPUs" + (f", cgroup quota {quota:g} CPUs" if quota else "")
     cores = _physical_cores(allowed)
     if len(cores) < local_world:
         return allowed, f"{len(cores)} cores for {local_world} ranks: not pinned"
@@ -207,8 +225,10 @@ def pin_host_share(local_rank, local_world):
         want = min(int(os.environ.get("OMP_NUM_THREADS", len(share))), len(share))
     except ValueError:
         want = len(share)
+    if team_cap:
+        want = min(want, team_cap)
     os.environ["OMP_NUM_THREADS"] = str(max(want, 1))
-    return share, f"rank-local share: physical cores {lo}..{hi - 1} of {len(cores)} ({len(share)} logical CPUs), OMP_NUM_THREADS={os.environ['OMP_NUM_THREADS']}"
+    return share, f"rank-local share: physical cores {lo}..{hi - 1} of {len(cores)} ({len(share)} logical CPUs), OMP_NUM_THREADS={os.environ['OMP_NUM_THREADS']}" + (f", cgroup quota {quota:g} CPUs" if quota else "")
 
 
 def _free_port():
@@ -415,20 +435,22 @@ def main():
         submit(plan(0, a.warmup))
     timed = plan(a.warmup, a.steps)
     barrier()
+    cpu0 = time.process_time()   # CPU time of ALL threads of this process (enqueue thread + the HIP runtime's helpers)
     t0 = time.perf_counter()
     submit(timed)   # exactly K frames, enqueued back to back, one sync at the end
     t_enq = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    cpu_busy = (time.process_time() - cpu0) / max(elapsed, 1e-9)   # host cores this rank kept busy during the timed region
     if os.environ.get("WS_BENCH_DEBUG"):
         print(f"[bench debug] enqueue {t_enq * 1e3:.1f} ms, total {elapsed * 1e3:.1f} ms for {a.steps} frames", file=sys.stderr)
     # every frame of the timed region (and of the warm-up) must have been drawn completely: the slots' sticky error
     # words collect tile-entry overflow and look-back time-outs of ALL frames since the batch was created
     err_bits = batch.errors()
     if dist is not None:
-        t = torch.tensor([elapsed, float(err_bits), t_enq], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(err_bits), t_enq, cpu_busy], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # RCCL: the only collective, off the data path
-        elapsed, err_bits, t_enq = float(t[0].item()), int(t[1].item()), float(t[2].item())
+        elapsed, err_bits, t_enq, cpu_busy = float(t[0].item()), int(t[1].item()), float(t[2].item()), float(t[3].item())
     if err_bits:
         raise SystemExit(f"[bench] INVALID RUN: device-side error bits 0x{err_bits:x} in the timed frames (bit 0 = tile-entry "
                          "list overflow: entries were dropped; bits 1-3 = look-back time-out) -- no result line is printed")
@@ -449,6 +471,9 @@ def main():
                        # frames; host_bound = that thread, not the GPU, set the pace
                        "host_enqueue_ms_per_frame": t_enq / a.steps * 1e3, "host_bound": bool(t_enq > 0.8 * elapsed),
                        "host_cpus": len(host_cpus) if host_cpus else None, "host_affinity": host_note,
+                       # cores one rank keeps busy while it renders (MAX over ranks) and what the container grants in total:
+                       # world x busy above the quota means the ranks throttle each other, whatever the core count says
+                       "host_cores_busy_per_rank": cpu_busy, "host_cpu_quota": cpu_quota(),
                        "timing_barrier": ("none (one process, --no-dist)" if dist is None else
                                           "host barrier (gloo group) + device synchronize, both sides" if host_pg is not None
                                           else f"{dist.get_backend()} barrier + device synchronize, both sides")},

@@ -39,7 +39,7 @@ if [[ $WHAT == *measure* ]]; then
   grep -E "average_fps_(best|median)" $OUT/measure.log >> $OUT/summary.txt
 fi
 if [[ $WHAT == *host* ]]; then
-  timeout 900 python -m pytest tests/test_gpu_bench.py -m gpu -q --timeout 900 -p no:cacheprovider -k "eighth or secondary or contract" 2>&1 | tail -15 > $OUT/tests_host.log
+  timeout 900 python -m pytest tests/test_gpu_bench.py -m gpu -q --timeout 900 -p no:cacheprovider -k "sliver or secondary or contract or capacity" 2>&1 | tail -15 > $OUT/tests_host.log
   echo "host tests exit=${PIPESTATUS[0]}" >> $OUT/summary.txt; tail -3 $OUT/tests_host.log >> $OUT/summary.txt
   cp gpurun_out/host_contention.json $OUT/ 2>/dev/null; cat $OUT/host_contention.json >> $OUT/summary.txt 2>/dev/null
   ( time timeout 600 python bench.py > $OUT/default_bench.json 2> $OUT/default_bench.err ) 2> $OUT/default_bench.time; echo "default bench exit=$?" >> $OUT/summary.txt

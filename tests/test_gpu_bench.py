@@ -47,6 +47,7 @@ def test_bench_one_rank_rccl_and_contract():
     # must say whether the enqueue threads kept up)
     cfg = out["config"]
     assert cfg["host_enqueue_ms_per_frame"] > 0 and isinstance(cfg["host_bound"], bool) and cfg["host_cpus"] >= 1
+    assert 0 < cfg["host_cores_busy_per_rank"] < 64 and "host_cpu_quota" in cfg
     assert "secondary" not in out      # (only the default workload carries the c3 block)
 
 
@@ -70,43 +71,53 @@ def test_bench_secondary_c3_block():
     assert out["config"]["workload"].startswith("hd1m:") and out["value"] > 1000
 
 
-def test_bench_holds_its_rate_on_an_eighth_of_the_host(tmp_path):
-    """Eight ranks share one node's host: each gets an eighth of the cores (bench.py pins itself: pin_host_share) while the
-    other seven ranks' threads keep theirs busy.  Emulated on the one-GPU box: the hd1m line under `taskset` to the first
-    eighth of the physical cores, with burner threads spinning on ALL the other cores, against the same line with the whole
-    host to itself.  The rate must hold (within 7 %: run-to-run spread is +-2 %), and the record says the host was not
-    the limit."""
+def test_bench_holds_its_rate_on_a_sliver_of_the_host(tmp_path):
+    """Eight ranks share one node's host.  What one rank needs: measured on the one-GPU box by pinning the whole bench
+    process (`taskset`) to FOUR logical CPUs -- two physical cores of the first eighth of the host -- while stand-ins for
+    the other seven ranks (two busy threads each, scripts/ubench/cpu_burn.c) spin on CPUs of the other seven eighths.  The
+    hd1m line must hold the rate of the same line with the whole host to itself (within 7 %: run-to-run spread is +-2 %)
+    and say that the host was not the limit.  The burners respect the container's CPU QUOTA (cgroup cpu.max: this build's
+    boxes show 256 CPUs and grant 16 CPUs' worth of run time; 224 busy threads throttle the whole cgroup, bench included,
+    to a sixth of its rate -- profiles/r04/host_share_probe.txt -- which says nothing about bench.py)."""
+    sys.path.insert(0, ROOT)
+    import bench
     cores = _cpu_groups()
     if len(cores) < 16:
         pytest.skip("fewer than 16 physical cores: an eighth of the host is not a meaningful share")
-    mine = sorted(c for g in cores[: len(cores) // 8] for c in g)
-    others = sorted(c for g in cores[len(cores) // 8:] for c in g)
+    quota = bench.cpu_quota() or float(len(cores))
+    eighth = len(cores) // 8
+    mine = sorted(c for g in cores[:2] for c in g)                 # two physical cores (four logical CPUs with SMT)
+    nburn = int(min(14, max(0, quota - 6)))                        # two busy threads per other rank, inside the quota
+    burn_cpus = [cores[(1 + i % 7) * eighth + i // 7][0] for i in range(nburn)]
     burn = str(tmp_path / "cpu_burn")
     subprocess.run(["gcc", "-O2", "-pthread", os.path.join(ROOT, "scripts", "ubench", "cpu_burn.c"), "-o", burn], check=True)
     args = ["--steps", "1500", "--warmup", "50", "--no-cpu-baseline", "--no-secondary"]
     p0, free = _bench(args)
     assert p0.returncode == 0, p0.stderr[-3000:]
-    burner = subprocess.Popen([burn, "600", *map(str, others)], stdout=subprocess.PIPE, text=True)
+    burner = subprocess.Popen([burn, "600", *map(str, burn_cpus)], stdout=subprocess.PIPE, text=True) if nburn else None
     try:
-        burner.stdout.readline()   # "burning N cpus": the threads run
-        e = dict(os.environ)
+        if burner:
+            burner.stdout.readline()   # "burning N cpus": the threads run
         p = subprocess.run(["taskset", "-c", ",".join(map(str, mine)), sys.executable, os.path.join(ROOT, "bench.py"), *args],
-                           capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+                           capture_output=True, text=True, timeout=900, env=dict(os.environ), cwd=ROOT)
     finally:
-        burner.kill()
-        burner.wait()
+        if burner:
+            burner.kill()
+            burner.wait()
     assert p.returncode == 0, p.stderr[-3000:]
     shared = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    rep = {"whole_host": {"fps": free["value"], "host_enqueue_ms_per_frame": free["config"]["host_enqueue_ms_per_frame"],
-                          "host_cpus": free["config"]["host_cpus"]},
-           "eighth_with_burners": {"fps": shared["value"], "host_enqueue_ms_per_frame": shared["config"]["host_enqueue_ms_per_frame"],
-                                   "host_cpus": shared["config"]["host_cpus"], "burner_cpus": len(others)}}
+    keys = ("host_enqueue_ms_per_frame", "host_cores_busy_per_rank", "host_cpus", "host_cpu_quota", "host_bound")
+    rep = {"whole_host": dict({"fps": free["value"]}, **{k: free["config"][k] for k in keys}),
+           "four_cpus_beside_burners": dict({"fps": shared["value"], "burner_threads": nburn}, **{k: shared["config"][k] for k in keys})}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "host_contention.json"), "w") as f:
         json.dump(rep, f, indent=1)
     assert shared["config"]["host_cpus"] == len(mine)
     assert shared["config"]["host_bound"] is False, rep
     assert shared["value"] >= 0.93 * free["value"], rep
+    # eight such ranks fit the host: cores busy per rank x 8 stays below what the box has (and, where a quota exists, the
+    # record carries it so that a throttled 8-GPU run can be told from a slow one)
+    assert 8 * shared["config"]["host_cores_busy_per_rank"] <= len(cores), rep
 
 
 def test_bench_real_scene_hook(tmp_path):

@@ -497,7 +497,21 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     const float ly = (float)(qy * 8 + (lane >> 3)) + 0.5f;
     const uint32_t qbit = 1u << wave;
     const bool stager = NT == STAGE || tid < STAGE;  // wave-uniform
-    if ((uint32_t)tid < tpw) {  // the ranges of all my tiles up front: one round trip instead of one per tile
+    // One tile per workgroup (!MULTI): its coordinates and range are workgroup-uniform values of blockIdx -- scalar loads,
+    // no trip through LDS and no barrier in front of the first gather.  MULTI: the ranges of all my tiles up front, one
+    // round trip instead of one per tile.
+    uint2 range_one = make_uint2(0u, 0u);
+    uint32_t code_one = 0xFFFFFFFFu;
+    if (!MULTI) {
+        const uint32_t slot = blk.w;
+        const uint32_t tx = (blk.bx << shape.tbx_log2) + (slot & ((1u << shape.tbx_log2) - 1u));
+        const uint32_t ty = (blk.by << shape.tby_log2) + (slot >> shape.tbx_log2);
+        if (tx < p.tiles_x && ty < p.tiles_y) {
+            code_one = tx | (ty << 16);
+            range_one = p.tile_ranges[tile_list_index(p, tx, ty)];
+            range_one.x = range_one.y ? 0xFFFFFFFFu - range_one.x : 0u;
+        }
+    } else if ((uint32_t)tid < tpw) {
         const uint32_t slot = blk.w + (uint32_t)tid * wpb;
         const uint32_t tx = (blk.bx << shape.tbx_log2) + (slot & ((1u << shape.tbx_log2) - 1u));
         const uint32_t ty = (blk.by << shape.tby_log2) + (slot >> shape.tbx_log2);
@@ -511,11 +525,12 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         s_range[tid] = range;
         s_txy[tid] = code;
     }
-    if (tid == 0) {  // the null record: a' = 1e18, never inside the cut-off (visible after the first barrier)
+    if (tid == 0) {  // the null record: a' = 1e18, never inside the cut-off (visible after the first barrier: MULTI the one
+                     // below, else the first staging barrier of the tile loop -- nothing reads it before)
         s_rec[STAGE] = make_float4(0.0f, 0.0f, 1.0e9f, 0.0f);
         s_rec[SLOTS + STAGE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    __syncthreads();
+    if (MULTI) __syncthreads();
     const float W = (float)p.width, H = (float)p.height;
     uint32_t* my_list = s_list[wave];
 
@@ -523,15 +538,15 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     uint32_t rbuf = 0u;  // DMA: the raw buffer (slot offset 0 or STAGE) the current tile stages out of
     const uint32_t wslot = (uint32_t)wave * 64u;  // first raw slot of this wave (stager waves only)
     if (stager) {
-        const uint2 r0 = s_range[0];
+        const uint2 r0 = MULTI ? s_range[0] : range_one;
         if (r0.y > r0.x) {  // (an empty tile must not touch the entry list)
             if (DMA) blend_gather_lds(p, blend_entry_idx<STAGE>(p, r0, r0.y, tid), s_raw4 + wslot, s_raw1 + wslot);
             else raw = blend_fetch_raw<STAGE>(p, r0, r0.y, tid);
         }
     }
     for (uint32_t k = 0; k < tpw; ++k) {
-    const uint32_t code = s_txy[k];
-    const uint2 range = s_range[k];
+    const uint32_t code = MULTI ? s_txy[k] : code_one;
+    const uint2 range = MULTI ? s_range[k] : range_one;
     // the first batch of the NEXT tile (entry index -> Splat record: two dependent round trips) flies while this
     // tile is composited.  (DMA: issued from the first staging step of this tile, behind its s_waitcnt vmcnt(0): every
     // older LDS-DMA into that buffer -- the unused prefetch of an earlier tile that saturated -- has landed by then.)
