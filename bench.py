@@ -650,9 +650,6 @@ def analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world
         "k_preprocess<compressed>": n * 24 + V * (12 + 3 * (gpc.sh_deg + 1) ** 2) + V * 28,
         "depth:k_sort_tile_hist": 4 * V, "depth:k_sort_col_scan": None, "depth:k_sort_scatter": 16 * V,
         "depth:k_sort_hist": 4 * V,
-        # range-adaptive depth sort: the histogram kernel reads the keys; a scatter pass moves key + index + packed tile
-        # rectangle in and out (12 B each way)
-        "depth:k_dsort_hist": 4 * V, "depth:k_dsort_scatter": 24 * V, "k_gather_footprints": 12 * V,
         # fat-tile one-sweep (round 4): a pass reads and writes key + index + rectangle once; the single-launch form does
         # the histogram read and all four passes in one launch
         "depth:k_dsort_fat": 24 * V, "depth:k_dsort_fat_coop": 4 * 24 * V + 4 * V,

@@ -450,9 +450,9 @@ void ws_sorter_destroy(ws_sorter* s);
  * clamped to n): ascending, stable, in place in d_keys / d_payload (gpu_rs.rs:865-884). */
 int ws_sorter_sort(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, const uint32_t* d_count, uint32_t n,
                    void* stream);
-/* The same contract (record_sort / record_sort_indirect) through the renderer's depth-sort specialisation: three digit
- * passes whose width follows the range of the keys (typically 3 x 9 bits for a frame's depth keys instead of 4 x 8),
- * two launches per pass; d_aux (may be NULL) is a 4-byte companion that travels with the payload.  In place.
+/* The same contract (record_sort / record_sort_indirect) through the kernels a frame's depth sort runs: four 8-bit
+ * passes of the generic sorter -- or, in a context created with WS_DEPTH_SORT=onesweep | coop, the fat-tile one-sweep --
+ * with d_aux (may be NULL), a 4-byte companion that travels with the payload.  In place.
  * d_keys must be 16-byte aligned (both entry points: the histogram kernels read the keys four at a time);
  * WS_ERR_INVALID otherwise. */
 int ws_sorter_sort_depth(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, uint32_t* d_aux, const uint32_t* d_count,

@@ -263,19 +263,19 @@ def test_ply_file_roundtrip(ws, ctx, oracle, tmp_path):
             pc.close()
 
 
-@pytest.mark.parametrize("env", [{"WS_SORT_ALGO": "1"}, {"WS_BLEND_VARIANT": "1"}, {"WS_SORT_ALGO": "1", "WS_BLEND_VARIANT": "1"},
+@pytest.mark.parametrize("env", [{"WS_BLEND_VARIANT": "1"}, {"WS_DEPTH_SORT": "onesweep", "WS_BLEND_VARIANT": "1"},
                                  {"WS_TILE_SHAPE": "2x2"}, {"WS_TILE_SHAPE": "4x2"}, {"WS_TILE_SHAPE": "4x4"},
                                  {"WS_TILE_SHAPE": "4x2", "WS_BLEND_VARIANT": "1"},
-                                 {"WS_TILE_SHAPE": "4x4", "WS_BLEND_VARIANT": "1", "WS_SORT_ALGO": "1"},
+                                 {"WS_TILE_SHAPE": "4x4", "WS_BLEND_VARIANT": "1", "WS_DEPTH_SORT": "onesweep"},
                                  {"WS_TILE_SHAPE": "4x4", "WS_BLEND_TPW_LOG2": "1"},
                                  {"WS_TILE_SHAPE": "4x2", "WS_BLEND_TPW_LOG2": "2"},
-                                 {"WS_DEPTH_SORT": "adaptive"}, {"WS_DEPTH_SORT": "adaptive", "WS_TILE_SHAPE": "2x2"},
+                                 {"WS_DEPTH_SORT": "onesweep", "WS_TILE_SHAPE": "2x2"},
                                  {"WS_BLEND_SPLIT": "1"}, {"WS_BLEND_SPLIT": "0"},
                                  {"WS_BLEND_DMA": "1"}, {"WS_BLEND_DMA": "1", "WS_BLEND_TPW_LOG2": "2"},
                                  {"WS_DEPTH_SORT": "onesweep"}, {"WS_DEPTH_SORT": "coop"}, {"WS_DEPTH_SORT": "scan"}])
 def test_cross_check_paths(ws, oracle, env, monkeypatch):
-    """The alternative implementations kept as cross-checks (one-sweep look-back sort, range-adaptive three-pass depth
-    sort, wave-per-quadrant blend) and
+    """The alternative implementations kept as cross-checks (fat-tile one-sweep depth sort as per-pass launches and as one
+    launch with device-wide barriers, wave-per-quadrant blend, LDS-DMA staging) and
     every tile shape (16x16, 32x16, 32x32 binning tiles) must give the same image as the oracle: a context reads the
     selection from the environment when it is created."""
     for k, v in env.items():

@@ -8,15 +8,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[1, 0, "depth", "depth:onesweep", "depth:coop"],
-                ids=["onesweep", "reduce_scan", "depth3pass", "depth_fat_onesweep", "depth_fat_coop"])
+@pytest.fixture(scope="module", params=["generic", "depth", "depth:onesweep", "depth:coop"],
+                ids=["reduce_scan", "depth_scan_companion", "depth_fat_onesweep", "depth_fat_coop"])
 def sort_ctx(ws, request):
-    """Five paths to the same contract: the generic sorter's one-sweep and reduce-then-scan cross-tile prefixes, and the
-    renderer's depth sorts behind ws_sorter_sort_depth -- the range-adaptive three-pass form and the fat-tile one-sweep
-    (round 4), as per-pass launches and as ONE launch with device-wide barriers (WS_DEPTH_SORT selects; inputs beyond
-    the fat form's 2 M pairs fall back to the three-pass form)."""
-    depth = isinstance(request.param, str)
-    env = {"WS_SORT_ALGO": "0" if depth else str(request.param)}
+    """Four paths to the same contract: the generic sorter (per-tile histograms -> column scan -> scatter), and the
+    renderer's depth sorts behind ws_sorter_sort_depth -- the generic sorter carrying a companion value, and the fat-tile
+    one-sweep (round 4) as per-pass launches and as ONE launch with device-wide barriers (WS_DEPTH_SORT selects; inputs
+    beyond the fat form's 2 M pairs take the generic sorter)."""
+    depth = request.param != "generic"
+    env = {}
     if depth and ":" in request.param:
         env["WS_DEPTH_SORT"] = request.param.split(":")[1]
     old = {k: os.environ.get(k) for k in env}
@@ -125,9 +125,10 @@ def test_sort_large_sortedness(ws, sort_ctx):
 
 
 @pytest.mark.parametrize("nbits", [0, 1, 5, 12, 13, 20, 26, 27, 28, 30, 31, 32])
-def test_depth_sort_digit_width_follows_the_key_range(ws, ctx, oracle, nbits):
-    """The depth sort sizes its three digit passes by bit_length(kmax - kmin): every width from 4 to 11 bits, ranges that
-    start anywhere (kmin is subtracted), including the full 32 bits and a single value."""
+def test_depth_sort_key_ranges(ws, ctx, oracle, nbits):
+    """Keys confined to a range of nbits bits that starts anywhere (a frame's depth keys are: bits of zfar - z), from a
+    single value to the full 32 bits: passes whose digit is the same for every key are the degenerate case of every
+    histogram and scan in the sorter."""
     n = 300_001
     rng = np.random.default_rng(1000 + nbits)
     span = (1 << nbits) - 1 if nbits else 0

@@ -537,7 +537,6 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_cnt[K1_ITEMS][K1_THREADS / 64];
     __shared__ uint32_t s_base;
-    __shared__ uint32_t s_kmax[K1_THREADS / 64], s_kmin_inv[K1_THREADS / 64];
     __shared__ uint32_t s_t32[K1_THREADS / 64], s_t64[K1_THREADS / 64];
 
     const int tid = threadIdx.x;
@@ -627,25 +626,6 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
             if (vis[it]) k1_back_compressed<FPMODE>(p, b, fr[it], &so[it]);
     }
 
-    // ---- range of the block's depth keys (the depth sort sizes its digits by the frame's range, sort.hip) ----------
-    {
-        uint32_t kmax = 0u, kmin_inv = 0u;
-#pragma unroll
-        for (int it = 0; it < K1_ITEMS; ++it)
-            if (vis[it]) {
-                kmax = max(kmax, so[it].key);
-                kmin_inv = max(kmin_inv, ~so[it].key);
-            }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
-            kmin_inv = max(kmin_inv, (uint32_t)__shfl_xor((int)kmin_inv, o, 64));
-        }
-        if (lane == 0) {
-            s_kmax[wave] = kmax;
-            s_kmin_inv[wave] = kmin_inv;
-        }
-    }
     // ---- ordered compaction, part 2: look-back (wave 0) and scatter ----------------------------------------
     if (wave == 0) {
         // (measured: replacing the ordered look-back by one unordered atomicAdd per block does not change this kernel's
@@ -658,17 +638,6 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
         }
     }
     __syncthreads();
-    if (tid == 0 && block_cnt) {  // returnless atomics on this workgroup's slot of the key-range table
-        uint32_t kmax = 0u, kmin_inv = 0u;
-#pragma unroll
-        for (int w = 0; w < K1_THREADS / 64; ++w) {
-            kmax = max(kmax, s_kmax[w]);
-            kmin_inv = max(kmin_inv, s_kmin_inv[w]);
-        }
-        uint32_t* kr = b.key_range + (bid & (KEY_RANGE_SLOTS - 1)) * KEY_RANGE_STRIDE;
-        atomicMax(kr, kmax);
-        atomicMax(kr + 1, kmin_inv);
-    }
     const uint32_t base = s_base;
 #pragma unroll
     for (int it = 0; it < K1_ITEMS; ++it) {

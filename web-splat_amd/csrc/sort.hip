@@ -12,17 +12,14 @@
 // tiles' runs meet in one L2).  Digit width is a template parameter: 8 bits for 32-bit keys, 6..8 for the tile-id
 // sort, whose keys may also be stored as 16-bit values.
 //
-// Cross-tile prefix, two selectable paths (measured on MI355X, profiles/):
-//   algo 0  "tile histograms -> column scan -> scatter" (default): per pass a histogram kernel writes the digit counts
-//           of every tile (transposed, [digit][tile]), one workgroup per digit scans its row, the scatter kernel reads
-//           its offsets.  No spinning, nothing to order; costs one extra read of the keys per pass.  When the producer
-//           of the keys already knows the per-tile digit counts of the first pass (the tile binning kernel does)
-//           that histogram kernel is skipped.
-//   algo 1  one-sweep: one histogram pass for all digits, then per pass a decoupled look-back over epoch-tagged
-//           64-bit {epoch,flag,count} words (lookback.h), windowed (4 predecessor tiles per round trip), tiles handed
-//           out by an atomic ticket.  Fewer launches, every pair read once per pass, but with every tile co-resident
-//           and starting together the look-back chain (one ~1 us cross-XCD round trip per hop) costs more than
-//           re-reading the keys.  Kept as a cross-check (tests run both).
+// Cross-tile prefix ("tile histograms -> column scan -> scatter"): per pass a histogram kernel writes the digit counts of
+// every tile (transposed, [digit][tile]), one workgroup per digit scans its row, the scatter kernel reads its offsets.  No
+// spinning, nothing to order; costs one extra read of the keys per pass.  When the producer of the keys already knows the
+// per-tile digit counts of the first pass (the tile binning kernel does) that histogram kernel is skipped.
+// Two other forms were built, tested bit-exact and measured slower in two rounds each; they left the tree in round 4
+// (git history): the classic one-sweep with a windowed decoupled look-back over 2048-pair tiles (every tile
+// is resident and starts together on this chip: ~83 serial hops at 0.7 M keys) and the range-adaptive three-pass depth sort.
+// The fat-tile one-sweep below (k_dsort_fat) is the form of that idea that does not chain; it is a measured variant too.
 #include <hip/hip_runtime.h>
 
 #include "grid_barrier.h"
@@ -37,7 +34,6 @@ namespace {
 
 constexpr int WAVES = SORT_THREADS / 64;
 constexpr int HIST_COPIES = 8;  // replicated LDS bins: lanes l and l+8k share a copy -> <= 8-way conflicts
-constexpr int LB_WINDOW = 4;
 
 __device__ __forceinline__ uint32_t device_count(const uint32_t* d_count, uint32_t n) {
     if (!d_count) return n;
@@ -80,7 +76,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     return wave_off + incl - v;
 }
 
-// ---- algo 1: histogram of every participating digit in one read of the keys -------------------------
+// ---- histogram of every participating digit in one read of the keys (the fat-tile one-sweep's extra launch) ----
 // LDS bins are replicated HIST_COPIES times (copy = lane & 7): depth keys and tile ids are strongly
 // clustered in their upper digits, and 64 lanes hammering one LDS word serialise.
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys,
@@ -121,7 +117,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __re
     }
 }
 
-// ---- algo 0: digit counts of every tile, transposed: tile_sums[digit * tiles_cap + tile] ---------------
+// ---- digit counts of every tile, transposed: tile_sums[digit * tiles_cap + tile] -----------------------------------
 template <int KPT, bool KEY16>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ d_count, uint32_t n,
@@ -187,7 +183,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* 
     if (threadIdx.x == 0) hist[blockIdx.x] = total;
 }
 
-// ---- one digit pass: rank, cross-tile prefix (look-back or precomputed), LDS reorder, scatter ----------
+// ---- one digit pass: rank, precomputed cross-tile prefix, LDS reorder, scatter ------------------------------------
 // RANGES (last pass of the tile-id sort only): the sorted keys themselves are never read again -- what the
 // compositing pass needs is [begin, end) of every key value in the sorted order.  Equal keys of one workgroup are
 // a contiguous run of its LDS-ordered tile, so run boundaries are found there and merged across workgroups with
@@ -200,20 +196,16 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* 
 // KEY16: the key arrays hold uint16_t (tile ids below 65535): 2 B less per entry.  A template parameter, not an argument:
 // with both load forms behind a run-time flag the compiler shared registers between them and put a full s_waitcnt vmcnt
 // between the second and third key load of every thread -- two exposed round trips per tile instead of one.
-template <bool LOOKBACK, int KPT, bool RANGES, int BITS, bool CARRY = false, bool KEY16 = false>
+template <int KPT, bool RANGES, int BITS, bool CARRY = false, bool KEY16 = false>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out,
     const uint32_t* __restrict__ d_count, uint32_t n, int shift, int iota,
     const uint32_t* __restrict__ hist,     // [256] global digit histogram of this pass
-    uint64_t* __restrict__ status,         // [tiles][256] epoch-tagged look-back words      (LOOKBACK)
-    uint32_t* __restrict__ ticket,         // tile dispenser, zero on entry                  (LOOKBACK)
-    const uint32_t* __restrict__ tile_off, // [256][tiles_cap] exclusive offsets per digit   (!LOOKBACK)
-    uint32_t tiles_cap, uint32_t epoch, uint32_t* __restrict__ error_word, uint2* __restrict__ ranges,
-    uint32_t nranges) {
+    const uint32_t* __restrict__ tile_off, // [256][tiles_cap] exclusive offsets per digit
+    uint32_t tiles_cap, uint2* __restrict__ ranges, uint32_t nranges) {
     constexpr int TILE_N = SORT_THREADS * KPT;
     constexpr uint32_t DMASK = (1u << BITS) - 1u;
-    static_assert(!LOOKBACK || BITS == RADIX_BITS, "the one-sweep path uses 8-bit digits");
     __shared__ uint32_t s_wave_hist[WAVES][RADIX];
     __shared__ uint32_t s_local_excl[RADIX];
     __shared__ uint32_t s_global_base[RADIX];
@@ -221,7 +213,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     __shared__ uint32_t s_vals[TILE_N];
     __shared__ uint32_t s_aux[CARRY ? TILE_N : 1];
     __shared__ uint32_t s_tmp[WAVES];
-    __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -230,20 +221,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t count = device_count(d_count, n);
     // first output position of every digit: the same for all tiles of this pass
     const uint32_t digit_base = block_exclusive_scan((uint32_t)tid <= DMASK ? hist[tid] : 0u, s_tmp, nullptr);
-    // Scan path: the grid is capped (sort_grid) and workgroups stride over the tiles.  One-sweep path: the grid is
-    // sized for the host-side bound n, only ceil(count / TILE) workgroups have work; the surplus ones leave BEFORE
-    // touching the ticket, so exactly the needed number of tickets 0..ntiles-1 is drawn, one tile per workgroup.
+    // the grid is capped (sort_grid) and workgroups stride over the tiles
     const uint32_t ntiles = (count + TILE_N - 1) / TILE_N;
-    for (uint32_t L = blockIdx.x; LOOKBACK ? ((uint64_t)L * TILE_N < count) : ((L >> 3) < ((ntiles + 7u) >> 3));
-         L += gridDim.x) {
+    for (uint32_t L = blockIdx.x; (L >> 3) < ((ntiles + 7u) >> 3); L += gridDim.x) {
     uint32_t t;
-    if (LOOKBACK) {
-        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-        __syncthreads();
-        t = s_tile;
-    } else if (!xcd_tile(L, ntiles, &t)) {
-        continue;  // block-uniform
-    }
+    if (!xcd_tile(L, ntiles, &t)) continue;  // block-uniform
     const uint32_t tile_base = t * TILE_N;
     const uint32_t valid = (count - tile_base) < (uint32_t)TILE_N ? (count - tile_base) : (uint32_t)TILE_N;
 
@@ -271,7 +253,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         }
     }
     uint32_t my_tile_off = 0u;  // issued early: needed only after the ranking
-    if (!LOOKBACK && (uint32_t)tid <= DMASK) my_tile_off = tile_off[(size_t)tid * tiles_cap + t];
+    if ((uint32_t)tid <= DMASK) my_tile_off = tile_off[(size_t)tid * tiles_cap + t];
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) s_wave_hist[w][tid] = 0u;
     __syncthreads();
@@ -326,49 +308,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         s_wave_hist[w][tid] = tile_cnt;
         tile_cnt += c;
     }
-    if (LOOKBACK) {
-        // publish first, scan afterwards: successors can use the aggregate while this tile is still busy.
-        // padding keys (0xFFFFFFFF, digit 255 in every pass) are ranked last and never published
-        const uint32_t pub_cnt = tile_cnt - ((tid == RADIX - 1) ? ((uint32_t)TILE_N - valid) : 0u);
-        uint64_t* my_status = status + (size_t)t * RADIX + tid;
-        lb::st(my_status, lb::pack(epoch, t == 0 ? lb::FLAG_INCL : lb::FLAG_AGG, pub_cnt));
-        const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp, nullptr);
-        s_local_excl[tid] = local_excl;
-        uint32_t prev_sum = 0;
-        if (t > 0) {
-            int64_t i = (int64_t)t - 1;  // next predecessor to consume
-            uint32_t spins = 0;
-            bool done = false;
-            while (!done) {
-                uint64_t w[LB_WINDOW];
-#pragma unroll
-                for (int j = 0; j < LB_WINDOW; ++j) {
-                    const int64_t idx = i - j;
-                    w[j] = idx >= 0 ? lb::ld(status + (size_t)idx * RADIX + tid) : lb::pack(epoch, lb::FLAG_INCL, 0u);
-                }
-                int consumed = 0;
-#pragma unroll
-                for (int j = 0; j < LB_WINDOW; ++j) {
-                    if (done || consumed < j) continue;  // stop at the first unpublished word
-                    const uint32_t flag = lb::flag_of(w[j], epoch);
-                    if (flag == 0u) continue;
-                    prev_sum += lb::value_of(w[j]);
-                    consumed = j + 1;
-                    if (flag == lb::FLAG_INCL) done = true;
-                }
-                i -= consumed;
-                if (!done && consumed < LB_WINDOW) {
-                    if (++spins > lb::SPIN_LIMIT) {
-                        if (error_word) atomicOr(error_word, 8u);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            lb::st(my_status, lb::pack(epoch, lb::FLAG_INCL, prev_sum + pub_cnt));
-        }
-        s_global_base[tid] = digit_base + prev_sum - local_excl;  // + tile-local position = global address
-    } else {
+    {
         const uint32_t local_excl = block_exclusive_scan(tile_cnt, s_tmp, nullptr);
         s_local_excl[tid] = local_excl;
         s_global_base[tid] = digit_base + my_tile_off - local_excl;
@@ -406,7 +346,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             }
         }
     }
-    if (LOOKBACK) break;  // one ticket per workgroup
     __syncthreads();      // LDS is reused by the next tile
     }
 }
@@ -415,7 +354,7 @@ template <int KPT, int BITS, bool KEY16>
 int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t* ain,
                     uint32_t* aout,
                     const uint32_t* d_count, uint32_t n, int begin_bit, int npass, bool implicit_iota,
-                    bool first_tile_hist_ready, uint32_t epoch, hipStream_t stream, uint32_t** fk, uint32_t** fv,
+                    bool first_tile_hist_ready, hipStream_t stream, uint32_t** fk, uint32_t** fv,
                     KernelMarks* km, const char* const* names, uint2* ranges, uint32_t nranges) {
     constexpr uint32_t TILE_N = SORT_THREADS * KPT;
     const uint32_t tiles = sort_grid((n + TILE_N - 1) / TILE_N);
@@ -431,20 +370,17 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
                            sc.tile_sums, sc.tiles_cap, sc.hist + p * RADIX);
         km_mark(km, names[1]);
         if (ranges && p == npass - 1)
-            hipLaunchKernelGGL((k_sort_scatter<false, KPT, true, BITS, false, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
+            hipLaunchKernelGGL((k_sort_scatter<KPT, true, BITS, false, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota,
-                               sc.hist + p * RADIX, (uint64_t*)nullptr, (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch,
-                               (uint32_t*)nullptr, ranges, nranges);
+                               sc.hist + p * RADIX, sc.tile_sums, sc.tiles_cap, ranges, nranges);
         else if (ain)
-            hipLaunchKernelGGL((k_sort_scatter<false, KPT, false, BITS, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
-                               vin, kout, vout, ain, aout, d_count, n, shift, iota, sc.hist + p * RADIX, (uint64_t*)nullptr,
-                               (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch, (uint32_t*)nullptr, (uint2*)nullptr,
-                               0u);
+            hipLaunchKernelGGL((k_sort_scatter<KPT, false, BITS, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
+                               vin, kout, vout, ain, aout, d_count, n, shift, iota, sc.hist + p * RADIX, sc.tile_sums,
+                               sc.tiles_cap, (uint2*)nullptr, 0u);
         else
-            hipLaunchKernelGGL((k_sort_scatter<false, KPT, false, BITS, false, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
+            hipLaunchKernelGGL((k_sort_scatter<KPT, false, BITS, false, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota,
-                               sc.hist + p * RADIX, (uint64_t*)nullptr, (uint32_t*)nullptr, sc.tile_sums, sc.tiles_cap, epoch,
-                               (uint32_t*)nullptr, (uint2*)nullptr, 0u);
+                               sc.hist + p * RADIX, sc.tile_sums, sc.tiles_cap, (uint2*)nullptr, 0u);
         km_mark(km, names[2]);
         WS_HIP(hipGetLastError());
         uint32_t* tk = kin;
@@ -627,398 +563,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_scatter_wide(
             const uint32_t pos = wave_base + j * 64;
             const uint32_t d = key[j] & (uint32_t)(BINS - 1);
             if (pos < count) vals_out[s_base[d] + ((s_wave_hist[wsel][d] >> wsh) & 0xFFFFu) + rank[j]] = val[j];
-        }
-        __syncthreads();  // LDS is reused by the next tile
-    }
-}
-
-// =====================================================================================================================
-// Depth sort: three range-adaptive digit passes, two launches per pass (ws_internal.h, DepthSortScratch).
-// =====================================================================================================================
-struct DSortPlan {
-    uint32_t kmin;   // smallest key of the input: digits are taken from key - kmin
-    uint32_t w;      // digit width of all three passes, 4..11
-    uint32_t shift;  // pass * w
-    uint32_t mask;   // (1 << w) - 1
-    uint32_t nb;     // 1 << w bins
-};
-
-// The plan is a pure function of the key range K1 (or k_key_minmax) left in device memory: every workgroup of every
-// launch of the sort derives the same one.  nbits = bit length of (kmax - kmin); three passes of ceil(nbits / 3) bits.
-__device__ __forceinline__ DSortPlan dsort_plan(const uint32_t* __restrict__ key_range, int pass) {
-    uint32_t kmax = 0u, kmin_inv = 0u;
-#pragma unroll
-    for (int sl = 0; sl < KEY_RANGE_SLOTS; ++sl) {
-        kmax = max(kmax, key_range[sl * KEY_RANGE_STRIDE]);
-        kmin_inv = max(kmin_inv, key_range[sl * KEY_RANGE_STRIDE + 1]);
-    }
-    DSortPlan p;
-    p.kmin = ~kmin_inv;
-    const uint32_t range = kmax >= p.kmin ? kmax - p.kmin : 0u;  // (no keys at all: 0)
-    const uint32_t nbits = range ? 32u - (uint32_t)__clz((int)range) : 0u;
-    uint32_t w = (nbits + (uint32_t)DSORT_PASSES - 1u) / (uint32_t)DSORT_PASSES;
-    if (w < 4u) w = 4u;
-    p.w = w;
-    p.shift = (uint32_t)pass * w;
-    p.mask = (1u << w) - 1u;
-    p.nb = 1u << w;
-    return p;
-}
-
-// tiles are grouped for the cross-tile prefix: at most DSORT_MAX_GROUPS groups of `gt` consecutive tiles
-__device__ __forceinline__ uint32_t dsort_group_tiles(uint32_t ntiles) {
-    const uint32_t gt = (ntiles + (uint32_t)DSORT_MAX_GROUPS - 1u) / (uint32_t)DSORT_MAX_GROUPS;
-    return gt ? gt : 1u;
-}
-
-constexpr int DSORT_LB_WINDOW = 16;  // predecessor rows per look-back round trip
-
-// ---- k_dsort_hist: per-tile digit counts + the whole cross-tile prefix, one launch ------------------------------
-// One 1024-thread workgroup = one GROUP of gt consecutive tiles (group ids from an atomic ticket: a workgroup only ever
-// waits for groups that already run).
-//   phase 1  every WAVE counts whole tiles on its own (tiles wave, wave + 16, ... of the group) into a wave-private
-//            LDS histogram of 16-bit counters -- no workgroup barrier inside the loop, sixteen tiles' loads in flight per
-//            CU -- and writes the raw counts to tile_off[t][.].
-//   phase 2  per digit: exclusive prefix over the group's tiles in place (tile_off[t][d] = digits d in the group's
-//            EARLIER tiles); the group's digit counts are published as epoch-tagged 64-bit words; the predecessors'
-//            words are summed (the groups start together, so all of them are published at about the same time: a few
-//            windows of independent loads, not a serial chain) into group_off[g][d]; the last group leaves the
-//            exclusive scan of the digit totals, the first output position of every digit.
-// The scatter kernel adds the three levels: totals[d] + group_off[g][d] + tile_off[t][d].
-constexpr int DH_THREADS = 1024;
-constexpr int DH_WAVES = DH_THREADS / 64;
-
-__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* s_tmp /*[DH_WAVES]*/, uint32_t* total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_tmp[wave] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < DH_WAVES; ++w) {
-        const uint32_t c = s_tmp[w];
-        if (w < wave) wave_off += c;
-        tot += c;
-    }
-    __syncthreads();
-    if (total) *total = tot;
-    return wave_off + incl - v;
-}
-
-template <int KPT>
-__global__ __launch_bounds__(DH_THREADS) void k_dsort_hist(const uint32_t* __restrict__ keys,
-                                                          const uint32_t* __restrict__ d_count, uint32_t n, int pass,
-                                                          const uint32_t* __restrict__ key_range,
-                                                          uint32_t* __restrict__ tile_off,
-                                                          uint32_t* __restrict__ group_off,  // [groups][nb] of this pass
-                                                          uint64_t* __restrict__ status,     // [groups][nb] of this pass
-                                                          uint32_t* __restrict__ totals,     // [nb] of this pass: first output position of every digit
-                                                          uint32_t* __restrict__ ticket, uint32_t epoch,
-                                                          uint32_t* __restrict__ error_word) {
-    constexpr int TILE_N = SORT_THREADS * KPT;
-    constexpr int QPL = TILE_N / 256;                      // 16-byte key quads per lane and tile
-    constexpr int MAX_DPT = DSORT_MAX_BINS / DH_THREADS;   // digits per thread in phase 2 (2 at 2048 bins)
-    __shared__ uint32_t s_cnt[DH_WAVES][DSORT_MAX_BINS / 2];  // wave-private, two 16-bit counters per word (a tile has < 65536 keys)
-    __shared__ uint32_t s_group;
-    __shared__ uint32_t s_tmp[DH_WAVES];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t count = device_count(d_count, n);
-    if (count == 0u) return;
-    const uint32_t ntiles = (count + TILE_N - 1) / TILE_N;
-    const uint32_t gt = dsort_group_tiles(ntiles);
-    const uint32_t ngroups = (ntiles + gt - 1u) / gt;
-    if (blockIdx.x >= ngroups) return;  // surplus workgroups leave before drawing a ticket
-    if (tid == 0) s_group = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t g = s_group;
-    const DSortPlan pl = dsort_plan(key_range, pass);
-    const uint32_t nb = pl.nb;
-
-    // ---- phase 1: whole tiles per wave ---------------------------------------------------------------------
-    uint32_t* cnt = s_cnt[wave];
-    const uint4* keys4 = reinterpret_cast<const uint4*>(keys);
-    for (uint32_t ti = (uint32_t)wave; ti < gt; ti += DH_WAVES) {
-        const uint32_t t = g * gt + ti;
-        if (t >= ntiles) break;  // wave-uniform
-        for (uint32_t i = lane; i < nb / 2u; i += 64u) cnt[i] = 0u;
-        const uint32_t base = t * TILE_N;
-        uint4 q[QPL];
-#pragma unroll
-        for (int j = 0; j < QPL; ++j) {
-            const uint32_t p4 = base + (uint32_t)(j * 64 + lane) * 4u;
-            if (p4 + 3u < count) {
-                q[j] = keys4[p4 >> 2];
-            } else {  // the last, partial quad(s) of the input
-                q[j].x = p4 < count ? keys[p4] : 0u;
-                q[j].y = p4 + 1u < count ? keys[p4 + 1u] : 0u;
-                q[j].z = p4 + 2u < count ? keys[p4 + 2u] : 0u;
-                q[j].w = 0u;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < QPL; ++j) {
-            const uint32_t p4 = base + (uint32_t)(j * 64 + lane) * 4u;
-            const uint32_t kk[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (p4 + (uint32_t)e < count) {
-                    const uint32_t d = ((kk[e] - pl.kmin) >> pl.shift) & pl.mask;
-                    atomicAdd(&cnt[d >> 1], 1u << ((d & 1u) * 16u));
-                }
-            }
-        }
-        // raw counts of the tile (LDS operations of one wave execute in order: no barrier needed)
-        uint2* row = reinterpret_cast<uint2*>(tile_off + (size_t)t * nb);
-        for (uint32_t i = lane; i < nb / 2u; i += 64u) {
-            const uint32_t wv = cnt[i];
-            row[i] = make_uint2(wv & 0xFFFFu, wv >> 16);
-        }
-    }
-    __syncthreads();  // workgroup-scope release / acquire: phase 2 reads what the other waves just stored
-
-    // ---- phase 2: thread owns digits tid, tid + 1024 ----------------------------------------------------------
-    const uint32_t t_first = g * gt;
-    const uint32_t t_end = (t_first + gt) < ntiles ? (t_first + gt) : ntiles;
-    uint32_t run[MAX_DPT];
-#pragma unroll
-    for (int j = 0; j < MAX_DPT; ++j) {
-        const uint32_t d = (uint32_t)tid + (uint32_t)j * DH_THREADS;
-        run[j] = 0u;
-        if (d < nb) {
-            uint32_t acc = 0u;
-            for (uint32_t t = t_first; t < t_end; t += 8u) {  // eight independent loads in flight
-                uint32_t c[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) c[u] = (t + u < t_end) ? tile_off[(size_t)(t + u) * nb + d] : 0u;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (t + u < t_end) tile_off[(size_t)(t + u) * nb + d] = acc;
-                    acc += c[u];
-                }
-            }
-            run[j] = acc;
-            // publish first, look back afterwards: successors can use the aggregate at once
-            lb::st(status + (size_t)g * nb + d, lb::pack(epoch, g == 0u ? lb::FLAG_INCL : lb::FLAG_AGG, acc));
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < MAX_DPT; ++j) {
-        const uint32_t d = (uint32_t)tid + (uint32_t)j * DH_THREADS;
-        if (d >= nb) continue;
-        uint32_t prev_sum = 0u;
-        if (g > 0u) {
-            int64_t i = (int64_t)g - 1;  // next predecessor to consume
-            uint32_t spins = 0u;
-            bool done = false;
-            while (!done) {
-                uint64_t wv[DSORT_LB_WINDOW];
-#pragma unroll
-                for (int q2 = 0; q2 < DSORT_LB_WINDOW; ++q2) {
-                    const int64_t idx = i - q2;
-                    wv[q2] = idx >= 0 ? lb::ld(status + (size_t)idx * nb + d) : lb::pack(epoch, lb::FLAG_INCL, 0u);
-                }
-                int consumed = 0;
-#pragma unroll
-                for (int q2 = 0; q2 < DSORT_LB_WINDOW; ++q2) {
-                    if (done || consumed < q2) continue;  // stop at the first unpublished word
-                    const uint32_t flag = lb::flag_of(wv[q2], epoch);
-                    if (flag == 0u) continue;
-                    prev_sum += lb::value_of(wv[q2]);
-                    consumed = q2 + 1;
-                    if (flag == lb::FLAG_INCL) done = true;
-                }
-                i -= consumed;
-                if (!done && consumed < DSORT_LB_WINDOW) {
-                    if (++spins > lb::SPIN_LIMIT) {
-                        if (error_word) atomicOr(error_word, 8u);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            lb::st(status + (size_t)g * nb + d, lb::pack(epoch, lb::FLAG_INCL, prev_sum + run[j]));
-        }
-        group_off[(size_t)g * nb + d] = prev_sum;
-        run[j] += prev_sum;  // in the last group: the total count of digit d
-    }
-    // The last group knows the digit totals of the pass: it leaves their exclusive scan, the first output position of
-    // every digit (one workgroup does it once instead of every scatter workgroup redoing it).
-    if (g == ngroups - 1u) {  // block-uniform
-        uint32_t carry = 0u;
-#pragma unroll
-        for (int j = 0; j < MAX_DPT; ++j) {
-            const uint32_t d = (uint32_t)tid + (uint32_t)j * DH_THREADS;
-            const uint32_t c = d < nb ? run[j] : 0u;
-            uint32_t total;
-            const uint32_t ex = block_exclusive_scan_1024(c, s_tmp, &total) + carry;
-            if (d < nb) totals[d] = ex;
-            carry += total;
-        }
-    }
-}
-
-// ---- k_dsort_scatter: one digit pass -------------------------------------------------------------------------------
-// The ranking of k_sort_scatter (wave64 ballots, one leader lane per distinct digit bumps the wave's LDS counter) with a
-// RUN-TIME digit width: up to 2048 bins.  To keep five-ish workgroups per CU at that size the per-wave counters are 16 bit
-// (a wave holds at most 64 * KPT keys; LDS atomics work on the containing 32-bit word) and share their LDS with the
-// reorder buffers (they are dead by the time the pairs move), at the price of one more barrier per tile.
-// CARRY: a 4-byte companion value travels with the payload (the splat's packed tile rectangle).
-#ifndef WS_DSORT_MINWAVES
-#define WS_DSORT_MINWAVES 1
-#endif
-template <int KPT, bool CARRY>
-__global__ __launch_bounds__(SORT_THREADS, WS_DSORT_MINWAVES) void k_dsort_scatter(
-    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, const uint32_t* __restrict__ aux_in,
-    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t* __restrict__ aux_out,
-    const uint32_t* __restrict__ d_count, uint32_t n, int pass, int iota, const uint32_t* __restrict__ key_range,
-    const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ group_off, const uint32_t* __restrict__ totals) {
-    constexpr int TILE_N = SORT_THREADS * KPT;
-    constexpr int POOL_PAIRS = TILE_N * (CARRY ? 3 : 2);
-    constexpr int POOL_WORDS = POOL_PAIRS > WAVES * DSORT_MAX_BINS / 2 ? POOL_PAIRS : WAVES * DSORT_MAX_BINS / 2;
-    __shared__ uint32_t s_pool[POOL_WORDS];           // per-wave 16-bit digit counters, later the reorder buffers
-    __shared__ uint16_t s_local_excl[DSORT_MAX_BINS];  // first position of digit d inside the LDS-ordered tile
-    __shared__ uint32_t s_global_base[DSORT_MAX_BINS]; // + tile-local position = output address
-    __shared__ uint32_t s_tmp[WAVES];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const uint32_t count = device_count(d_count, n);
-    if (count == 0u) return;
-    const DSortPlan pl = dsort_plan(key_range, pass);
-    const uint32_t nb = pl.nb;
-    const uint32_t dpt = nb > (uint32_t)SORT_THREADS ? nb / SORT_THREADS : 1u;  // digits per thread: tid, tid + 256, ...
-    const uint32_t ntiles = (count + TILE_N - 1) / TILE_N;
-    const uint32_t gt = dsort_group_tiles(ntiles);
-    uint16_t* wh = reinterpret_cast<uint16_t*>(s_pool);  // [WAVES][nb]
-    uint32_t* s_keys = s_pool;
-    uint32_t* s_vals = s_pool + TILE_N;
-    uint32_t* s_aux = s_pool + 2 * TILE_N;
-    const uint32_t lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xFFFFFFFFu;
-    const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
-
-    for (uint32_t L = blockIdx.x; (L >> 3) < ((ntiles + 7u) >> 3); L += gridDim.x) {
-        uint32_t t;
-        if (!xcd_tile(L, ntiles, &t)) continue;  // block-uniform
-        const uint32_t tile_base = t * TILE_N;
-        const uint32_t valid = (count - tile_base) < (uint32_t)TILE_N ? (count - tile_base) : (uint32_t)TILE_N;
-        const uint32_t g = t / gt;
-
-        // ---- load (wave-striped: order = (wave, j, lane) = position order); keys become key - kmin, padding sorts last
-        uint32_t nk[KPT];
-        const uint32_t wave_base = tile_base + wave * (64 * KPT) + lane;
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t pos = wave_base + j * 64;
-            nk[j] = pos < count ? keys_in[pos] - pl.kmin : 0xFFFFFFFFu;
-        }
-        // output offset of digit `tid` = first position of the digit + digits in earlier groups + in earlier tiles of
-        // the group (issued early: needed only after the ranking; the digits tid + 256, ... of wider passes are loaded below)
-        uint32_t off0 = 0u;
-        if ((uint32_t)tid < nb) off0 = totals[tid] + tile_off[(size_t)t * nb + tid] + group_off[(size_t)g * nb + tid];
-        for (uint32_t i = tid; i < (uint32_t)WAVES * nb / 2u; i += SORT_THREADS) s_pool[i] = 0u;
-        __syncthreads();
-
-        // ---- rank inside the wave (see k_sort_scatter): ballots over the w digit bits, leaders bump the counters
-        uint32_t info[KPT];  // below | leader << 8 | count << 16 (count only on the leader lane, else 0)
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t d = (nk[j] >> pl.shift) & pl.mask;
-            uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
-            for (uint32_t bit = 0; bit < pl.w; ++bit) {
-                const uint32_t B = (uint32_t)(-(int32_t)((d >> bit) & 1u));  // all ones if the bit is set
-                const unsigned long long bal = __ballot(B != 0u);
-                mlo &= ~((uint32_t)bal ^ B);
-                mhi &= ~((uint32_t)(bal >> 32) ^ B);
-            }
-            const uint32_t below = (uint32_t)__popc(mlo & lt_lo) + (uint32_t)__popc(mhi & lt_hi);
-            const uint32_t leader = mlo ? (uint32_t)(__ffs((int)mlo) - 1) : 32u + (uint32_t)(__ffs((int)mhi) - 1);
-            const uint32_t cnt = (below == 0u) ? (uint32_t)(__popc(mlo) + __popc(mhi)) : 0u;  // below == 0 <=> leader
-            info[j] = below | (leader << 8) | (cnt << 16);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        uint32_t prev[KPT];
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t d = (nk[j] >> pl.shift) & pl.mask;
-            prev[j] = 0u;
-            if (info[j] >> 16) {
-                const uint32_t sft = (d & 1u) * 16u;
-                const uint32_t old = atomicAdd(&s_pool[((uint32_t)wave * nb + d) >> 1], (info[j] >> 16) << sft);
-                prev[j] = (old >> sft) & 0xFFFFu;
-            }
-        }
-        uint32_t rank[KPT];
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) rank[j] = __shfl(prev[j], (int)((info[j] >> 8) & 63u), 64) + (info[j] & 63u);
-        // payload (and companion) are loaded only now -- the ballots above are the register peak of this kernel -- and
-        // are in flight during the per-digit phase below (the scheduling barrier keeps the compiler from hoisting them)
-        __builtin_amdgcn_sched_barrier(0);
-        uint32_t val[KPT], aux[KPT];
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t pos = wave_base + j * 64;
-            val[j] = iota ? pos : (pos < count ? vals_in[pos] : 0u);
-            aux[j] = (CARRY && pos < count) ? aux_in[pos] : 0u;
-        }
-        __syncthreads();
-
-        // ---- per digit (thread tid owns digits tid, tid + 256, ...): prefix over the waves, count in the tile, position
-        // of the digit's run in the LDS-ordered tile and in the output.  One block scan per 256 digits, carried on.
-        uint32_t carry = 0u;
-        for (uint32_t j = 0; j < dpt; ++j) {
-            const uint32_t d = (uint32_t)tid + j * SORT_THREADS;
-            uint32_t off = off0;
-            if (j > 0u) off = totals[d] + tile_off[(size_t)t * nb + d] + group_off[(size_t)g * nb + d];
-            uint32_t tile_cnt = 0u;
-            if (d < nb) {
-#pragma unroll
-                for (int w = 0; w < WAVES; ++w) {
-                    const uint32_t c = wh[(uint32_t)w * nb + d];
-                    wh[(uint32_t)w * nb + d] = (uint16_t)tile_cnt;
-                    tile_cnt += c;
-                }
-            }
-            uint32_t total;
-            const uint32_t ex = block_exclusive_scan(tile_cnt, s_tmp, &total) + carry;
-            if (d < nb) {
-                s_local_excl[d] = (uint16_t)ex;
-                s_global_base[d] = off - ex;
-            }
-            carry += total;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {  // rank -> position in the LDS-ordered tile
-            const uint32_t d = (nk[j] >> pl.shift) & pl.mask;
-            rank[j] += (uint32_t)s_local_excl[d] + (uint32_t)wh[(uint32_t)wave * nb + d];
-        }
-        __syncthreads();  // the counters are dead: their LDS becomes the reorder buffers
-
-        // ---- reorder keys, payload (and companion) through LDS, write contiguous digit runs
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            s_keys[rank[j]] = nk[j];
-            s_vals[rank[j]] = val[j];
-            if (CARRY) s_aux[rank[j]] = aux[j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const uint32_t lp = k * SORT_THREADS + tid;
-            const uint32_t kk = s_keys[lp];
-            const uint32_t gpos = s_global_base[(kk >> pl.shift) & pl.mask] + lp;
-            if (lp < valid) {
-                keys_out[gpos] = kk + pl.kmin;
-                vals_out[gpos] = s_vals[lp];
-                if (CARRY) aux_out[gpos] = s_aux[lp];
-            }
         }
         __syncthreads();  // LDS is reused by the next tile
     }
@@ -1311,96 +855,6 @@ __global__ __launch_bounds__(FAT_THREADS) void k_dsort_fat(const FatSortArgs a, 
     }
 }
 
-// key range of arbitrary input (stand-alone sorter in depth mode): the same table K1 fills
-__global__ __launch_bounds__(SORT_THREADS) void k_key_minmax(const uint32_t* __restrict__ keys,
-                                                            const uint32_t* __restrict__ d_count, uint32_t n,
-                                                            uint32_t* __restrict__ key_range) {
-    __shared__ uint32_t s_max[WAVES], s_min_inv[WAVES];
-    const uint32_t count = device_count(d_count, n);
-    uint32_t kmax = 0u, kmin_inv = 0u;
-    bool any = false;
-    for (uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x; i < count; i += gridDim.x * SORT_THREADS) {
-        const uint32_t k = keys[i];
-        kmax = max(kmax, k);
-        kmin_inv = max(kmin_inv, ~k);
-        any = true;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
-        kmin_inv = max(kmin_inv, (uint32_t)__shfl_xor((int)kmin_inv, o, 64));
-    }
-    const bool wave_any = __ballot(any) != 0ull;
-    if ((threadIdx.x & 63) == 0) {
-        s_max[threadIdx.x >> 6] = wave_any ? kmax : 0u;
-        s_min_inv[threadIdx.x >> 6] = wave_any ? kmin_inv : 0u;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t a = 0u, b = 0u;
-        for (int w = 0; w < WAVES; ++w) {
-            a = max(a, s_max[w]);
-            b = max(b, s_min_inv[w]);
-        }
-        if (a | b) {
-            uint32_t* kr = key_range + (blockIdx.x & (KEY_RANGE_SLOTS - 1)) * KEY_RANGE_STRIDE;
-            atomicMax(kr, a);
-            atomicMax(kr + 1, b);
-        }
-    }
-}
-
-__global__ __launch_bounds__(SORT_THREADS) void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx,
-                                                            const uint32_t* __restrict__ d_count, uint32_t n,
-                                                            uint32_t* __restrict__ out) {
-    const uint32_t count = device_count(d_count, n);
-    for (uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x; i < count; i += gridDim.x * SORT_THREADS) out[i] = src[idx[i]];
-}
-
-// dst[i] = src[i] for i < count, up to three arrays at once (the stand-alone depth sort brings its result home)
-__global__ __launch_bounds__(SORT_THREADS) void k_copy_counted(const uint32_t* __restrict__ s0, uint32_t* __restrict__ d0,
-                                                              const uint32_t* __restrict__ s1, uint32_t* __restrict__ d1,
-                                                              const uint32_t* __restrict__ s2, uint32_t* __restrict__ d2,
-                                                              const uint32_t* __restrict__ d_count, uint32_t n) {
-    const uint32_t count = device_count(d_count, n);
-    for (uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x; i < count; i += gridDim.x * SORT_THREADS) {
-        d0[i] = s0[i];
-        d1[i] = s1[i];
-        if (s2) d2[i] = s2[i];
-    }
-}
-
-template <int KPT>
-int run_depth_sort(const DepthSortScratch& sc, uint32_t* keys, uint32_t* vals, uint32_t* aux, const uint32_t* d_count,
-                   uint32_t n, bool implicit_iota, uint32_t epoch, hipStream_t stream, KernelMarks* km) {
-    constexpr uint32_t TILE_N = SORT_THREADS * KPT;
-    const uint32_t tiles = sort_grid((n + TILE_N - 1) / TILE_N);
-    const size_t gw = (size_t)DSORT_MAX_GROUPS * DSORT_MAX_BINS;
-    uint32_t *kin = keys, *vin = vals, *ain = aux;
-    uint32_t *kout = sc.keys_alt, *vout = sc.vals_alt, *aout = sc.aux_alt;
-    for (int p = 0; p < DSORT_PASSES; ++p) {
-        hipLaunchKernelGGL(k_dsort_hist<KPT>, dim3(DSORT_MAX_GROUPS), dim3(DH_THREADS), 0, stream, kin, d_count, n, p,
-                           sc.key_range, sc.tile_off, sc.group_off + p * gw, sc.status + p * gw,
-                           sc.totals + (size_t)p * DSORT_MAX_BINS, sc.tickets + p, epoch, sc.error);
-        km_mark(km, "depth:k_dsort_hist");
-        const int iota = (implicit_iota && p == 0) ? 1 : 0;
-        if (aux)
-            hipLaunchKernelGGL((k_dsort_scatter<KPT, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, ain, kout,
-                               vout, aout, d_count, n, p, iota, sc.key_range, sc.tile_off, sc.group_off + p * gw,
-                               sc.totals + (size_t)p * DSORT_MAX_BINS);
-        else
-            hipLaunchKernelGGL((k_dsort_scatter<KPT, false>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
-                               (const uint32_t*)nullptr, kout, vout, (uint32_t*)nullptr, d_count, n, p, iota, sc.key_range,
-                               sc.tile_off, sc.group_off + p * gw, sc.totals + (size_t)p * DSORT_MAX_BINS);
-        km_mark(km, "depth:k_dsort_scatter");
-        WS_HIP(hipGetLastError());
-        uint32_t* t0 = kin; kin = kout; kout = t0;
-        uint32_t* t1 = vin; vin = vout; vout = t1;
-        uint32_t* t2 = ain; ain = aout; aout = t2;
-    }
-    return WS_OK;
-}
-
 }  // namespace
 
 // Grid cap of the tile-strided kernels: 8 workgroups per CU on a 256-CU part; enough to fill the chip at any
@@ -1412,25 +866,6 @@ uint32_t sort_grid(uint32_t tiles) {
 }
 
 uint32_t sort_tile_size(uint32_t n) { return n <= SORT_SMALL_MAX ? SORT_THREADS * SORT_KPT_SMALL : SORT_TILE; }
-
-size_t depth_sort_tile_off_words(uint32_t cap) {
-    const uint32_t small_n = cap < SORT_SMALL_MAX ? cap : SORT_SMALL_MAX;
-    const uint32_t small_tiles = (small_n + SORT_THREADS * SORT_KPT_SMALL - 1) / (SORT_THREADS * SORT_KPT_SMALL);
-    const uint32_t big_tiles = (cap + SORT_TILE - 1) / SORT_TILE;
-    const uint32_t tiles = (small_tiles > big_tiles ? small_tiles : big_tiles) + 1u;
-    return (size_t)tiles * DSORT_MAX_BINS;
-}
-size_t depth_sort_group_words() { return (size_t)DSORT_PASSES * DSORT_MAX_GROUPS * DSORT_MAX_BINS; }
-
-int launch_depth_sort(const DepthSortScratch& sc, uint32_t* keys, uint32_t* vals, uint32_t* aux, const uint32_t* d_count,
-                      uint32_t n, bool implicit_iota, uint32_t epoch, hipStream_t stream, KernelMarks* km) {
-    if (n == 0) return WS_OK;
-    if (n > sc.cap) return fail(WS_ERR_INVALID, "depth sort: n exceeds the scratch capacity");
-    if (aux && !sc.aux_alt) return fail(WS_ERR_INVALID, "depth sort: companion values without a companion scratch buffer");
-    if (sort_tile_size(n) == SORT_TILE)
-        return run_depth_sort<SORT_KPT>(sc, keys, vals, aux, d_count, n, implicit_iota, epoch, stream, km);
-    return run_depth_sort<SORT_KPT_SMALL>(sc, keys, vals, aux, d_count, n, implicit_iota, epoch, stream, km);
-}
 
 size_t fat_sort_status_words() { return (size_t)4 * FAT_MAX_GRID * RADIX; }
 
@@ -1498,35 +933,6 @@ int launch_depth_sort_fat(const FatSortScratch& sc, uint32_t* keys, uint32_t* va
     return WS_OK;
 }
 
-int launch_copy_counted(const uint32_t* s0, uint32_t* d0, const uint32_t* s1, uint32_t* d1, const uint32_t* s2, uint32_t* d2,
-                        const uint32_t* d_count, uint32_t n, hipStream_t stream) {
-    if (n == 0) return WS_OK;
-    uint32_t blocks = (n + SORT_THREADS * 4 - 1) / (SORT_THREADS * 4);
-    if (blocks > 2048u) blocks = 2048u;
-    hipLaunchKernelGGL(k_copy_counted, dim3(blocks), dim3(SORT_THREADS), 0, stream, s0, d0, s1, d1, s2, d2, d_count, n);
-    WS_HIP(hipGetLastError());
-    return WS_OK;
-}
-
-int launch_gather_u32(const uint32_t* src, const uint32_t* idx, const uint32_t* d_count, uint32_t n, uint32_t* out,
-                      hipStream_t stream) {
-    if (n == 0) return WS_OK;
-    uint32_t blocks = (n + SORT_THREADS * 4 - 1) / (SORT_THREADS * 4);
-    if (blocks > 2048u) blocks = 2048u;
-    hipLaunchKernelGGL(k_gather_u32, dim3(blocks), dim3(SORT_THREADS), 0, stream, src, idx, d_count, n, out);
-    WS_HIP(hipGetLastError());
-    return WS_OK;
-}
-
-int launch_key_minmax(const uint32_t* keys, const uint32_t* d_count, uint32_t n, uint32_t* key_range, hipStream_t stream) {
-    if (n == 0) return WS_OK;
-    uint32_t blocks = (n + SORT_THREADS * 16 - 1) / (SORT_THREADS * 16);
-    if (blocks > 1024u) blocks = 1024u;
-    hipLaunchKernelGGL(k_key_minmax, dim3(blocks), dim3(SORT_THREADS), 0, stream, keys, d_count, n, key_range);
-    WS_HIP(hipGetLastError());
-    return WS_OK;
-}
-
 int launch_tile_sort_wide(const SortScratch& sc, const uint32_t* keys16, const uint32_t* vals, const uint32_t* d_count,
                           uint32_t n, int bits, hipStream_t stream, KernelMarks* km, uint2* ranges, uint32_t nranges) {
     if (n == 0) return WS_OK;
@@ -1557,24 +963,18 @@ int launch_tile_sort_wide(const SortScratch& sc, const uint32_t* keys16, const u
 }
 
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
-                      int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
-                      uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km,
-                      const char* tag, uint2* ranges, uint32_t nranges, int digit_bits, bool key16, uint32_t* aux,
-                      uint32_t* aux_alt) {
+                      int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, hipStream_t stream,
+                      uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km, const char* tag, uint2* ranges,
+                      uint32_t nranges, int digit_bits, bool key16, uint32_t* aux, uint32_t* aux_alt) {
     // labels of the per-kernel timers: "<tag>k_sort_..." with tag = "depth:" / "tiles:"
     const bool depth = tag && tag[0] == 'd';
-    static const char* const N_DEPTH[4] = {"depth:k_sort_tile_hist", "depth:k_sort_col_scan", "depth:k_sort_scatter",
-                                           "depth:k_sort_hist"};
-    static const char* const N_TILES[4] = {"tiles:k_sort_tile_hist", "tiles:k_sort_col_scan", "tiles:k_sort_scatter",
-                                           "tiles:k_sort_hist"};
+    static const char* const N_DEPTH[3] = {"depth:k_sort_tile_hist", "depth:k_sort_col_scan", "depth:k_sort_scatter"};
+    static const char* const N_TILES[3] = {"tiles:k_sort_tile_hist", "tiles:k_sort_col_scan", "tiles:k_sort_scatter"};
     const char* const* names = depth ? N_DEPTH : N_TILES;
     if (out_keys) *out_keys = keys;
     if (out_vals) *out_vals = vals;
     if (n == 0) return WS_OK;
     if (n > sc.cap) return fail(WS_ERR_INVALID, "sort: n exceeds the scratch capacity");
-    if (algo == 1) digit_bits = RADIX_BITS;
-    if (algo == 1 && key16) return fail(WS_ERR_INVALID, "sort: 16-bit keys are a feature of the scan path");
-    if (algo == 1 && aux) return fail(WS_ERR_INVALID, "sort: companion values are a feature of the scan path");
     if (aux && (ranges || !aux_alt)) return fail(WS_ERR_INVALID, "sort: companion values need a scratch partner and no range recording");
     if (key16 && end_bit > 16) return fail(WS_ERR_INVALID, "sort: 16-bit keys with more than 16 key bits");
     if (key16 && aux) return fail(WS_ERR_INVALID, "sort: companion values travel with 32-bit keys only");
@@ -1589,58 +989,24 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
     uint32_t* vin = vals;
     uint32_t* kout = sc.keys_alt;
     uint32_t* vout = sc.vals_alt;
-
-    if (algo != 1) {
-        int rc;
-        const bool big = sort_tile_size(n) == SORT_TILE;
+    int rc;
+    const bool big = sort_tile_size(n) == SORT_TILE;
 #define WS_RUN_SCAN(KPT_, BITS_)                                                                                       \
     rc = key16 ? run_passes_scan<KPT_, BITS_, true>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass,   \
-                                                    implicit_iota, first_tile_hist_ready, epoch, stream, &kin, &vin, km,   \
-                                                    names, ranges, nranges)                                                \
+                                                    implicit_iota, first_tile_hist_ready, stream, &kin, &vin, km, names,   \
+                                                    ranges, nranges)                                                       \
                : run_passes_scan<KPT_, BITS_, false>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass,  \
-                                                     implicit_iota, first_tile_hist_ready, epoch, stream, &kin, &vin, km,  \
-                                                     names, ranges, nranges)
-        if (digit_bits == 8) {
-            if (big) WS_RUN_SCAN(SORT_KPT, 8); else WS_RUN_SCAN(SORT_KPT_SMALL, 8);
-        } else if (digit_bits == 7) {
-            if (big) WS_RUN_SCAN(SORT_KPT, 7); else WS_RUN_SCAN(SORT_KPT_SMALL, 7);
-        } else {
-            if (big) WS_RUN_SCAN(SORT_KPT, 6); else WS_RUN_SCAN(SORT_KPT_SMALL, 6);
-        }
-#undef WS_RUN_SCAN
-        if (rc) return rc;
+                                                     implicit_iota, first_tile_hist_ready, stream, &kin, &vin, km, names,  \
+                                                     ranges, nranges)
+    if (digit_bits == 8) {
+        if (big) WS_RUN_SCAN(SORT_KPT, 8); else WS_RUN_SCAN(SORT_KPT_SMALL, 8);
+    } else if (digit_bits == 7) {
+        if (big) WS_RUN_SCAN(SORT_KPT, 7); else WS_RUN_SCAN(SORT_KPT_SMALL, 7);
     } else {
-        const uint32_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
-        uint32_t hist_blocks = (n / 4 + SORT_THREADS * 8 - 1) / (SORT_THREADS * 8);
-        if (hist_blocks < 1) hist_blocks = 1;
-        if (hist_blocks > 1024) hist_blocks = 1024;
-        hipLaunchKernelGGL(k_sort_hist, dim3(hist_blocks), dim3(SORT_THREADS), 0, stream, kin, d_count, n, begin_bit,
-                           npass, sc.hist);
-        km_mark(km, names[3]);
-        WS_HIP(hipGetLastError());
-        for (int p = 0; p < npass; ++p) {
-            const int shift = begin_bit + p * RADIX_BITS;
-            const int iota = (implicit_iota && p == 0) ? 1 : 0;
-            if (ranges && p == npass - 1)
-                hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, true, RADIX_BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
-                                   vin, kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota, sc.hist + p * RADIX,
-                                   sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
-                                   0u, epoch, sc.error, ranges, nranges);
-            else
-                hipLaunchKernelGGL((k_sort_scatter<true, SORT_KPT, false, RADIX_BITS>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
-                                   vin, kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota, sc.hist + p * RADIX,
-                                   sc.status + (size_t)p * sc.tiles * RADIX, sc.tickets + p, (const uint32_t*)nullptr,
-                                   0u, epoch, sc.error, (uint2*)nullptr, 0u);
-            km_mark(km, names[2]);
-            WS_HIP(hipGetLastError());
-            uint32_t* tk = kin;
-            kin = kout;
-            kout = tk;
-            uint32_t* tv = vin;
-            vin = vout;
-            vout = tv;
-        }
+        if (big) WS_RUN_SCAN(SORT_KPT, 6); else WS_RUN_SCAN(SORT_KPT_SMALL, 6);
     }
+#undef WS_RUN_SCAN
+    if (rc) return rc;
     if (out_keys) *out_keys = kin;
     if (out_vals) *out_vals = vin;
     return WS_OK;

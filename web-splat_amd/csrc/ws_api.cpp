@@ -96,14 +96,12 @@ struct SorterZero {
     uint32_t error;
     uint32_t _pad[3];
     uint32_t hist[4 * RADIX];
-    uint32_t key_range[KEY_RANGE_SLOTS * KEY_RANGE_STRIDE];  // depth mode: filled by k_key_minmax
     uint32_t fat_barrier[9 * 16];                            // single-launch depth sort: barrier state
 };
 
 struct ws_sorter {
     ws_context* ctx = nullptr;
     SortScratch sc;
-    DepthSortScratch ds;   // ws_sorter_sort_depth
     FatSortScratch fat;    // ws_sorter_sort_depth of a context whose depth sort is the fat-tile one-sweep (status: own allocation)
     uint32_t* aux_alt = nullptr;
     SorterZero* zero = nullptr;
@@ -136,8 +134,6 @@ struct ws_renderer {
     uint2* tile_ranges = nullptr;    // inside the zero arena
     FrameCounters* counters = nullptr;  // = &zero->counters
     SortScratch sort_depth, sort_tiles;
-    DepthSortScratch dsort;          // range-adaptive three-pass depth sort (WS_DEPTH_SORT=adaptive only; the default is the
-                                     // generic 4 x 8-bit sorter, sort_depth); allocated only when that path is selected
     FatSortScratch fat;              // fat-tile one-sweep depth sort (WS_DEPTH_SORT=onesweep | coop): chunk-count rows
     uint32_t* fp_sorted = nullptr;  // where the last frame's draw-ordered footprint words are
     int footprint_mode = FP_RECT_PACKED;  // of the current scratch (chosen by the viewport and WS_FOOTPRINT)
@@ -190,15 +186,13 @@ static void free_sort_scratch(SortScratch& sc, bool own_alt) {
         dfree(sc.keys_alt);
         dfree(sc.vals_alt);
     }
-    dfree(sc.status);
     dfree(sc.tile_sums);
     dfree(sc.wide_hist);
     sc = SortScratch();
 }
 
-// status words are zeroed ONCE here; afterwards the epoch tag makes stale words invisible (lookback.h)
 // wide_bins != 0: also room for the [tiles][wide_bins] count rows of the single-pass tile-id sort (launch_tile_sort_wide)
-static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, bool one_sweep, uint32_t wide_bins = 0) {
+static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, uint32_t wide_bins = 0) {
     sc.cap = cap;
     sc.tiles = (cap + SORT_TILE - 1) / SORT_TILE;
     if (sc.tiles == 0) sc.tiles = 1;
@@ -207,10 +201,6 @@ static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, bool 
         if ((rc = dmalloc(&sc.keys_alt, (size_t)cap + 4))) return rc;
         if ((rc = dmalloc(&sc.vals_alt, (size_t)cap + 4))) return rc;
     }
-    // look-back words of the one-sweep path (WS_SORT_ALGO=1): 8 KiB per 2048 pairs, only when that path is selected
-    const size_t status_words = one_sweep ? 4 * (size_t)sc.tiles * RADIX : 1;
-    if ((rc = dmalloc(&sc.status, status_words))) return rc;
-    WS_HIP(hipMemset(sc.status, 0, status_words * sizeof(uint64_t)));
     const uint32_t small_n = std::min<uint32_t>(cap, SORT_SMALL_MAX);
     const uint32_t small_tiles = (small_n + SORT_THREADS * SORT_KPT_SMALL - 1) / (SORT_THREADS * SORT_KPT_SMALL);
     sc.tiles_cap = std::max<uint32_t>(std::max<uint32_t>(small_tiles, sc.tiles), 1u);
@@ -246,11 +236,6 @@ static void renderer_free_scratch(ws_renderer* r) {
     dfree(r->vals_b);
     dfree(r->fpw_a);
     dfree(r->fpw_b);
-    dfree(r->dsort.tile_off);
-    dfree(r->dsort.group_off);
-    dfree(r->dsort.status);
-    dfree(r->dsort.totals);
-    r->dsort = DepthSortScratch();
     dfree(r->fat.status);
     r->fat = FatSortScratch();
     dfree(r->src_index);
@@ -326,7 +311,7 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     WS_HIP(hipMemset(r->zero, 0, r->zero_bytes));
     r->counters = &r->zero->counters;
     r->tile_ranges = reinterpret_cast<uint2*>(reinterpret_cast<char*>(r->zero) + sizeof(FrameZero));
-    if ((rc = alloc_sort_scratch(r->sort_depth, n ? n : 1, false, r->ctx->sort_algo == 1))) return rc;
+    if ((rc = alloc_sort_scratch(r->sort_depth, n ? n : 1, false))) return rc;
     r->sort_depth.keys_alt = r->keys_b;
     r->sort_depth.vals_alt = r->vals_b;
     r->sort_depth.hist = r->zero->depth_hist;
@@ -334,37 +319,16 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     uint32_t wide_bins = 0;
     {
         const uint32_t ntiles = r->tiles_x * r->tiles_y;
-        if (r->ctx->tile_sort_wide && r->ctx->sort_algo != 1 && ntiles > 64u && ntiles <= (uint32_t)TILE_SORT_WIDE_MAX_BINS &&
+        if (r->ctx->tile_sort_wide && ntiles > 64u && ntiles <= (uint32_t)TILE_SORT_WIDE_MAX_BINS &&
             sort_tile_size(r->entry_cap) == (uint32_t)EMIT_TILE) {
             wide_bins = 128u;
             while (wide_bins < ntiles) wide_bins <<= 1;
         }
     }
-    if ((rc = alloc_sort_scratch(r->sort_tiles, r->entry_cap, false, r->ctx->sort_algo == 1, wide_bins))) return rc;
+    if ((rc = alloc_sort_scratch(r->sort_tiles, r->entry_cap, false, wide_bins))) return rc;
     r->sort_tiles.keys_alt = r->ekeys_b;
     r->sort_tiles.vals_alt = r->evals_b;
     r->sort_tiles.hist = r->zero->tile_hist;
-    r->sort_depth.tickets = r->counters->sort_ticket;
-    r->sort_tiles.tickets = r->counters->sort_ticket + 4;
-    r->sort_depth.error = &r->counters->overflow;
-    r->sort_tiles.error = &r->counters->overflow;
-    if (r->ctx->depth_sort_mode == DS_ADAPTIVE) {  // scratch of the cross-check depth sort: per-tile / per-group digit offsets,
-                                        // look-back words (zeroed once; epoch-tagged afterwards)
-        DepthSortScratch& ds = r->dsort;
-        ds.cap = n ? n : 1;
-        const size_t gw = depth_sort_group_words();
-        if ((rc = dmalloc(&ds.tile_off, depth_sort_tile_off_words(ds.cap)))) return rc;
-        if ((rc = dmalloc(&ds.group_off, gw))) return rc;
-        if ((rc = dmalloc(&ds.status, gw))) return rc;
-        if ((rc = dmalloc(&ds.totals, (size_t)DSORT_PASSES * DSORT_MAX_BINS))) return rc;
-        WS_HIP(hipMemset(ds.status, 0, gw * sizeof(uint64_t)));
-        ds.keys_alt = r->keys_b;
-        ds.vals_alt = r->vals_b;
-        ds.aux_alt = r->fpw_b;
-        ds.key_range = r->zero->key_range;
-        ds.tickets = r->counters->sort_ticket;  // [0..2]; the tile sort uses [4..7]
-        ds.error = &r->counters->overflow;
-    }
     if (r->ctx->depth_sort_mode == DS_ONESWEEP || r->ctx->depth_sort_mode == DS_COOP) {
         FatSortScratch& fs = r->fat;
         fs.cap = n ? n : 1;
@@ -411,7 +375,6 @@ int ws_context_create(int hip_device, ws_context** out) {
     if (!ctx) return fail(WS_ERR_OOM, "ws_context_create: host allocation failed");
     ctx->device = hip_device;
     WS_HIP(hipGetDeviceProperties(&ctx->props, hip_device));
-    ctx->sort_algo = env_int("WS_SORT_ALGO", 0);
     {   // WS_TILE_SORT=wide: ONE counting pass over the whole tile id up to 2048 binning tiles instead of two digit passes.
         // Measured (profiles/r03/tile_sort_wide_ab_v20_summary.txt): one frame at a time +1..+5 % (three launches fewer), with
         // frames in flight -0.5..-5 %: at 2048 bins the [sort tile][bin] count rows are as many bytes as the entries themselves.
@@ -420,13 +383,11 @@ int ws_context_create(int hip_device, ws_context** out) {
     }
     ctx->depth_sort_mode = WS_DEPTH_SORT_DEFAULT;
     if (const char* ds = std::getenv("WS_DEPTH_SORT")) {
-        if (std::strcmp(ds, "adaptive") == 0) ctx->depth_sort_mode = DS_ADAPTIVE;
-        else if (std::strcmp(ds, "onesweep") == 0) ctx->depth_sort_mode = DS_ONESWEEP;
+        if (std::strcmp(ds, "onesweep") == 0) ctx->depth_sort_mode = DS_ONESWEEP;
         else if (std::strcmp(ds, "coop") == 0) ctx->depth_sort_mode = DS_COOP;
         else if (std::strcmp(ds, "scan") == 0 || std::strcmp(ds, "classic") == 0) ctx->depth_sort_mode = DS_SCAN;
     }
     ctx->dsort_fat_grid = env_int("WS_DSORT_FAT_GRID", 0);
-    if (ctx->sort_algo == 1) ctx->depth_sort_mode = DS_SCAN;  // the one-sweep cross-check path is a generic-sorter path
     ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
     ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
@@ -893,8 +854,8 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
         return WS_OK;
     }
     // depth sort: V (key, store index) pairs, values start as iota (preprocess.wgsl:274), the splat's footprint word
-    // (packed tile rectangle, or tile count) rides along as a companion value.  Default: the generic 4 x 8-bit sorter (GPURSSorter's shape);
-    // WS_DEPTH_SORT=adaptive: three range-adaptive digit passes (launch_depth_sort; measured: no faster).
+    // (packed tile rectangle, or tile count) rides along as a companion value.  Default: the generic 4 x 8-bit sorter
+    // (GPURSSorter's shape); WS_DEPTH_SORT=onesweep | coop: the fat-tile one-sweep (measured variants).
     const bool fat_sort = (r->ctx->depth_sort_mode == DS_ONESWEEP || r->ctx->depth_sort_mode == DS_COOP) && r->fat.status &&
                           fat_sort_grid(pc->num_points, r->ctx->num_cus, r->fat.grid_request) != 0u;
     if (fat_sort) {
@@ -905,29 +866,15 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
         r->sorted_idx = r->vals_a;
         r->sorted_keys = r->keys_a;
         r->fp_sorted = r->fpw_a;
-    } else if (!(r->ctx->depth_sort_mode == DS_ADAPTIVE)) {
-        const bool carry = r->ctx->sort_algo != 1;  // (the one-sweep cross-check path gathers the footprint words afterwards)
+    } else {
         uint32_t *sk = nullptr, *sv = nullptr;
         if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
-                                    true, false, r->ctx->sort_algo, r->epoch, stream, &sk, &sv, km, "depth:", nullptr, 0,
-                                    RADIX_BITS, false, carry ? r->fpw_a : nullptr, carry ? r->fpw_b : nullptr)))
+                                    true, false, stream, &sk, &sv, km, "depth:", nullptr, 0, RADIX_BITS, false, r->fpw_a,
+                                    r->fpw_b)))
             return rc;
         r->sorted_idx = sv;
         r->sorted_keys = sk;
-        if (carry) {
-            r->fp_sorted = (sv == r->vals_a) ? r->fpw_a : r->fpw_b;  // where the payload went
-        } else {
-            if ((rc = launch_gather_u32(r->fpw_a, sv, &r->counters->num_visible, pc->num_points, r->fpw_b, stream))) return rc;
-            km_mark(km, "k_gather_footprints");
-            r->fp_sorted = r->fpw_b;
-        }
-    } else {
-        if ((rc = launch_depth_sort(r->dsort, r->keys_a, r->vals_a, r->fpw_a, &r->counters->num_visible, pc->num_points,
-                                    true, r->epoch, stream, km)))
-            return rc;
-        r->sorted_idx = r->vals_b;    // three passes: A -> B -> A -> B
-        r->sorted_keys = r->keys_b;
-        r->fp_sorted = r->fpw_b;
+        r->fp_sorted = (sv == r->vals_a) ? r->fpw_a : r->fpw_b;  // where the payload went
     }
     if (r->timers) WS_HIP(hipEventRecord(r->ev[2], stream));
     if (cut == 2) {  // analysis only (WS_DEBUG_CUT): the image is NOT produced
@@ -960,7 +907,7 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     bb.tiles_y = r->tiles_y;
     // the emit kernel cuts the entry list into the same 4096-entry tiles the radix sort uses, so it can hand
     // the sort the digit counts of its first pass for free
-    const bool fused_hist = r->ctx->sort_algo != 1 && sort_tile_size(r->entry_cap) == (uint32_t)EMIT_TILE;
+    const bool fused_hist = sort_tile_size(r->entry_cap) == (uint32_t)EMIT_TILE;
     bb.tile_hist = fused_hist ? r->sort_tiles.tile_sums : nullptr;
     bb.tile_hist_pitch = r->sort_tiles.tiles_cap;
     // The tile-id sort is "segmented": only the bits a tile id can have take part, split evenly over the passes
@@ -976,10 +923,6 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     // a workgroup holds a handful of tiles.
     if (tile_passes == 1 && ntiles > 64) digit_bits = 6;
     if (digit_bits < 6) digit_bits = 6;
-    if (r->ctx->sort_algo == 1) {  // one-sweep cross-check path: 8-bit digits
-        digit_bits = RADIX_BITS;
-        tile_bits = tile_passes * RADIX_BITS;
-    }
     bb.tile_hist_mask = (1u << digit_bits) - 1u;
     // ONE counting pass over the whole tile id when the scratch was sized for it (at most 2048 binning tiles): the emit
     // kernel leaves [sort tile][bin] counts, a column scan and a scatter follow -- two launches instead of five, the
@@ -990,7 +933,7 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     bb.tile_hist_wide = wide_sort ? 1 : 0;
     if (wide_sort) bb.tile_hist_pitch = 1u << wide_bits;
     // tile ids fit 16 bits up to 65534 tiles (4096 x 4080 px): the key arrays of the tile sort then hold uint16_t
-    const bool key16 = r->ctx->sort_algo != 1 && ntiles < 65535u;
+    const bool key16 = ntiles < 65535u;
     bb.key16 = key16 ? 1 : 0;
     if ((rc = launch_bin_prefix(bb, stream))) return rc;
     km_mark(km, "k_bin_prefix");
@@ -1009,7 +952,7 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
             return rc;
         evv = r->sort_tiles.vals_alt;
     } else if ((rc = launch_sort_pairs(r->sort_tiles, r->ekeys_a, r->evals_a, &r->counters->num_entries, r->entry_cap, 0,
-                                       tile_bits, false, fused_hist, r->ctx->sort_algo, r->epoch, stream, &ek, &evv, km,
+                                       tile_bits, false, fused_hist, stream, &ek, &evv, km,
                                        "tiles:", r->tile_ranges, ntiles, digit_bits, key16)))
         return rc;
     r->entries_sorted = evv;  // the last pass wrote the per-tile ranges instead of the sorted tile ids
@@ -1092,7 +1035,6 @@ static int prepare_setup(ws_renderer* r, const ws_pointcloud* pc, const ws_splat
     kb.splats = r->splats;
     kb.keys = r->keys_a;
     kb.footprints = r->fpw_a;
-    kb.key_range = r->zero->key_range;
     kb.src_index = r->capture ? r->src_index : nullptr;
     kb.block_status = r->k1_status;
     kb.counters = r->counters;
@@ -1101,12 +1043,7 @@ static int prepare_setup(ws_renderer* r, const ws_pointcloud* pc, const ws_splat
     if (++r->epoch == 0) {
         WS_HIP(hipMemsetAsync(r->k1_status, 0, ((size_t)preprocess_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
         WS_HIP(hipMemsetAsync(r->bin_status, 0, ((size_t)bin_prefix_blocks(pc->num_points) + 1) * sizeof(uint64_t), stream));
-        if (r->dsort.status) WS_HIP(hipMemsetAsync(r->dsort.status, 0, depth_sort_group_words() * sizeof(uint64_t), stream));
         if (r->fat.status) WS_HIP(hipMemsetAsync(r->fat.status, 0, fat_sort_status_words() * sizeof(uint64_t), stream));
-        if (r->ctx->sort_algo == 1) {
-            WS_HIP(hipMemsetAsync(r->sort_depth.status, 0, 4 * (size_t)r->sort_depth.tiles * RADIX * sizeof(uint64_t), stream));
-            WS_HIP(hipMemsetAsync(r->sort_tiles.status, 0, 4 * (size_t)r->sort_tiles.tiles * RADIX * sizeof(uint64_t), stream));
-        }
         r->epoch = 1;
     }
     kp.epoch = r->epoch;
@@ -1125,7 +1062,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     // A captured frame graph (one hipGraphLaunch + one kernel-argument update instead of 22 launches + a memset on the host)
     // when the caller gave a real stream and no per-launch instrumentation is on.  The legacy NULL stream cannot be captured.
     const bool use_graph = r->ctx->use_graph && stream != nullptr && !r->marks.active && !r->timers && !r->capture &&
-                           cut_mode == 0 && r->ctx->sort_algo == 0 && !(r->ctx->depth_sort_mode == DS_ADAPTIVE);
+                           cut_mode == 0;
     if (!use_graph) return enqueue_frame(r, pc, kp, kb, stream);
     ws_renderer::FrameGraph& g = r->fg;
     if (!(g.valid && g.pc == pc && g.generation == r->scratch_generation)) {
@@ -1206,7 +1143,7 @@ int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_point
     for (uint32_t i = 0; i < n; ++i) {
         ws_renderer* r = rs[i];
         if (!r || !streams[i] || r->ctx != rs[0]->ctx || r->compressed != pc->compressed || r->timers || r->marks.active ||
-            r->capture || r->ctx->use_graph || r->ctx->debug_cut || r->ctx->sort_algo != 0 || (r->ctx->depth_sort_mode == DS_ADAPTIVE))
+            r->capture || r->ctx->use_graph || r->ctx->debug_cut)
             return WS_ERR_UNSUPPORTED;
         for (uint32_t j = 0; j < i; ++j)
             if (rs[j] == r || streams[j] == streams[i]) return WS_ERR_UNSUPPORTED;
@@ -1503,30 +1440,13 @@ int ws_sorter_create(ws_context* ctx, uint32_t max_n, ws_sorter** out) {
     ws_sorter* s = new (std::nothrow) ws_sorter();
     if (!s) return fail(WS_ERR_OOM, "ws_sorter_create: host allocation failed");
     s->ctx = ctx;
-    int rc = alloc_sort_scratch(s->sc, max_n, true, ctx->sort_algo == 1);
+    int rc = alloc_sort_scratch(s->sc, max_n, true);
     if (rc == WS_OK) rc = dmalloc(&s->zero, 1);
+    if (rc == WS_OK) rc = dmalloc(&s->aux_alt, (size_t)max_n + 4);
     if (rc == WS_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(WS_ERR_HIP, "ws_sorter_create: device sync failed");
     if (rc == WS_OK) {
-        s->sc.tickets = s->zero->tickets;
-        s->sc.error = &s->zero->error;
         s->sc.hist = s->zero->hist;
-        DepthSortScratch& ds = s->ds;
-        ds.cap = max_n;
-        const size_t gw = depth_sort_group_words();
-        rc = dmalloc(&ds.tile_off, depth_sort_tile_off_words(max_n));
-        if (rc == WS_OK) rc = dmalloc(&ds.group_off, gw);
-        if (rc == WS_OK) rc = dmalloc(&ds.status, gw);
-        if (rc == WS_OK) rc = dmalloc(&ds.totals, (size_t)DSORT_PASSES * DSORT_MAX_BINS);
-        if (rc == WS_OK) rc = dmalloc(&s->aux_alt, (size_t)max_n + 4);
-        if (rc == WS_OK && (hipMemset(ds.status, 0, gw * sizeof(uint64_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess))
-            rc = fail(WS_ERR_HIP, "ws_sorter_create: look-back word initialisation failed");
-        ds.keys_alt = s->sc.keys_alt;
-        ds.vals_alt = s->sc.vals_alt;
-        ds.aux_alt = s->aux_alt;
-        ds.key_range = s->zero->key_range;
-        ds.tickets = s->zero->tickets;
-        ds.error = &s->zero->error;
-        if (rc == WS_OK && (ctx->depth_sort_mode == DS_ONESWEEP || ctx->depth_sort_mode == DS_COOP)) {
+        if (ctx->depth_sort_mode == DS_ONESWEEP || ctx->depth_sort_mode == DS_COOP) {
             FatSortScratch& fs = s->fat;
             fs.cap = max_n;
             rc = dmalloc(&fs.status, fat_sort_status_words());
@@ -1555,10 +1475,6 @@ void ws_sorter_destroy(ws_sorter* s) {
     if (!s) return;
     (void)hipDeviceSynchronize();
     dfree(s->zero);
-    dfree(s->ds.tile_off);
-    dfree(s->ds.group_off);
-    dfree(s->ds.status);
-    dfree(s->ds.totals);
     dfree(s->aux_alt);
     dfree(s->fat.status);
     free_sort_scratch(s->sc, true);
@@ -1569,52 +1485,42 @@ int ws_sorter_sort(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, const ui
                    void* stream_v) {
     if (!s || !d_keys || !d_payload) return fail(WS_ERR_INVALID, "ws_sorter_sort: null argument");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    if (++s->epoch == 0) {
-        if (s->ctx->sort_algo == 1)
-            WS_HIP(hipMemsetAsync(s->sc.status, 0, 4 * (size_t)s->sc.tiles * RADIX * sizeof(uint64_t), stream));
-        s->epoch = 1;
-    }
     WS_HIP(hipMemsetAsync(s->zero, 0, sizeof(SorterZero), stream));
     uint32_t *ok = nullptr, *ov = nullptr;
-    int rc = launch_sort_pairs(s->sc, d_keys, d_payload, d_count, n, 0, 32, false, false, s->ctx->sort_algo, s->epoch,
-                               stream, &ok, &ov);
+    int rc = launch_sort_pairs(s->sc, d_keys, d_payload, d_count, n, 0, 32, false, false, stream, &ok, &ov);
     if (rc) return rc;
     if (ok != d_keys) return fail(WS_ERR_STATE, "ws_sorter_sort: internal ping-pong parity error");
     return WS_OK;
 }
 
 // The renderer's depth sort as a stand-alone call: the same result as ws_sorter_sort (stable ascending on the full
-// 32-bit keys), by three digit passes whose width follows the range of the keys (sort.hip); `d_aux` (may be null)
-// is a 4-byte companion value that travels with the payload.  Keys, payload and companion are sorted in place.
+// 32-bit keys) by the kernels a frame's depth sort runs -- the generic sorter with a companion value, or, in a context
+// created with WS_DEPTH_SORT=onesweep | coop and for inputs within its capacity, the fat-tile one-sweep (sort.hip);
+// `d_aux` (may be null) is a 4-byte companion value that travels with the payload.  Four passes: keys, payload and
+// companion are sorted in place.
 int ws_sorter_sort_depth(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, uint32_t* d_aux, const uint32_t* d_count,
                          uint32_t n, void* stream_v) {
     if (!s || !d_keys || !d_payload) return fail(WS_ERR_INVALID, "ws_sorter_sort_depth: null argument");
-    if (n > s->ds.cap) return fail(WS_ERR_INVALID, "ws_sorter_sort_depth: n exceeds the sorter's capacity");
-    // k_dsort_hist reads the keys 16 bytes at a time: the same alignment ws_sorter_sort asks for
+    if (n > s->sc.cap) return fail(WS_ERR_INVALID, "ws_sorter_sort_depth: n exceeds the sorter's capacity");
+    // the histogram kernels read the keys 16 bytes at a time: the same alignment ws_sorter_sort asks for
     if ((reinterpret_cast<uintptr_t>(d_keys) & 15u) != 0)
         return fail(WS_ERR_INVALID, "ws_sorter_sort_depth: keys must be 16-byte aligned");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    if (++s->epoch == 0) {
-        WS_HIP(hipMemsetAsync(s->ds.status, 0, depth_sort_group_words() * sizeof(uint64_t), stream));
+    if (++s->epoch == 0) {  // epoch-tagged count rows of the fat-tile form: re-zeroed on wrap-around
         if (s->fat.status) WS_HIP(hipMemsetAsync(s->fat.status, 0, fat_sort_status_words() * sizeof(uint64_t), stream));
-        if (s->ctx->sort_algo == 1)
-            WS_HIP(hipMemsetAsync(s->sc.status, 0, 4 * (size_t)s->sc.tiles * RADIX * sizeof(uint64_t), stream));
         s->epoch = 1;
     }
     WS_HIP(hipMemsetAsync(s->zero, 0, sizeof(SorterZero), stream));
     if (n == 0) return WS_OK;
-    // a context whose frames sort with the fat-tile one-sweep (WS_DEPTH_SORT=onesweep | coop): the same kernels, in place
     if (s->fat.status && fat_sort_grid(n, s->ctx->num_cus, s->fat.grid_request) != 0u)
         return launch_depth_sort_fat(s->fat, d_keys, d_payload, d_aux, d_count, n, false, s->ctx->depth_sort_mode == DS_COOP,
                                      s->epoch, s->ctx->num_cus, stream, nullptr);
-    int rc = launch_key_minmax(d_keys, d_count, n, s->zero->key_range, stream);
+    uint32_t *ok = nullptr, *ov = nullptr;
+    int rc = launch_sort_pairs(s->sc, d_keys, d_payload, d_count, n, 0, 32, false, false, stream, &ok, &ov, nullptr, "depth:",
+                               nullptr, 0, RADIX_BITS, false, d_aux, d_aux ? s->aux_alt : nullptr);
     if (rc) return rc;
-    rc = launch_depth_sort(s->ds, d_keys, d_payload, d_aux, d_count, n, false, s->epoch, stream, nullptr);
-    if (rc) return rc;
-    // three passes leave the result in the scratch buffers: bring the sorted prefix home (elements past the
-    // device-side count are not touched)
-    return launch_copy_counted(s->ds.keys_alt, d_keys, s->ds.vals_alt, d_payload, d_aux ? s->ds.aux_alt : nullptr, d_aux, d_count,
-                               n, stream);
+    if (ok != d_keys) return fail(WS_ERR_STATE, "ws_sorter_sort_depth: internal ping-pong parity error");
+    return WS_OK;
 }
 
 int ws_sort_selftest(ws_context* ctx, int* passed) {

@@ -68,7 +68,7 @@ struct FrameCounters {
     uint32_t k1_ticket;      // dynamic block id dispenser of the preprocess kernel
     uint32_t num_entries;    // D  (clamped to capacity)
     uint32_t overflow;       // bit 0: D exceeded capacity; bits 1..3: a look-back spin timed out (K1/bin/sort)
-    uint32_t sort_ticket[8]; // per-pass tile dispensers: [0..3] depth sort, [4..7] tile sort
+    uint32_t sort_ticket[8]; // [0..3] chunk dispensers of the fat-tile depth sort's passes (k_dsort_fat); [4..7] spare
     uint32_t bin_ticket;     // block dispenser of the binning prefix kernel
     uint32_t entries_needed; // D before clamping to the capacity (what a retry has to allocate)
     uint32_t epoch;          // look-back epoch of the frame, written by K1 (the only kernel whose arguments change per
@@ -89,18 +89,10 @@ static_assert(sizeof(FrameCounters) == 128 + TILE_SUM_SLOTS * TILE_SUM_STRIDE * 
 
 // Everything a frame needs zeroed lives in one contiguous arena: counters, the digit histograms of both
 // sorts, and the tile ranges (appended after this struct).
-// Range of the frame's depth keys, reduced by K1 while it writes them: KEY_RANGE_SLOTS independent {max(key),
-// max(~key)} pairs, one 64-B line each (workgroup b updates slot b % 8), so that the ~1200 returnless atomics of a
-// frame neither serialise on one address (~12 ns each) nor share a line with K1's ticket dispenser.  Zero-initialised
-// maxima: ~min is kept instead of min.  Readers combine the slots (key_range_load).
-constexpr int KEY_RANGE_SLOTS = 8;
-constexpr int KEY_RANGE_STRIDE = 16;  // uint32 words per slot (64 B)
-
 struct FrameZero {
     FrameCounters counters;
     uint32_t depth_hist[4 * RADIX];
     uint32_t tile_hist[4 * RADIX];
-    uint32_t key_range[KEY_RANGE_SLOTS * KEY_RANGE_STRIDE];
     uint32_t fat_barrier[9 * 16];  // single-launch depth sort (WS_DEPTH_SORT=coop): state of its device-wide barriers (grid_barrier.h)
     // uint2 tile_ranges[tiles] follows
 };
@@ -230,13 +222,10 @@ constexpr int TILE_SORT_WIDE_MAX_BINS = 1 << TILE_SORT_WIDE_MAX_BITS;
 struct SortScratch {
     uint32_t* keys_alt = nullptr;     // ping-pong partner of the caller's key buffer   [cap]
     uint32_t* vals_alt = nullptr;     // ping-pong partner of the caller's value buffer [cap]
-    uint32_t* hist = nullptr;         // [4][256] digit histograms, zero on entry
-    uint64_t* status = nullptr;       // [4][tiles][256] epoch-tagged look-back words (never re-zeroed)
-    uint32_t* tickets = nullptr;      // [4] tile dispensers, zero on entry
-    uint32_t* tile_sums = nullptr;    // [256][tiles_cap] per-tile digit counts / offsets of the scan path (algo 0)
-    uint32_t* error = nullptr;        // device word OR-ed with 8 if a look-back spin ever times out
+    uint32_t* hist = nullptr;         // [4][256] digit totals of the passes (written by the column scans)
+    uint32_t* tile_sums = nullptr;    // [256][tiles_cap] per-tile digit counts / offsets
     uint32_t cap = 0;
-    uint32_t tiles = 0;               // ceil(cap / SORT_TILE): one-sweep status rows per pass
+    uint32_t tiles = 0;               // ceil(cap / SORT_TILE)
     uint32_t tiles_cap = 0;           // row pitch of tile_sums: the largest tile count any n <= cap can need
     uint32_t wide_bins = 0;           // != 0: tile_sums also holds [tiles][wide_bins] rows (launch_tile_sort_wide)
     uint32_t* wide_hist = nullptr;    // [wide_bins] totals per bin, written by the wide column scan
@@ -246,19 +235,17 @@ struct SortScratch {
 //   d_count == nullptr -> sort n pairs; else the count is read on the device (clamped to n).
 //   begin_bit/end_bit: key bits that participate; digit_bits (6..8): digit width, passes = ceil(bits / digit_bits).
 //   implicit_iota: values of the first pass are the element positions (vals in is not read).
-//   first_tile_hist_ready (algo 0): the producer of the keys already wrote the first pass's per-tile digit
+//   first_tile_hist_ready: the producer of the keys already wrote the first pass's per-tile digit
 //     counts into sc.tile_sums (layout [digit][tiles_cap], tile = sort_tile_size(n) consecutive keys).
-//   algo 1 needs sc.hist and sc.tickets zero on entry (the renderer zeroes them with the frame arena).
 //   ranges != nullptr: the LAST pass does not write the sorted keys; instead ranges[key] (key < nranges, zero on
 //     entry) receives (0xFFFFFFFF - begin, end) of that key's run in the sorted order (see k_sort_scatter).
 // The result lands in (keys, vals) if the pass count is even, else in (scratch.keys_alt, vals_alt);
 // *out_keys / *out_vals receive the final pointers.
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
-                      int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, int algo,
-                      uint32_t epoch, hipStream_t stream, uint32_t** out_keys, uint32_t** out_vals,
-                      KernelMarks* km = nullptr, const char* tag = "", uint2* ranges = nullptr, uint32_t nranges = 0,
+                      int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, hipStream_t stream,
+                      uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km = nullptr, const char* tag = "", uint2* ranges = nullptr, uint32_t nranges = 0,
                       int digit_bits = RADIX_BITS, bool key16 = false, uint32_t* aux = nullptr, uint32_t* aux_alt = nullptr);
-//   aux / aux_alt (scan path only): a 4-byte companion value per pair travels with the payload; the result lands where
+//   aux / aux_alt: a 4-byte companion value per pair travels with the payload; the result lands where
 //     the payload lands (aux for an even pass count, aux_alt for an odd one).
 
 // ---- single-pass tile-id sort (sort.hip) ---------------------------------------------------------------------------
@@ -273,39 +260,6 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
 int launch_tile_sort_wide(const SortScratch& sc, const uint32_t* keys16, const uint32_t* vals, const uint32_t* d_count,
                           uint32_t n, int bits, hipStream_t stream, KernelMarks* km, uint2* ranges, uint32_t nranges);
 
-// ---- depth sort: range-adaptive three-pass LSD sort of the frame's depth keys (sort.hip) ------------------------
-// Exactly the order of a stable ascending sort on the full 32-bit keys.  The keys of a frame occupy a narrow range
-// [kmin, kmax] (K1 reduces it while it writes them): only nbits = bit_length(kmax - kmin) bits of key - kmin differ,
-// and three digit passes of w = ceil(nbits / 3) bits (<= 11) sort them -- typically 3 x 9 bits instead of the
-// reference's 4 x 8 (gpu_rs.rs:865-884).  Per pass TWO launches: k_dsort_hist (per-tile digit counts, then a decoupled
-// look-back over groups of tiles: the column scan of the generic path is gone) and k_dsort_scatter.  Optionally a
-// 4-byte companion value (the splat's packed tile rectangle) rides along with the payload, so that the consumer of the
-// draw order needs no gather.
-constexpr int DSORT_PASSES = 3;
-constexpr int DSORT_MAX_BITS = 11;
-constexpr int DSORT_MAX_BINS = 1 << DSORT_MAX_BITS;
-constexpr int DSORT_MAX_GROUPS = 128;
-struct DepthSortScratch {
-    uint32_t* keys_alt = nullptr;   // [cap] ping-pong partners
-    uint32_t* vals_alt = nullptr;
-    uint32_t* aux_alt = nullptr;    // companion values (nullptr when nothing is carried)
-    uint32_t* tile_off = nullptr;   // [tiles_cap][bins]  exclusive prefix of the tile's digit counts INSIDE its group
-    uint32_t* group_off = nullptr;  // [passes][groups][bins]  exclusive prefix over the groups
-    uint64_t* status = nullptr;     // [passes][groups][bins]  epoch-tagged look-back words (never re-zeroed)
-    uint32_t* totals = nullptr;     // [passes][bins]  digit totals of the pass
-    uint32_t* tickets = nullptr;    // [passes] group dispensers, zero on entry
-    const uint32_t* key_range = nullptr;    // [KEY_RANGE_SLOTS][KEY_RANGE_STRIDE]: {max(key), max(~key)} per slot (FrameZero)
-    uint32_t* error = nullptr;      // OR-ed with 8 if a look-back spin times out
-    uint32_t cap = 0, tiles_cap = 0;
-};
-size_t depth_sort_tile_off_words(uint32_t cap);     // allocation sizes for capacity `cap`
-size_t depth_sort_group_words();
-// keys/vals(/aux) in -> sorted vals (and aux) in sc.vals_alt / sc.aux_alt (three passes: A -> B -> A -> B); sorted keys
-// in sc.keys_alt.  implicit_iota: the payload of the first pass is the element position.  aux == nullptr: nothing carried.
-int launch_depth_sort(const DepthSortScratch& sc, uint32_t* keys, uint32_t* vals, uint32_t* aux, const uint32_t* d_count,
-                      uint32_t n, bool implicit_iota, uint32_t epoch, hipStream_t stream, KernelMarks* km = nullptr);
-// stand-alone use (ws_sorter in depth mode): reduce the key range of arbitrary input into key_range (zero on entry)
-// out[i] = src[idx[i]] for i < count (the classic depth-sort path brings the rectangles into draw order with it)
 // ---- fat-tile one-sweep depth sort (sort.hip k_dsort_fat) -----------------------------------------------------------
 // The same result as launch_sort_pairs over bits 0..32 with a companion value: four 8-bit passes, A -> B -> A -> B -> A, the
 // sorted arrays end where they started.  At most FAT_MAX_GRID workgroups of 1024 threads rank chunks of up to 8192 pairs;
@@ -334,12 +288,6 @@ int launch_depth_sort_fat(const FatSortScratch& sc, uint32_t* keys, uint32_t* va
                           uint32_t n, bool implicit_iota, bool coop, uint32_t epoch, int num_cus, hipStream_t stream,
                           KernelMarks* km = nullptr);
 
-int launch_gather_u32(const uint32_t* src, const uint32_t* idx, const uint32_t* d_count, uint32_t n, uint32_t* out,
-                      hipStream_t stream);
-int launch_copy_counted(const uint32_t* s0, uint32_t* d0, const uint32_t* s1, uint32_t* d1, const uint32_t* s2, uint32_t* d2,
-                        const uint32_t* d_count, uint32_t n, hipStream_t stream);
-int launch_key_minmax(const uint32_t* keys, const uint32_t* d_count, uint32_t n, uint32_t* key_range, hipStream_t stream);
-
 // ---- preprocess ---------------------------------------------------------------------------------
 struct K1Buffers {
     const uint4* planes;         // uncompressed: PC_PLANES planes
@@ -352,7 +300,6 @@ struct K1Buffers {
     uint32_t* src_index;         // [N] or nullptr (capture mode)
     uint64_t* block_status;      // [blocks] epoch-tagged look-back words
     FrameCounters* counters;
-    uint32_t* key_range;         // FrameZero::key_range
 };
 int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, int footprint_mode, hipStream_t stream);
 // K1 of up to K1_MAX_VIEWS views of ONE scene in one launch (preprocess.hip k_preprocess_multi): the scene is read once
@@ -450,18 +397,17 @@ int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_point
 
 // opaque handle definitions -------------------------------------------------------------------------
 // The depth sort of a frame (V keys + store index + footprint word):
-//   DS_SCAN      four 8-bit passes of tile histograms -> column scan -> scatter: 12 launches (round 1-3 default)
-//   DS_ADAPTIVE  three range-adaptive passes, two launches each (round 2; cross-check)
-//   DS_ONESWEEP  fat-tile one-sweep: one histogram launch + one launch per pass (round 4)
-//   DS_COOP      the same kernels as ONE launch with device-wide barriers between the passes (round 4, measured variant)
+//   DS_SCAN      four 8-bit passes of tile histograms -> column scan -> scatter: 12 launches (the default since round 1)
+//   DS_ONESWEEP  fat-tile one-sweep: one histogram launch + one launch per pass (round 4; measured variant)
+//   DS_COOP      the same kernels as ONE launch with device-wide barriers between the passes (round 4, measured variant;
+//                one frame at a time only: several such launches in flight starve each other of workgroup slots)
 // Inputs beyond the fat forms' capacity (FAT_MAX_GRID x 8192 pairs) take DS_SCAN.
-enum DepthSortMode { DS_SCAN = 0, DS_ADAPTIVE = 1, DS_ONESWEEP = 2, DS_COOP = 3 };
+enum DepthSortMode { DS_SCAN = 0, DS_ONESWEEP = 2, DS_COOP = 3 };
 
 struct ws_context {
     int device = 0;
     hipDeviceProp_t props;
-    int sort_algo = 0;    // 0 = tile histograms -> column scan -> scatter (default), 1 = one-sweep (look-back)
-    int depth_sort_mode = 0;  // DepthSortMode, WS_DEPTH_SORT = scan | adaptive | onesweep | coop
+    int depth_sort_mode = 0;  // DepthSortMode, WS_DEPTH_SORT = scan | onesweep | coop
     int dsort_fat_grid = 0;   // WS_DSORT_FAT_GRID (tuning): workgroups of the fat-tile depth sort, 0 = automatic
     int blend_variant = 0;
     int debug_cut = 0;        // WS_DEBUG_CUT (analysis): 0 = whole frame

@@ -793,7 +793,7 @@ class GPURSSorter:
                                  C.c_void_p(d_count) if d_count else None, int(n), C.c_void_p(stream or 0)))
 
     def sort_depth(self, d_keys: int, d_payload: int, n: int, d_aux: int = None, d_count: int = None, stream=None):
-        """The renderer's range-adaptive three-pass depth sort as a stand-alone call (same result as sort())."""
+        """The renderer's depth sort as a stand-alone call: same result as sort(), a 4-byte companion value rides along."""
         check(lib.ws_sorter_sort_depth(self.handle, C.c_void_p(d_keys), C.c_void_p(d_payload),
                                        C.c_void_p(d_aux) if d_aux else None, C.c_void_p(d_count) if d_count else None,
                                        int(n), C.c_void_p(stream or 0)))
