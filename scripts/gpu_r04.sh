@@ -79,7 +79,7 @@ if [[ $WHAT == *ab* ]]; then
     for v in $VARIANTS; do
       N=${v%%=*}
       echo "== $W $N (${v#*=})" >> $OUT/ab.txt
-      env $(venv ${v#*=}) timeout 600 python scripts/tile_stats.py $W 2>&1 | grep -E "^view 0|^  consumed|kernel times" | head -3 >> $OUT/ab.txt
+      [[ -z ${SKIP_TILE_STATS:-} ]] && env $(venv ${v#*=}) timeout 600 python scripts/tile_stats.py $W 2>&1 | grep -E "^view 0|^  consumed|kernel times" | head -3 >> $OUT/ab.txt
       env $(venv ${v#*=}) timeout 600 python bench.py --steps $STEPS --warmup 30 --no-cpu-baseline --no-secondary --workload $W 2> $OUT/bench_${N}_$W.err | tail -1 > $OUT/bench_${N}_$W.json
       python - $OUT/bench_${N}_$W.json >> $OUT/ab.txt <<'PY'
 import json,sys
@@ -96,6 +96,17 @@ PY
     done
   done
   cat $OUT/ab.txt >> $OUT/summary.txt
+fi
+if [[ $WHAT == *pmcvalu* ]]; then   # VALU issue / wait accounting per kernel (one PMC pass; no trace domains beside --kernel-trace)
+  for W in ${PMC_WORKLOADS:-c3}; do
+    rm -rf $OUT/pmc_valu_$W
+    timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_valu_$W -o pmc -- python bench.py --steps 6 --warmup 2 --streams 1 --no-cpu-baseline --no-secondary --no-dist --workload $W > $OUT/pmc_valu_$W.log 2>&1
+    python scripts/pmc_valu.py $OUT/pmc_valu_$W/pmc_counter_collection.csv $OUT/valu_$W.json > $OUT/valu_$W.txt 2>&1; echo "pmc valu $W exit=$?" >> $OUT/summary.txt
+    rm -rf $OUT/pmc_lds_$W
+    timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_lds_$W -o pmc -- python bench.py --steps 6 --warmup 2 --streams 1 --no-cpu-baseline --no-secondary --no-dist --workload $W > $OUT/pmc_lds_$W.log 2>&1
+    python scripts/pmc_summary.py $OUT/pmc_lds_$W/pmc_counter_collection.csv > $OUT/lds_$W.txt 2>&1; echo "pmc lds $W exit=$?" >> $OUT/summary.txt
+    find $OUT/pmc_valu_$W $OUT/pmc_lds_$W -size +2M -delete 2>/dev/null
+  done
 fi
 if [[ $WHAT == *prof* ]]; then
   for N in ${PROF_VARIANTS:-$(echo $VARIANTS | awk '{print $NF}' | cut -d= -f1)}; do
