@@ -393,14 +393,22 @@ def main():
         if ok.item() < 1.0:
             host_pg = None
 
+    bar_t = {}
+
     def barrier():
+        ta = time.perf_counter()
         device_sync()
+        tb = time.perf_counter()
         if dist is not None:
             if host_pg is not None:
                 dist.barrier(group=host_pg)
             else:
                 dist.barrier()
+            tc = time.perf_counter()
             device_sync()
+            bar_t.update(sync1=tb - ta, host_barrier=tc - tb, sync2=time.perf_counter() - tc)
+        else:
+            bar_t.update(sync1=tb - ta, host_barrier=0.0, sync2=0.0)
 
     if not a.dry_run:
         # one more renderer on the default stream: the one-frame-at-a-time rate and the per-kernel times (rank 0)
@@ -443,7 +451,9 @@ def main():
     elapsed = time.perf_counter() - t0
     cpu_busy = (time.process_time() - cpu0) / max(elapsed, 1e-9)   # host cores this rank kept busy during the timed region
     if os.environ.get("WS_BENCH_DEBUG"):
-        print(f"[bench debug] enqueue {t_enq * 1e3:.1f} ms, total {elapsed * 1e3:.1f} ms for {a.steps} frames", file=sys.stderr)
+        print(f"[bench debug] enqueue {t_enq * 1e3:.3f} ms, total {elapsed * 1e3:.3f} ms for {a.steps} frames; closing bracket: "
+              f"device sync {bar_t['sync1'] * 1e3:.3f} ms, host barrier {bar_t['host_barrier'] * 1e3:.3f} ms, second sync "
+              f"{bar_t['sync2'] * 1e3:.3f} ms", file=sys.stderr)
     # every frame of the timed region (and of the warm-up) must have been drawn completely: the slots' sticky error
     # words collect tile-entry overflow and look-back time-outs of ALL frames since the batch was created
     err_bits = batch.errors()
