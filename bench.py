@@ -442,17 +442,24 @@ def main():
     if a.warmup:
         submit(plan(0, a.warmup))
     timed = plan(a.warmup, a.steps)
+    # The timed region.  Opening bracket: every rank's device idle, then the host barrier, then device synchronize: all ranks
+    # start together.  Closing bracket: THIS rank's device synchronize, the clock, then the host barrier.  A rank's interval
+    # ends when its own K frames are done; the job's time is the MAX of the intervals over the ranks (the all-reduce below),
+    # which is what a closing barrier in front of the clock would measure too -- plus the barrier itself: a gloo barrier is a
+    # TCP round trip, measured at 0.15-0.33 ms on ONE rank (profiles/r04/short_run_probe.txt), 5-10 % of the 3-ms region of
+    # `--steps 20`, and it is not frames.
     barrier()
     cpu0 = time.process_time()   # CPU time of ALL threads of this process (enqueue thread + the HIP runtime's helpers)
     t0 = time.perf_counter()
     submit(timed)   # exactly K frames, enqueued back to back, one sync at the end
     t_enq = time.perf_counter() - t0
-    barrier()
+    device_sync()
     elapsed = time.perf_counter() - t0
     cpu_busy = (time.process_time() - cpu0) / max(elapsed, 1e-9)   # host cores this rank kept busy during the timed region
+    barrier()
     if os.environ.get("WS_BENCH_DEBUG"):
         print(f"[bench debug] enqueue {t_enq * 1e3:.3f} ms, total {elapsed * 1e3:.3f} ms for {a.steps} frames; closing bracket: "
-              f"device sync {bar_t['sync1'] * 1e3:.3f} ms, host barrier {bar_t['host_barrier'] * 1e3:.3f} ms, second sync "
+              f"(outside the interval) host barrier {bar_t['host_barrier'] * 1e3:.3f} ms, second sync "
               f"{bar_t['sync2'] * 1e3:.3f} ms", file=sys.stderr)
     # every frame of the timed region (and of the warm-up) must have been drawn completely: the slots' sticky error
     # words collect tile-entry overflow and look-back time-outs of ALL frames since the batch was created
@@ -484,9 +491,10 @@ def main():
                        # cores one rank keeps busy while it renders (MAX over ranks) and what the container grants in total:
                        # world x busy above the quota means the ranks throttle each other, whatever the core count says
                        "host_cores_busy_per_rank": cpu_busy, "host_cpu_quota": cpu_quota(),
-                       "timing_barrier": ("none (one process, --no-dist)" if dist is None else
-                                          "host barrier (gloo group) + device synchronize, both sides" if host_pg is not None
-                                          else f"{dist.get_backend()} barrier + device synchronize, both sides")},
+                       "timing_barrier": ("none (one process, --no-dist): device synchronize on both sides" if dist is None else
+                                          ("host barrier (gloo group)" if host_pg is not None else f"{dist.get_backend()} barrier")
+                                          + " + device synchronize in front of the region; behind it device synchronize, the "
+                                            "clock, then the barrier; MAX over ranks of the per-rank interval")},
         }
         if workload_note:
             out["config"]["workload_note"] = workload_note
