@@ -2,6 +2,7 @@
 bench.py uses with RCCL on the GPU box (views shard, nothing else is exchanged)."""
 import os
 import socket
+import subprocess
 import sys
 
 import pytest
@@ -93,3 +94,44 @@ def test_bench_dry_run_two_ranks_gloo():
     # whole-job value: all ranks' frames over the MAX elapsed (each dry frame sleeps 0.2 ms)
     assert abs(out["value"] - 2 * 40 / (out["ms_per_step"] * 40 / 1e3)) < 1e-6 * out["value"]
     assert 0.15 < out["ms_per_step"] < 5.0
+
+
+def test_ranks_take_disjoint_shares_of_the_physical_cores():
+    """bench.pin_host_share (round 4): rank r of w pins itself to the r-th of w slices of the physical cores it may run on --
+    SMT siblings stay together, the shares are disjoint and cover the allowed set, a rank alone is not pinned at all -- and
+    sizes its OpenMP team to the share (and to its part of a cgroup CPU quota, if there is one)."""
+    import json as _json
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 4:
+        pytest.skip("needs at least four CPUs")
+    code = ("import json, os, sys; sys.path.insert(0, %r); import bench; "
+            "r, w = int(sys.argv[1]), int(sys.argv[2]); cpus, note = bench.pin_host_share(r, w); "
+            "print(json.dumps({'cpus': sorted(cpus), 'aff': sorted(os.sched_getaffinity(0)), 'omp': os.environ.get('OMP_NUM_THREADS'), "
+            "'note': note, 'cores': bench._physical_cores(%r), 'quota': bench.cpu_quota()}))") % (ROOT, allowed)
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "WS_BENCH_PIN")}
+
+    def run(r, w, extra=None):
+        p = subprocess.run([sys.executable, "-c", code, str(r), str(w)], capture_output=True, text=True, timeout=120,
+                           env=dict(env, **(extra or {})))
+        assert p.returncode == 0, p.stderr[-2000:]
+        return _json.loads(p.stdout.strip().splitlines()[-1])
+    alone = run(0, 1)
+    assert alone["aff"] == allowed and alone["cpus"] == allowed          # one rank: nothing is pinned
+    cores = alone["cores"]
+    assert sorted(c for g in cores for c in g) == allowed                # the groups partition the allowed CPUs
+    w = 2 if len(cores) >= 2 else 1
+    shares = [run(r, w) for r in range(w)]
+    seen = []
+    for r, s in enumerate(shares):
+        assert s["aff"] == s["cpus"] and s["cpus"], s                    # the process IS pinned to what it reports
+        assert int(s["omp"]) >= 1 and int(s["omp"]) <= len(s["cpus"])
+        if s["quota"]:
+            assert int(s["omp"]) <= max(1, int(s["quota"] / w))
+        for g in cores:                                                  # a physical core belongs to one rank entirely
+            inter = set(g) & set(s["cpus"])
+            assert not inter or inter == set(g), (g, s["cpus"])
+        seen += s["cpus"]
+    assert sorted(seen) == allowed or w == 1                             # disjoint and covering
+    assert len(seen) == len(set(seen))
+    off = run(1, 2, {"WS_BENCH_PIN": "0"})
+    assert off["aff"] == allowed and "not pinned" in off["note"]
