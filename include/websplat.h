@@ -320,7 +320,10 @@ typedef enum ws_blend_mode { WS_BLEND_FAST = 0, WS_BLEND_TARGET_PRECISION = 1 } 
 int ws_renderer_set_blend_mode(ws_renderer* r, int mode);
 /* parity tooling: also record the original Gaussian index of every store slot (costs 4 B per visible splat) */
 int ws_renderer_enable_capture(ws_renderer* r, int enable);
-/* tuning: capacity of the (tile, splat) entry list; 0 = automatic. Takes effect at the next prepare. */
+/* Capacity of the (tile, splat) entry list; 0 = automatic: max(8 M, 4 per Gaussian per Mpixel), twice what the BASELINE
+ * scenes need.  A frame that needs more sets error bit 0 and leaves its demand in a word that survives the per-frame reset;
+ * once ws_renderer_errors (or ws_view_batch_errors) has read it, the next prepare() with the automatic capacity allocates
+ * 1.25 x that demand.  Takes effect at the next prepare. */
 int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries);
 /* parity read-back of the prepared frame (the reference's test tooling reads buffers back the same way,
  * gpu_rs.rs:900-941 download_buffer): splats = V x 20 B in store order, keys/src_index = V u32 in store
