@@ -246,49 +246,6 @@ def test_view_batch_matches_single_renders(ws, ctx, oracle):
         pc.close()
 
 
-@pytest.mark.parametrize("slots,nviews", [(4, 11), (3, 3), (2, 7), (4, 3)])
-def test_view_batch_heads_first_draws_identical_frames(ws, oracle, monkeypatch, slots, nviews):
-    """WS_BATCH_HEADS_FIRST=1: a view batch call enqueues the arena memset + K1 of its first frame on EVERY slot before the
-    rest of those frames, so that all slots start within a few launches of each other (the driver's 20-step region is 3 ms
-    long; frame by frame the fourth stream starts ~200 us after the first).  Only the host's order of enqueueing across
-    streams changes: the frames are bit-identical to the plain renderer's, through repeated calls, a call with fewer views
-    than slots (plain path) and ring positions that are not multiples of the slot count."""
-    monkeypatch.setenv("WS_BATCH_HEADS_FIRST", "1")
-    c = ws.Context(0)
-    try:
-        sc = scenes.c2(ws, oracle, n=200_000, viewport=(640, 480))
-        cams = synth.orbit_cameras(16, 640, 480, 640.0, 640.0)
-        views = []
-        for cj in cams[:nviews]:
-            cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, 640, 480)
-            cam.fit_near_far(sc.gpc.aabb)
-            views.append(ws.SplattingArgs(camera=cam, viewport=(640, 480), max_sh_deg=3))
-        pc = ws.PointCloud(c, sc.gpc)
-        r = ws.GaussianRenderer(c, "rgba32float", 3, False)
-        batch = ws.ViewBatch(c, "rgba32float", 3, False, frames_in_flight=slots)
-        bufs = [c.malloc(640 * 480 * 16) for _ in range(nviews)]
-        try:
-            alone = []
-            for v in views:
-                r.prepare(pc, v)
-                r.render(pc)
-                alone.append(r.download_target())
-            for rep in range(3):   # (the ring position advances by nviews per call: 11 % 4 = 3 -> every alignment)
-                batch.render(pc, views, bufs, 640 * 16)
-                batch.sync()
-                assert batch.errors() == 0
-                for i in range(nviews):
-                    assert np.array_equal(c.download(bufs[i], (480, 640, 4), np.float32), alone[i]), (rep, i)
-        finally:
-            for b in bufs:
-                c.free(b)
-            batch.close()
-            r.close()
-            pc.close()
-    finally:
-        c.close()
-
-
 @pytest.mark.parametrize("group,slots,compressed", [(2, 4, False), (4, 4, False), (4, 8, False), (3, 3, False), (2, 4, True)])
 def test_view_batch_shared_k1_draws_identical_frames(ws, oracle, monkeypatch, tmp_path, group, slots, compressed):
     """WS_BATCH_K1=g: groups of g consecutive frames of a view batch share ONE K1 launch (k_preprocess_multi: the scene is

@@ -285,21 +285,6 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
     size_t group = (size_t)b->ctx->batch_k1;
     if (group > 1 && slots % group != 0) group = 1;
     uint32_t i = 0;
-    if (b->ctx->batch_heads_first && group == 1 && slots >= 2 && slots <= 8 && num_views >= slots) {
-        // the call's first frame on every slot: heads (memset + K1) of all of them first (ws_internal_prepare_heads_first)
-        ws_renderer* rs[8];
-        hipStream_t ss[8];
-        for (size_t j = 0; j < slots; ++j) {
-            rs[j] = b->renderers[(b->next + j) % slots];
-            ss[j] = b->streams[(b->next + j) % slots];
-        }
-        int rc = ws_internal_frames_heads_first(rs, (uint32_t)slots, pc, views, ss, d_targets, row_pitch_bytes, background);
-        if (rc != WS_ERR_UNSUPPORTED) {
-            if (rc) return rc;
-            i = (uint32_t)slots;
-            b->next += slots;
-        }
-    }
     while (i < num_views) {
         const size_t k = (size_t)(b->next % slots);
         if (group > 1 && k % group == 0 && num_views - i >= group) {

@@ -400,7 +400,6 @@ int ws_context_create(int hip_device, ws_context** out) {
         ctx->bin_request = !bs ? BIN_AUTO : (std::strcmp(bs, "1") == 0 ? BIN_ALWAYS : (std::strcmp(bs, "0") == 0 ? BIN_NEVER : BIN_AUTO));
     }
     ctx->batch_k1 = env_int("WS_BATCH_K1", 1);
-    ctx->batch_heads_first = env_int("WS_BATCH_HEADS_FIRST", 0);
     if (ctx->batch_k1 < 1 || ctx->batch_k1 > K1_MAX_VIEWS) ctx->batch_k1 = 1;
     {
         const char* fm = std::getenv("WS_FOOTPRINT");  // ellipse | rect (default)
@@ -826,7 +825,7 @@ int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries) {
 // by launch, or once under stream capture (ws_renderer_prepare replays the captured graph afterwards).
 // phase: FRAME_ALL = the whole sequence; FRAME_CLEAR = the arena memset only, FRAME_REST = everything behind K1 (a view
 // batch runs K1 for several renderers in ONE launch between the two: ws_internal_prepare_group).
-enum FramePhase { FRAME_ALL = 0, FRAME_CLEAR = 1, FRAME_REST = 2, FRAME_HEAD = 3 };  // HEAD = the arena memset + K1
+enum FramePhase { FRAME_ALL = 0, FRAME_CLEAR = 1, FRAME_REST = 2 };
 static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params& kp, const K1Buffers& kb, hipStream_t stream,
                          int phase = FRAME_ALL) {
     int rc;
@@ -845,7 +844,6 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
             if ((rc = launch_empty(stream))) return rc;
             km_mark(km, "_empty_launch");
         }
-        if (phase == FRAME_HEAD) return WS_OK;
     }
 
     const int cut = r->ctx->debug_cut;
@@ -1182,40 +1180,6 @@ int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_point
     for (uint32_t i = 0; i < n; ++i) {
         if (i > 0) WS_HIP(hipStreamWaitEvent(streams[i], rs[0]->ev_group[1], 0));
         if ((rc = enqueue_frame(rs[i], pc, kp[i], kb[i], streams[i], FRAME_REST))) return rc;
-    }
-    return WS_OK;
-}
-
-// The first frames of a view batch call, one per slot, prepared AND drawn: every slot's arena memset + K1 are enqueued FIRST,
-// then frame by frame the rest of prepare() and render().  Launch by launch the host needs ~65 us per frame, so frame by frame the fourth stream's first kernel reaches the
-// GPU ~200 us after the first one's; with the heads up front all slots start within ~40 us.  The order of the launches on
-// each stream is unchanged.  Returns WS_ERR_UNSUPPORTED (nothing enqueued, nothing changed) when the renderers cannot be driven
-// this way (timers, capture, a frame graph, an analysis cut).
-extern "C" int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float background[4], void* d_rgba_out,
-                                  size_t row_pitch_bytes, void* stream_v);
-int ws_internal_frames_heads_first(ws_renderer* const* rs, uint32_t n, const ws_pointcloud* pc, const ws_splatting_args* views,
-                                   hipStream_t const* streams, void* const* d_targets, size_t row_pitch_bytes,
-                                   const float background[4]) {
-    if (!rs || !pc || !views || !streams || n < 2 || n > 8u) return WS_ERR_UNSUPPORTED;
-    for (uint32_t i = 0; i < n; ++i) {
-        ws_renderer* r = rs[i];
-        if (!r || !streams[i] || r->ctx != rs[0]->ctx || r->compressed != pc->compressed || r->timers || r->marks.active ||
-            r->capture || r->ctx->use_graph || r->ctx->debug_cut)
-            return WS_ERR_UNSUPPORTED;
-        for (uint32_t j = 0; j < i; ++j)
-            if (rs[j] == r || streams[j] == streams[i]) return WS_ERR_UNSUPPORTED;
-        if (views[i].max_sh_deg > 3) return fail(WS_ERR_INVALID, "ws_view_batch_render: max_sh_deg > 3");
-    }
-    K1Params kp[8];
-    K1Buffers kb[8];
-    int rc;
-    for (uint32_t i = 0; i < n; ++i) {
-        if ((rc = prepare_setup(rs[i], pc, &views[i], streams[i], &kp[i], &kb[i]))) return rc;
-        if ((rc = enqueue_frame(rs[i], pc, kp[i], kb[i], streams[i], FRAME_HEAD))) return rc;
-    }
-    for (uint32_t i = 0; i < n; ++i) {
-        if ((rc = enqueue_frame(rs[i], pc, kp[i], kb[i], streams[i], FRAME_REST))) return rc;
-        if ((rc = ws_renderer_render(rs[i], pc, background, d_targets[i], row_pitch_bytes, streams[i]))) return rc;
     }
     return WS_OK;
 }

@@ -394,10 +394,6 @@ struct ws_renderer;
 struct ws_pointcloud;
 int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_pointcloud* pc, const ws_splatting_args* views,
                               hipStream_t const* streams);
-// the first frame of every slot of a view batch: all memset + K1 pairs first, then the rest of each frame (ws_api.cpp)
-int ws_internal_frames_heads_first(ws_renderer* const* rs, uint32_t n, const ws_pointcloud* pc, const ws_splatting_args* views,
-                                   hipStream_t const* streams, void* const* d_targets, size_t row_pitch_bytes,
-                                   const float background[4]);
 
 // opaque handle definitions -------------------------------------------------------------------------
 // The depth sort of a frame (V keys + store index + footprint word):
@@ -419,8 +415,6 @@ struct ws_context {
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
     int footprint = 0;        // WS_FOOTPRINT=ellipse: FP_ELLIPSE (the default is FP_RECT_PACKED, FP_RECT_COUNT for wide viewports)
     int batch_k1 = 1;         // WS_BATCH_K1=n: a view batch runs K1 once for groups of n frames (1 = every frame its own K1)
-    int batch_heads_first = 0; // WS_BATCH_HEADS_FIRST=1: a view batch call enqueues the memset + K1 of its first frame on every slot
-                              //   before the rest of those frames (all slots start within ~40 us instead of ~200)
     bool tile_sort_wide = false; // WS_TILE_SORT=wide: single-pass tile-id sort up to 2048 binning tiles (launch_tile_sort_wide)
     int bin_request = 1;      // WS_BIN_SHIFT=0 | auto (default) | 1: BinRequest for frames that can use coarse binning
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
