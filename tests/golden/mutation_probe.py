@@ -27,6 +27,15 @@ MUTATIONS = {
     "cull z <= 0 -> z < 0": ("preprocess.wgsl", "z <= 0.", "z < 0.", "k1_"),
     "K1c T=J*W": ("preprocess_compressed.wgsl", "let T = W * J;", "let T = J * W;", "k1c_"),
     "K1c cull z < 0 -> z <= 0": ("preprocess_compressed.wgsl", "z < 0.", "z <= 0.", "k1c_"),
+    # the round-3 judge's own probes, kept so that the table is complete
+    "cull bounds 1.2 -> 1.3": ("preprocess.wgsl", "let bounds = 1.2 * pos2d.w;", "let bounds = 1.3 * pos2d.w;", "k1_"),
+    "mip coef +1e-6 -> +1e-5": ("preprocess.wgsl", "var coef = sqrt(det_0 / (det_1 + 1e-6) + 1e-6);", "var coef = sqrt(det_0 / (det_1 + 1e-6) + 1e-5);", "k1_"),
+    "colour max(0.) -> max(0.01)": ("preprocess.wgsl", "max(vec3<f32>(0.), evaluate_sh(dir, idx, render_settings.max_sh_deg)),",
+                                    "max(vec3<f32>(0.01), evaluate_sh(dir, idx, render_settings.max_sh_deg)),", "k1_"),
+    "K1c cull bounds 1.2 -> 1.3": ("preprocess_compressed.wgsl", "let bounds = 1.2 * pos2d.w;", "let bounds = 1.3 * pos2d.w;", "k1c_"),
+    "K1c dequantise *127. -> *128.": ("preprocess_compressed.wgsl", "v1 = dequantizef4(v1 * 127., quantization.color_dc);",
+                                      "v1 = dequantizef4(v1 * 128., quantization.color_dc);", "k1c_"),
+    "K1c max(radius, 0.1) -> 0.3": ("preprocess_compressed.wgsl", "let lambda2 = mid - max(radius, 0.1);", "let lambda2 = mid - max(radius, 0.3);", "k1c_"),
     # the draw (gaussian.wgsl:59-67): fixtures k6_fragments, k6_fragments_opaque, frame, frame_opaque
     "alpha clamp 0.99 -> 0.98": ("gaussian.wgsl", "min(0.99, exp(-a) * in.color.a)", "min(0.98, exp(-a) * in.color.a)", ("k6_", "frame")),
     "cut-off 2 CUTOFF -> 1.9 CUTOFF": ("gaussian.wgsl", "if a > 2. * CUTOFF", "if a > 1.9 * CUTOFF", ("k6_", "frame")),
