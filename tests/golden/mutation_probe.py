@@ -32,6 +32,8 @@ MUTATIONS = {
     "mip coef +1e-6 -> +1e-5": ("preprocess.wgsl", "var coef = sqrt(det_0 / (det_1 + 1e-6) + 1e-6);", "var coef = sqrt(det_0 / (det_1 + 1e-6) + 1e-5);", "k1_"),
     "colour max(0.) -> max(0.01)": ("preprocess.wgsl", "max(vec3<f32>(0.), evaluate_sh(dir, idx, render_settings.max_sh_deg)),",
                                     "max(vec3<f32>(0.01), evaluate_sh(dir, idx, render_settings.max_sh_deg)),", "k1_"),
+    "fade-in 5. -> 4.": ("preprocess.wgsl", "let dd = 5. * distance(render_settings.center, xyz) / render_settings.scene_extend;",
+                         "let dd = 4. * distance(render_settings.center, xyz) / render_settings.scene_extend;", "k1_"),
     "K1c cull bounds 1.2 -> 1.3": ("preprocess_compressed.wgsl", "let bounds = 1.2 * pos2d.w;", "let bounds = 1.3 * pos2d.w;", "k1c_"),
     "K1c dequantise *127. -> *128.": ("preprocess_compressed.wgsl", "v1 = dequantizef4(v1 * 127., quantization.color_dc);",
                                       "v1 = dequantizef4(v1 * 128., quantization.color_dc);", "k1c_"),
