@@ -335,50 +335,6 @@ def test_switched_paths_draw_the_default_image_bit_for_bit(ws, ctx, oracle, env,
         c.close()
 
 
-@pytest.mark.parametrize("kind", ["c2", "c3", "hd"])
-def test_compaction_before_the_gather_draws_the_same_image(ws, ctx, oracle, kind, monkeypatch):
-    """WS_BLEND_COMPACT=1 (k_blend_c): under 64-px binning an entry carries four sub-tile bits and a blend workgroup compacts
-    its candidates before gathering them.  The same records reach the same pixels in the same order; only the batches -- and
-    with them the granularity of the early-out -- differ: the image equals the default path's within 2 x T_MIN (as the
-    64-px image equals the 32-px one), frame counters equal, on a scene that bins coarse (c2-like, hd-like at 1080p) and on
-    one that does not (pixel-sized splats: every candidate is relevant)."""
-    if kind == "c2":
-        rows, viewport = synth.scene_c2(n=200_000, seed=21), (1283, 721)
-        cj = synth.orbit_cameras(8, viewport[0], viewport[1], 900.0, 900.0)[3]
-    elif kind == "hd":
-        rows, viewport = synth.scene_c2(n=400_000, seed=23), (1920, 1080)
-        cj = synth.orbit_cameras(8, viewport[0], viewport[1], 1920.0, 1920.0)[5]
-    else:
-        rows, viewport = synth.scene_c3(n=300_000, seed=22), (640, 480)
-        cj = synth.look_at_camera(0, [0.0, 0.0, -9.0], [0, 0, 0], viewport[0], viewport[1], 520.0, 520.0)
-    sc = scenes.Scene(ws, oracle, rows, 3, cj, viewport)
-    pc, want, st0 = _render(ws, ctx, sc, background=(0.1, 0.2, 0.3, 1.0))
-    pc.close()
-    monkeypatch.setenv("WS_BLEND_COMPACT", "1")
-    c = ws.Context(0)
-    try:
-        pc = ws.PointCloud(c, sc.gpc)
-        r = ws.GaussianRenderer(c, "rgba32float", 3, False)
-        try:
-            for frame in range(2):
-                r.prepare(pc, sc.args)
-                r.render(pc, background=(0.1, 0.2, 0.3, 1.0))
-                img = r.download_target()
-                st = r.frame_stats()
-                assert st["num_visible"] == st0["num_visible"] and st["num_tile_entries"] == st0["num_tile_entries"]
-                assert st["overflow"] == 0 and r.errors()[0] == 0
-                assert float(np.abs(img - want).max()) <= 2.0 / 16384.0 * 1.6 + 1e-6, (kind, frame, float(np.abs(img - want).max()))
-            if kind == "hd":
-                assert r.binning_tile() == (64, 64)   # (the compaction has something to compact)
-            ref, ofr_ = sc.oracle_image(pc, background=(0.1, 0.2, 0.3, 1.0))
-            _assert_close(img, ref, proof=sc.proof(ofr_, (0.1, 0.2, 0.3, 1.0)))
-        finally:
-            r.close()
-            pc.close()
-    finally:
-        c.close()
-
-
 def test_many_tiles_32bit_keys(ws, oracle, monkeypatch):
     """65536 tiles (4096x4096 at 16x16): the tile sort switches from 16-bit to 32-bit tile ids, two 8-bit passes."""
     monkeypatch.setenv("WS_TILE_SHAPE", "2x2")

@@ -137,25 +137,6 @@ __device__ __forceinline__ uint32_t tile_of_rect(uint32_t r, uint32_t k, uint32_
     return (y0 + q) * tiles_x + (x0 + rem);
 }
 
-// The same for a frame that bins at twice the blend's tile size: tile id of the k-th COARSE tile of the rectangle (in units
-// of 2 x 2 tiles), and which of that tile's four blend tiles the fine rectangle reaches (bit j * 2 + i for blend tile
-// (2 cx + i, 2 cy + j)).
-__device__ __forceinline__ uint32_t tile_of_rect_coarse(uint32_t r, uint32_t k, uint32_t tiles_x_coarse, uint32_t* sub) {
-    const uint32_t x0 = r & 0xFFu, y0 = (r >> 8) & 0xFFu, x1 = x0 + ((r >> 16) & 0xFFu), y1 = y0 + (r >> 24);
-    const uint32_t x0c = x0 >> 1, y0c = y0 >> 1;
-    const uint32_t w = (x1 >> 1) - x0c + 1u;
-    uint32_t q = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
-    uint32_t rem = k - q * w;
-    if ((int32_t)rem < 0) { q -= 1u; rem += w; }
-    if (rem >= w) { q += 1u; rem -= w; }
-    const uint32_t cx = x0c + rem, cy = y0c + q;
-    const uint32_t fx = cx << 1, fy = cy << 1;
-    const uint32_t cols = (fx >= x0 && fx <= x1 ? 1u : 0u) | (fx + 1u >= x0 && fx + 1u <= x1 ? 2u : 0u);
-    const uint32_t rows = (fy >= y0 && fy <= y1 ? 1u : 0u) | (fy + 1u >= y0 && fy + 1u <= y1 ? 2u : 0u);
-    *sub = ((rows & 1u) ? cols : 0u) | ((rows & 2u) ? (cols << 2) : 0u);
-    return cy * tiles_x_coarse + cx;
-}
-
 // Entry el (0 <= el < sl.ne) of the slice: tile id and splat (store index).
 template <bool PACKED>
 __device__ __forceinline__ void entry(const Source& src, const Slice& sl, const uint32_t* s_off, const uint32_t* s_own,

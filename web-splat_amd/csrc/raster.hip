@@ -224,13 +224,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
                 if (el < sl.ne) {
                     const uint32_t e = sl.e0 + el;
                     const uint32_t k = e - sl.off_at(s_off, lo[j]);
-                    uint32_t sub = 0u;
-                    const uint32_t key = PACKED ? (coarse ? emit::tile_of_rect_coarse(rect[j], k, tiles_x, &sub)
-                                                          : emit::tile_of_rect(rect[j], k, tiles_x))
+                    const uint32_t key = PACKED ? emit::tile_of_rect(coarse ? rect_coarse(rect[j]) : rect[j], k, tiles_x)
                                                 : emit::tile_of(src, geom[j], k);
                     if (key16) reinterpret_cast<uint16_t*>(entry_keys)[e] = (uint16_t)key;
                     else entry_keys[e] = key;
-                    entry_vals[e] = val[j] | (sub << ENTRY_SUB_SHIFT);  // (sub = 0 unless the frame bins coarse)
+                    entry_vals[e] = val[j];
                     if (WIDE) atomicAdd(&s_hist[key], 1u);  // (key < tiles <= bins)
                     else atomicAdd(&s_hist[(key & tile_hist_mask) * EMIT_COPIES + copy], 1u);
                 }
@@ -360,7 +358,7 @@ __device__ __forceinline__ uint32_t blend_entry_idx(const BlendParams& p, uint2 
     const uint32_t h = hi > range.x ? hi : range.x + 1u;
     const uint32_t nb = (h - range.x) < (uint32_t)STAGE ? (h - range.x) : (uint32_t)STAGE;
     const uint32_t off = (uint32_t)tid < nb ? (uint32_t)tid : nb - 1u;
-    return p.entry_vals[h - 1u - off] & ENTRY_INDEX_MASK;
+    return p.entry_vals[h - 1u - off];
 }
 // The 20-B Splat record.  One dwordx4 + one dword, and the four words stay a single 128-bit value until the decode: as
 // five scalars the compiler parked three of them in other registers right behind the load (s_waitcnt vmcnt + v_mov: the
@@ -728,206 +726,6 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     if (DMA) wait_vector_loads();  // a prefetch the tile did not consume must have landed before the workgroup's LDS is released
 }
 
-// ---- k_blend_c: k_blend<., 4, 4> with the candidates COMPACTED before the gather (WS_BLEND_COMPACT=1; round 4) ---------------
-// Under 64-px binning four blend workgroups share one list, and k_blend stages -- gathers, decodes, masks -- every entry of
-// it in each of them although half concern other tiles.  Here an entry says which of the four tiles it reaches (bits 28..31,
-// k_bin_emit), and the workgroup looks at the entry INDICES first: 1024 candidates per step (one per thread, near -> far),
-// a ballot per wave, the waves' counts exchanged through LDS, and the survivors' indices written -- in depth order -- to the
-// slots of the batch they will fill (whole waves of candidates, as many as fit the 512 slots); only those are gathered and
-// decoded, by consecutive threads.  The staging pipeline is one step deeper than k_blend's: while batch b is composited the
-// records of batch b+1 (their indices were assigned during batch b-1) and the candidates of batch b+3 are in flight, and
-// the candidates of batch b+2 are assigned between the staging barrier and the walk.  A frame that did not bin coarse has
-// no bits: every candidate is relevant and the first eight waves of every step fill the batch.
-// The walk is k_blend's.
-template <int FORMAT>
-__global__ __launch_bounds__(1024, 8) void k_blend_c(const BlendParams p) {
-    constexpr int QW = 4, QH = 4, NW = 16, NT = 1024, STAGE = 512, SLOTS = STAGE + 1, TW = 32, TH = 32, LCAP = 512;
-    __shared__ float4 s_rec[2 * SLOTS];
-    __shared__ __attribute__((aligned(16))) uint16_t s_m[STAGE];
-    __shared__ __attribute__((aligned(16))) uint32_t s_list[NW][LCAP + 16];
-    __shared__ uint32_t s_idx[2][STAGE];  // Splat indices of the next two batches, by slot
-    __shared__ uint32_t s_cnt[NW];        // survivors per wave of the candidates being assigned
-
-    if (blockIdx.x == 0 && threadIdx.x == 0 && p.sticky) {
-        const uint32_t bits = p.counters->overflow;
-        if (bits) {
-            atomicOr(p.sticky, bits);
-            if (bits & 1u) atomicMax(p.sticky + 1, p.counters->entries_needed);
-        }
-    }
-    const BlendShape shape = blend_shape(QW, QH);
-    const BlendBlock blk = blend_block_of(blockIdx.x, p.tiles_x, p.tiles_y, shape, 0u);
-    if (!blk.valid) return;  // block-uniform
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int qx = wave % QW, qy = wave / QW;
-    const float lx = (float)(qx * 8 + (lane & 7)) + 0.5f;
-    const float ly = (float)(qy * 8 + (lane >> 3)) + 0.5f;
-    const uint32_t qbit = 1u << wave;
-    const bool stager = tid < STAGE;  // wave-uniform
-    const uint32_t tx = (blk.bx << shape.tbx_log2) + (blk.w & ((1u << shape.tbx_log2) - 1u));
-    const uint32_t ty = (blk.by << shape.tby_log2) + (blk.w >> shape.tbx_log2);
-    if (tx >= p.tiles_x || ty >= p.tiles_y) return;  // block-uniform
-    uint2 range = p.tile_ranges[tile_list_index(p, tx, ty)];
-    range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
-    // my tile's bit in an entry's sub-tile field; 0 = the frame binned at the blend's tile: every entry is mine
-    const uint32_t mybit = p.counters->bin_shift ? (1u << (ENTRY_SUB_SHIFT + ((ty & 1u) << 1) + (tx & 1u))) : 0u;
-    if (tid == 0) {
-        s_rec[STAGE] = make_float4(0.0f, 0.0f, 1.0e9f, 0.0f);
-        s_rec[SLOTS + STAGE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    const float W = (float)p.width, H = (float)p.height;
-    uint32_t* my_list = s_list[wave];
-    const uint32_t px = tx * TW + qx * 8 + (lane & 7);
-    const uint32_t py = ty * TH + qy * 8 + (lane >> 3);
-    const bool inside = px < p.width && py < p.height;
-    float T = inside ? 1.0f : 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    const float tile_x0 = (float)(tx * TW), tile_y0 = (float)(ty * TH);
-
-    // ---- candidate stream: entries [range.x, hi_scan) are still to be looked at, nearest first -------------------------
-    uint32_t hi_scan = range.y;
-    // candidates of one step: thread t holds entry hi - 1 - t; n = how many of the 1024 exist (workgroup-uniform)
-    auto cand_load = [&](uint32_t hi, uint32_t* n) -> uint32_t {
-        const uint32_t left = hi - range.x;
-        *n = left < (uint32_t)NT ? left : (uint32_t)NT;
-        // (the address is clamped into the list, or to entry 0 of an empty one: the load never depends on a branch)
-        const uint32_t pos = (uint32_t)tid < *n ? hi - 1u - (uint32_t)tid : (range.y > range.x ? range.x : 0u);
-        return p.entry_vals[pos];
-    };
-    // step 1 of an assignment: who survives, and how many per wave (read by everybody behind the next barrier)
-    auto cand_count = [&](uint32_t cand, uint32_t n, unsigned long long* bal) -> bool {
-        const bool keep = (uint32_t)tid < n && (mybit == 0u || (cand & mybit) != 0u);
-        *bal = __ballot(keep);
-        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(*bal);
-        return keep;
-    };
-    // step 2 (behind a barrier): whole waves of candidates, nearest first, as long as their survivors fit the batch; the
-    // survivors' indices go to their slots.  -> slots filled, candidates consumed (both workgroup-uniform)
-    auto cand_assign = [&](uint32_t cand, uint32_t n, bool keep, unsigned long long bal, uint32_t buf, uint32_t* consumed) -> uint32_t {
-        uint32_t total = 0u, before = 0u, take = 0u;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const uint32_t c = s_cnt[w];
-            const bool fits = take == (uint32_t)w && total + c <= (uint32_t)STAGE;
-            if (fits) {
-                if (w < wave) before += c;
-                total += c;
-                take = (uint32_t)w + 1u;
-            }
-        }
-        if ((uint32_t)wave < take && keep)
-            s_idx[buf][before + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
-                cand & ENTRY_INDEX_MASK;
-        const uint32_t looked = take * 64u;
-        *consumed = looked < n ? looked : n;
-        return total;
-    };
-
-    // ---- prologue: batches 0 and 1 assigned, batch 0's records requested, candidates of batch 2 in flight -------------
-    uint32_t n_c, consumed;
-    unsigned long long bal;
-    uint32_t cand = cand_load(hi_scan, &n_c);
-    bool keep = cand_count(cand, n_c, &bal);
-    __syncthreads();
-    uint32_t ns_cur = cand_assign(cand, n_c, keep, bal, 0u, &consumed);
-    hi_scan -= consumed;
-    cand = cand_load(hi_scan, &n_c);
-    __syncthreads();  // s_idx[0] is visible, s_cnt reusable
-    RawSplat raw = {{0u, 0u, 0u, 0u}, 0u};
-    // (slot clamped, and index 0 when the batch is empty: the gather never depends on a branch and never leaves the records)
-    if (stager) raw = blend_gather(p, ns_cur ? s_idx[0][(uint32_t)tid < ns_cur ? (uint32_t)tid : 0u] : 0u);
-    keep = cand_count(cand, n_c, &bal);
-    __syncthreads();
-    uint32_t ns_nxt = cand_assign(cand, n_c, keep, bal, 1u, &consumed);
-    hi_scan -= consumed;
-    cand = cand_load(hi_scan, &n_c);
-    __syncthreads();  // s_idx[1] visible (read by the first staging step), s_cnt reusable
-    if (ns_cur == 0u) {  // block-uniform: an empty list (or none of it mine so far AND nothing left)
-        if (hi_scan == range.x && ns_nxt == 0u) {
-            if (inside) store_pixel<FORMAT>(p, px, py, p.background[0], p.background[1], p.background[2], p.background[3]);
-            return;
-        }
-    }
-
-    uint32_t b = 0u;
-    for (;;) {
-        // ---- staging of batch b: decode what was gathered, request batch b + 1, count the candidates of batch b + 2
-        if (stager) {
-            uint32_t mask = 0u;
-            if ((uint32_t)tid < ns_cur) {
-                const stage::Staged s = stage::decode<QW, QH>(raw.a.x, raw.a.y, raw.a.z, raw.a.w, raw.w4, W, H, tile_x0, tile_y0, CUT_A2);
-                mask = s.mask;
-                s_rec[tid] = make_float4(s.i00, s.i01, s.c0, s.i10);
-                s_rec[SLOTS + tid] = make_float4(s.i11, s.c1, __uint_as_float(raw.a.w), __uint_as_float(raw.w4));
-            }
-            s_m[((uint32_t)tid & 63u) * (LCAP / 64) + ((uint32_t)tid >> 6)] = (uint16_t)mask;
-            // UNCONDITIONAL gather (slot clamped): see k_blend -- under a branch the loaded words are merged with the old ones
-            raw = blend_gather(p, ns_nxt ? s_idx[(b + 1u) & 1u][(uint32_t)tid < ns_nxt ? (uint32_t)tid : 0u] : 0u);
-        }
-        keep = cand_count(cand, n_c, &bal);
-        __syncthreads();
-        const uint32_t ns_n2 = cand_assign(cand, n_c, keep, bal, b & 1u, &consumed);
-        hi_scan -= consumed;
-        const bool more = hi_scan > range.x || ns_n2 != 0u || ns_nxt != 0u;  // something behind batch b
-        cand = cand_load(hi_scan, &n_c);
-
-        // ---- walk of batch b (k_blend's) -----------------------------------------------------------------------------
-        const uint32_t nb = ns_cur;
-        if (nb != 0u && __ballot(T >= T_MIN) != 0ull) {
-            const uint2* mp = reinterpret_cast<const uint2*>(s_m + (uint32_t)lane * (LCAP / 64));
-            uint32_t n = 0;
-            uint32_t slot16 = (uint32_t)lane * 16u;
-            asm volatile("" : "+v"(slot16));
-#pragma unroll
-            for (int h = 0; h < LCAP / 256; ++h) {
-                const uint2 mm = mp[h];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = h * 4 + q;
-                    const uint32_t word = (q & 2) ? mm.y : mm.x;
-                    const bool t = (word & (qbit << ((q & 1) * 16))) != 0u;
-                    const unsigned long long bl = __ballot(t);
-                    const uint32_t pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
-                    if (t) my_list[pos] = slot16 + (uint32_t)r * 1024u;
-                    n += (uint32_t)__popcll(bl);
-                }
-            }
-            if (n > 0u) {
-                if (lane < 4 && ((n + (uint32_t)lane) >> 2) == (n >> 2) && (n & 3u)) my_list[n + lane] = (uint32_t)STAGE * 16u;
-                const uint32_t n4 = (n + 3u) >> 2;
-                const uint4* lp = reinterpret_cast<const uint4*>(my_list);
-                uint4 o = lp[0];
-                uint4 on = lp[n4 > 1u ? 1u : 0u];
-                BlendRec cur = blend_load_rec<SLOTS>(s_rec, o.x);
-                for (uint32_t g = 0; g < n4; ++g) {
-                    const BlendRec r1 = blend_load_rec<SLOTS>(s_rec, o.y);
-                    blend_composite(cur, lx, ly, T, cr, cg, cb);
-                    const BlendRec r2 = blend_load_rec<SLOTS>(s_rec, o.z);
-                    blend_composite(r1, lx, ly, T, cr, cg, cb);
-                    const BlendRec r3 = blend_load_rec<SLOTS>(s_rec, o.w);
-                    blend_composite(r2, lx, ly, T, cr, cg, cb);
-                    cur = blend_load_rec<SLOTS>(s_rec, on.x);
-                    blend_composite(r3, lx, ly, T, cr, cg, cb);
-                    if (__ballot(T >= T_MIN) == 0ull) break;
-                    o = on;
-                    on = lp[g + 2u < n4 ? g + 2u : n4 - 1u];
-                }
-            }
-        }
-        const bool all_done = __syncthreads_and(T < T_MIN ? 1 : 0);
-        if (all_done || !more) break;
-        ns_cur = ns_nxt;
-        ns_nxt = ns_n2;
-        ++b;
-    }
-    {
-        const uint32_t sx = tx * TW + (uint32_t)lx, sy = ty * TH + (uint32_t)ly;
-        if (sx < p.width && sy < p.height)
-            store_pixel<FORMAT>(p, sx, sy, cr + p.background[0] * T, cg + p.background[1] * T, cb + p.background[2] * T,
-                                (1.0f - T) + p.background[3] * T);
-    }
-}
-
 // ---- k_blend_q: one WAVE per 8x8 quadrant, no LDS, no barriers -------------------------------------------
 // Measured on MI355X (profiles/): the 256-thread kernel above is bound by the serial latency of one tile (two
 // barriers per 256-splat batch, three dependent LDS reads per splat), not by VALU (26 % busy) or LDS bandwidth.
@@ -1018,7 +816,7 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
         const uint32_t h = hi_ > range.x ? hi_ : range.x + 1u;
         const uint32_t nbb = (h - range.x) < 64u ? (h - range.x) : 64u;
         const uint32_t off = (uint32_t)lane < nbb ? (uint32_t)lane : nbb - 1u;
-        return p.entry_vals[h - 1u - off] & ENTRY_INDEX_MASK;
+        return p.entry_vals[h - 1u - off];
     };
     auto chunk_len = [&](uint32_t hi_) -> uint32_t {
         return hi_ > range.x ? ((hi_ - range.x) < 64u ? (hi_ - range.x) : 64u) : 0u;
@@ -1150,7 +948,7 @@ __global__ __launch_bounds__(64) void k_blend_strict(const BlendParams p) {
     for (uint32_t lo = range.x; lo < range.y; lo += 64u) {  // far -> near: ascending position in the tile's list
         const uint32_t e = lo + (uint32_t)lane;
         const bool valid = e < range.y;
-        const uint32_t idx = p.entry_vals[valid ? e : range.y - 1u] & ENTRY_INDEX_MASK;
+        const uint32_t idx = p.entry_vals[valid ? e : range.y - 1u];
         const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx * 20);
         const StagedSplat s = decode_splat(sp[0], sp[1], sp[2], sp[3], sp[4], W, H, qx_lo, qy_lo, valid);
         unsigned long long rel = __ballot(s.touch);
@@ -1369,19 +1167,6 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
                 break;
             default:
                 return fail(WS_ERR_INVALID, "blend: unknown colour format");
-        }
-        WS_HIP(hipGetLastError());
-        return WS_OK;
-    }
-    if (p.compact && p.qw == 4u && p.qh == 4u && p.range_row_shift == 0u && !p.dma && !p.debug_consumed && !p.debug_walked &&
-        (p.tpw_log2 >= 0 ? p.tpw_log2 == 0 : blend_tpw_log2(p.tiles_x, p.tiles_y, blend_shape(4, 4)) == 0u)) {
-        // WS_BLEND_COMPACT=1: candidates compacted before the gather (k_blend_c); one tile per workgroup, the default shape
-        const uint32_t grid = blend_grid_blocks(p.tiles_x, p.tiles_y, blend_shape(4, 4), 0u);
-        switch (p.format) {
-            case WS_FORMAT_RGBA32_FLOAT: hipLaunchKernelGGL(k_blend_c<WS_FORMAT_RGBA32_FLOAT>, dim3(grid), dim3(1024), 0, stream, p); break;
-            case WS_FORMAT_RGBA16_FLOAT: hipLaunchKernelGGL(k_blend_c<WS_FORMAT_RGBA16_FLOAT>, dim3(grid), dim3(1024), 0, stream, p); break;
-            case WS_FORMAT_RGBA8_UNORM: hipLaunchKernelGGL(k_blend_c<WS_FORMAT_RGBA8_UNORM>, dim3(grid), dim3(1024), 0, stream, p); break;
-            default: return fail(WS_ERR_INVALID, "blend: unknown colour format");
         }
         WS_HIP(hipGetLastError());
         return WS_OK;

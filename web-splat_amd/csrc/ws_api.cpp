@@ -395,7 +395,6 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->use_graph = env_int("WS_GRAPH", 0);
     ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
     ctx->blend_dma = env_int("WS_BLEND_DMA", 0) ? 1 : 0;
-    ctx->blend_compact = env_int("WS_BLEND_COMPACT", 0) ? 1 : 0;
     {
         const char* bs = std::getenv("WS_BIN_SHIFT");  // 0 | 1 | auto (default): binning at twice the blend's tile size
         ctx->bin_request = !bs ? BIN_AUTO : (std::strcmp(bs, "1") == 0 ? BIN_ALWAYS : (std::strcmp(bs, "0") == 0 ? BIN_NEVER : BIN_AUTO));
@@ -1018,8 +1017,7 @@ static int prepare_setup(ws_renderer* r, const ws_pointcloud* pc, const ws_splat
     // Coarse binning (2 x 2 blend tiles per binning tile, decided per frame on the device: ws_internal.h bin_shift_decide) is
     // offered to frames of the default 32x32 shape whose rectangles travel packed; parity tooling that reads per-tile
     // lists back (capture mode) always sees the blend's own tiles.
-    kp.bin_request = (r->footprint_mode == FP_RECT_PACKED && !r->capture && r->ctx->tile_qw == 4 && r->ctx->tile_qh == 4 &&
-                      pc->num_points <= ENTRY_INDEX_MASK)  // (coarse entries carry four sub-tile bits above the index)
+    kp.bin_request = (r->footprint_mode == FP_RECT_PACKED && !r->capture && r->ctx->tile_qw == 4 && r->ctx->tile_qh == 4)
                          ? (uint32_t)r->ctx->bin_request : (uint32_t)BIN_NEVER;
     kp.znear = -kp.cam.proj[3 * 4 + 2] / kp.cam.proj[2 * 4 + 2];
     kp.zfar = -kp.cam.proj[3 * 4 + 2] / (kp.cam.proj[2 * 4 + 2] - 1.0f);
@@ -1213,7 +1211,6 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.pitch = row_pitch_bytes;
     bp.format = (int)r->format;
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
-    bp.compact = r->ctx->blend_compact;
     bp.lds_pad_kb = r->ctx->blend_lds_pad_kb;
     bp.dma = r->ctx->blend_dma;
     bp.num_cus = r->ctx->num_cus;
@@ -1402,10 +1399,8 @@ int ws_renderer_download_tile_lists(ws_renderer* r, uint32_t tile_capacity, uint
             if (end) end[i] = rg[i].y;
         }
     }
-    if (entries && st.num_tile_entries) {
+    if (entries && st.num_tile_entries)
         { int rc_ = copy_d2h(entries, r->entries_sorted, (size_t)st.num_tile_entries * 4, r->last_stream); if (rc_) return rc_; }
-        for (uint32_t i = 0; i < st.num_tile_entries; ++i) entries[i] &= ENTRY_INDEX_MASK;  // (coarse frames: sub-tile bits above)
-    }
     return WS_OK;
 }
 

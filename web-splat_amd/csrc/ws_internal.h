@@ -130,13 +130,6 @@ __host__ __device__ inline uint32_t rect_tiles(uint32_t r) {
 // all ratios 1.75..2.63 and by +4 % on average (-3..+13 %) at 1.53: the threshold sits just below the smallest ratio measured to win.  K1 sums both tile counts while it writes the rectangles; the binning prefix derives
 // the decision from the two sums (a pure function of the frame: ranks and renderers agree), no host round trip.
 enum BinRequest { BIN_NEVER = 0, BIN_AUTO = 1, BIN_ALWAYS = 2 };
-// A (tile, splat) entry's value is the splat's store index in its low 28 bits.  When the frame bins at twice the blend's tile
-// size, bits 28..31 say which of the 2 x 2 compositing tiles of the binning tile the splat's rectangle reaches (bit
-// (ty & 1) * 2 + (tx & 1)): a blend workgroup can tell from the entry alone whether it concerns its tile (k_blend_c compacts
-// its candidates before gathering them, WS_BLEND_COMPACT=1).  Frames of point clouds beyond 2^28 - 1 Gaussians bin at the
-// blend's tile.
-constexpr uint32_t ENTRY_INDEX_MASK = 0x0FFFFFFFu;
-constexpr uint32_t ENTRY_SUB_SHIFT = 28u;
 #ifndef WS_BIN64_RATIO_PERCENT
 #define WS_BIN64_RATIO_PERCENT 150
 #endif
@@ -364,7 +357,6 @@ struct BlendParams {
     int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
     int lds_pad_kb;             // tuning: extra (unused) dynamic LDS per workgroup, limits workgroups per CU
     int dma;                    // stage the Splat records with gfx950's LDS-DMA (global_load_lds) instead of through VGPRs
-    int compact;                // k_blend_c: candidates are compacted by their sub-tile bits before the gather (4x4 tiles, one tile per workgroup)
     int num_cus;
     uint32_t bin_tiles_x;       // binning tiles per row at the blend's tile size (the frame may bin at twice that: FrameCounters::bin_shift)
     uint32_t range_row_shift;   // 0, or 1 = "split" mode: tiles_y counts HALF binning tiles (32x16 px, 8 waves) and the list of
@@ -426,7 +418,6 @@ struct ws_context {
     bool tile_sort_wide = false; // WS_TILE_SORT=wide: single-pass tile-id sort up to 2048 binning tiles (launch_tile_sort_wide)
     int bin_request = 1;      // WS_BIN_SHIFT=0 | auto (default) | 1: BinRequest for frames that can use coarse binning
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
-    int blend_compact = 0;    // WS_BLEND_COMPACT=1: k_blend_c (compaction before the gather under 64-px binning; round 4, measured)
     int blend_split = -1;     // WS_BLEND_SPLIT: 4x4 binning tiles composited by two 4x2 workgroups each; -1 = when tiles < 2 x CUs
     int num_cus = 256;
     int use_graph = 0;        // WS_GRAPH=1: prepare() on a real stream replays a captured frame graph instead of enqueueing 22
