@@ -85,6 +85,8 @@ def test_bench_holds_its_rate_on_a_sliver_of_the_host(tmp_path):
     if len(cores) < 16:
         pytest.skip("fewer than 16 physical cores: an eighth of the host is not a meaningful share")
     quota = bench.cpu_quota() or float(len(cores))
+    if quota < 8:
+        pytest.skip("the container grants fewer than 8 CPUs' worth of run time: no room for the other ranks' stand-ins")
     eighth = len(cores) // 8
     mine = sorted(c for g in cores[:2] for c in g)                 # two physical cores (four logical CPUs with SMT)
     nburn = int(min(14, max(0, quota - 6)))                        # two busy threads per other rank, inside the quota
