@@ -246,6 +246,69 @@ def test_view_batch_matches_single_renders(ws, ctx, oracle):
         pc.close()
 
 
+@pytest.mark.parametrize("threads,slots,nviews", [("1", 4, 23), ("1", 3, 7), ("1", 2, 9), ("-1", 4, 16), ("0", 4, 16)])
+def test_view_batch_submission_threads_draw_identical_frames(ws, oracle, monkeypatch, threads, slots, nviews):
+    """WS_BATCH_THREADS: every slot of a view batch has a host thread that enqueues ITS frames of a call, in order (round 4:
+    one thread's launch rate is the limit on small scenes -- 13.7 k -> 31.4 k frames/s on the 10 k-Gaussian scene).  The
+    order of the launches on each stream is what the single thread produces: frames bit-identical to the plain renderer's,
+    through repeated calls, ring positions that are not multiples of the slot count, target rings, and an error in the
+    middle of a call comes back to the caller with its text.  "-1" = the default (threads for point clouds up to 512 Ki
+    Gaussians: this scene), "0" = never."""
+    monkeypatch.setenv("WS_BATCH_THREADS", threads)
+    c = ws.Context(0)
+    try:
+        sc = scenes.c2(ws, oracle, n=150_000, viewport=(640, 480))
+        cams = synth.orbit_cameras(32, 640, 480, 640.0, 640.0)
+        views = []
+        for cj in cams[:nviews]:
+            cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, 640, 480)
+            cam.fit_near_far(sc.gpc.aabb)
+            views.append(ws.SplattingArgs(camera=cam, viewport=(640, 480), max_sh_deg=3))
+        pc = ws.PointCloud(c, sc.gpc)
+        r = ws.GaussianRenderer(c, "rgba32float", 3, False)
+        batch = ws.ViewBatch(c, "rgba32float", 3, False, frames_in_flight=slots)
+        bufs = [c.malloc(640 * 480 * 16) for _ in range(nviews)]
+        try:
+            alone = []
+            for v in views:
+                r.prepare(pc, v)
+                r.render(pc)
+                alone.append(r.download_target())
+            for rep in range(3):   # (the ring position advances by nviews per call: every alignment of frame to slot)
+                batch.render(pc, views, bufs, 640 * 16)
+                batch.sync()
+                assert batch.errors() == 0
+                for i in range(nviews):
+                    assert np.array_equal(c.download(bufs[i], (480, 640, 4), np.float32), alone[i]), (rep, i)
+            # a ring of period `slots`: the last writer of every target wins, as with one thread
+            ring = [bufs[i % slots] for i in range(nviews)]
+            batch.render(pc, views, ring, 640 * 16)
+            batch.sync()
+            for k in range(slots):
+                last = max(i for i in range(nviews) if i % slots == k)
+                # (frame i ran on slot (next + i) % slots, not on i % slots: targets that repeat with the period of the
+                #  slots are written by ONE slot each whatever the ring position, so their frames are ordered)
+                assert np.array_equal(c.download(bufs[k], (480, 640, 4), np.float32), alone[last]), k
+            # an invalid view in the middle of a call: the error and its text reach the caller
+            import dataclasses
+            bad = list(views)
+            bad[nviews // 2] = dataclasses.replace(views[nviews // 2], viewport=(0, 0))
+            with pytest.raises(ws.WebSplatError):
+                batch.render(pc, bad, bufs, 640 * 16)
+            batch.sync()
+            batch.render(pc, views, bufs, 640 * 16)   # and the batch still works
+            batch.sync()
+            assert np.array_equal(c.download(bufs[nviews - 1], (480, 640, 4), np.float32), alone[nviews - 1])
+        finally:
+            for b in bufs:
+                c.free(b)
+            batch.close()
+            r.close()
+            pc.close()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("group,slots,compressed", [(2, 4, False), (4, 4, False), (4, 8, False), (3, 3, False), (2, 4, True)])
 def test_view_batch_shared_k1_draws_identical_frames(ws, oracle, monkeypatch, tmp_path, group, slots, compressed):
     """WS_BATCH_K1=g: groups of g consecutive frames of a view batch share ONE K1 launch (k_preprocess_multi: the scene is

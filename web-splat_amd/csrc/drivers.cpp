@@ -9,6 +9,9 @@
 
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -230,12 +233,72 @@ int ws_measure(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, 
 // HIP maps user streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, the null stream included): export
 // GPU_MAX_HW_QUEUES=8 before the process makes its first HIP call, or two of four slots may share a queue and
 // serialise (4800 instead of 5600 frames/s on c2).
+// SUBMISSION THREADS (round 4).  A frame is 22 launches + a memset, 65-90 us of one host thread; a small scene (10 k ... 250 k
+// Gaussians at 800x600) needs less GPU time per frame than that, so one thread enqueueing for four slots is the limit:
+// 13.7 k frames/s on the 10 k scene, 10.9 k at 250 k (profiles/r04/mt_enqueue_probe.txt).  The slots are independent -- own
+// renderer, own stream -- and HIP launches into different streams from different threads in parallel, so every slot gets a
+// worker thread that enqueues ITS frames of a call, in order (the order on each stream, and therefore every frame, is what
+// the single thread produces): 31.4 k and 18.8 k frames/s on the same scenes; nothing changes where the GPU is the limit
+// (1 M Gaussians at 1080p: 7.16 k either way), so the workers are used for point clouds of at most BATCH_THREADS_MAX_POINTS
+// Gaussians (WS_BATCH_THREADS=0 / 1 forces them off / on).  They cost host cores while they run (about one per slot).
+constexpr uint32_t BATCH_THREADS_MAX_POINTS = 512u * 1024u;
 struct ws_view_batch {
     ws_context* ctx = nullptr;
     std::vector<ws_renderer*> renderers;
     std::vector<hipStream_t> streams;
     uint64_t next = 0;  // frames enqueued so far: frame i runs on slot i % frames_in_flight
+
+    // one call's work, shared by the workers (valid while `pending` != 0)
+    struct Job {
+        const ws_pointcloud* pc = nullptr;
+        const ws_splatting_args* views = nullptr;
+        void* const* targets = nullptr;
+        uint32_t num_views = 0;
+        size_t pitch = 0;
+        const float* background = nullptr;
+        uint64_t first = 0;  // value of `next` at the start of the call
+    } job;
+    struct Worker {
+        std::thread th;
+        int rc = WS_OK;
+        std::string err;
+    };
+    std::vector<Worker> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    uint64_t generation = 0;  // bumped per call: a worker runs when it sees a new generation
+    uint32_t pending = 0;     // workers still busy with the current generation
+    bool quit = false;
 };
+
+namespace {
+void batch_worker(ws_view_batch* b, size_t slot) {
+    (void)hipSetDevice(b->ctx->device);
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(b->m);
+            b->cv_work.wait(lk, [&] { return b->quit || b->generation != seen; });
+            if (b->quit) return;
+            seen = b->generation;
+        }
+        const ws_view_batch::Job& j = b->job;
+        const size_t slots = b->renderers.size();
+        int rc = WS_OK;
+        for (uint32_t i = 0; i < j.num_views && rc == WS_OK; ++i) {
+            if ((j.first + i) % slots != slot) continue;
+            rc = ws_renderer_prepare(b->renderers[slot], j.pc, &j.views[i], b->streams[slot]);
+            if (rc == WS_OK) rc = ws_renderer_render(b->renderers[slot], j.pc, j.background, j.targets[i], j.pitch, b->streams[slot]);
+        }
+        b->workers[slot].rc = rc;
+        if (rc) b->workers[slot].err = ws_last_error();  // (the error text is thread-local: hand it to the caller)
+        {
+            std::lock_guard<std::mutex> lk(b->m);
+            if (--b->pending == 0) b->cv_done.notify_one();
+        }
+    }
+}
+}  // namespace
 
 int ws_view_batch_create(ws_context* ctx, ws_color_format format, uint32_t sh_deg, int compressed,
                          uint32_t frames_in_flight, ws_view_batch** out) {
@@ -268,6 +331,13 @@ int ws_view_batch_create(ws_context* ctx, ws_color_format format, uint32_t sh_de
 
 void ws_view_batch_destroy(ws_view_batch* b) {
     if (!b) return;
+    {
+        std::lock_guard<std::mutex> lk(b->m);
+        b->quit = true;
+    }
+    b->cv_work.notify_all();
+    for (auto& w : b->workers)
+        if (w.th.joinable()) w.th.join();
     (void)hipDeviceSynchronize();
     for (ws_renderer* r : b->renderers) ws_renderer_destroy(r);
     for (hipStream_t s : b->streams) (void)hipStreamDestroy(s);
@@ -284,6 +354,37 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
     // once per frame); groups are aligned to the slot ring, so with slots = 2 g one group's K1 overlaps the other's blends
     size_t group = (size_t)b->ctx->batch_k1;
     if (group > 1 && slots % group != 0) group = 1;
+    // every slot's frames enqueued by its own thread (see ws_view_batch): small scenes, enough frames to be worth a wake-up
+    const int want_threads = b->ctx->batch_threads;
+    if (group == 1 && slots >= 2 && num_views >= 2 * slots && want_threads != 0 &&
+        (want_threads > 0 || pc->num_points <= BATCH_THREADS_MAX_POINTS)) {
+        if (b->workers.empty()) {
+            b->workers.resize(slots);
+            for (size_t s2 = 0; s2 < slots; ++s2) b->workers[s2].th = std::thread(batch_worker, b, s2);
+        }
+        {
+            std::lock_guard<std::mutex> lk(b->m);
+            b->job.pc = pc;
+            b->job.views = views;
+            b->job.targets = d_targets;
+            b->job.num_views = num_views;
+            b->job.pitch = row_pitch_bytes;
+            b->job.background = background;
+            b->job.first = b->next;
+            for (auto& w : b->workers) w.rc = WS_OK;
+            b->pending = (uint32_t)slots;
+            ++b->generation;
+        }
+        b->cv_work.notify_all();
+        {
+            std::unique_lock<std::mutex> lk(b->m);
+            b->cv_done.wait(lk, [&] { return b->pending == 0; });
+        }
+        b->next += num_views;
+        for (auto& w : b->workers)
+            if (w.rc) return fail(w.rc, w.err);
+        return WS_OK;
+    }
     uint32_t i = 0;
     while (i < num_views) {
         const size_t k = (size_t)(b->next % slots);

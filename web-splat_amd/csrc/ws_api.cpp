@@ -400,6 +400,7 @@ int ws_context_create(int hip_device, ws_context** out) {
         ctx->bin_request = !bs ? BIN_AUTO : (std::strcmp(bs, "1") == 0 ? BIN_ALWAYS : (std::strcmp(bs, "0") == 0 ? BIN_NEVER : BIN_AUTO));
     }
     ctx->batch_k1 = env_int("WS_BATCH_K1", 1);
+    ctx->batch_threads = env_int("WS_BATCH_THREADS", -1);
     if (ctx->batch_k1 < 1 || ctx->batch_k1 > K1_MAX_VIEWS) ctx->batch_k1 = 1;
     {
         const char* fm = std::getenv("WS_FOOTPRINT");  // ellipse | rect (default)

@@ -415,6 +415,8 @@ struct ws_context {
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
     int footprint = 0;        // WS_FOOTPRINT=ellipse: FP_ELLIPSE (the default is FP_RECT_PACKED, FP_RECT_COUNT for wide viewports)
     int batch_k1 = 1;         // WS_BATCH_K1=n: a view batch runs K1 once for groups of n frames (1 = every frame its own K1)
+    int batch_threads = -1;   // WS_BATCH_THREADS: a view batch enqueues every slot's frames from its own host thread; -1 = for
+                              //   point clouds of at most 512 Ki Gaussians (where one thread's launch rate is the limit), 0 / 1 = never / always
     bool tile_sort_wide = false; // WS_TILE_SORT=wide: single-pass tile-id sort up to 2048 binning tiles (launch_tile_sort_wide)
     int bin_request = 1;      // WS_BIN_SHIFT=0 | auto (default) | 1: BinRequest for frames that can use coarse binning
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
