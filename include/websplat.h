@@ -424,7 +424,10 @@ int ws_measure(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, 
  * The reference renders one view at a time on one queue (lib.rs:422-431, bin/measure.rs:98-146).  A view batch keeps
  * `frames_in_flight` frames going at once: frame i of the batch's life runs on renderer + HIP stream i mod
  * frames_in_flight (private scratch each; the point cloud is shared).  ws_view_batch_render only ENQUEUES; the caller
- * observes completion with ws_view_batch_sync.  d_targets[i] receives view i (device memory, format of the batch);
+ * observes completion with ws_view_batch_sync.  For point clouds of at most 512 Ki Gaussians -- where the GPU needs less time
+ * per frame than one host thread needs to enqueue it -- every slot's frames are enqueued by a worker thread of the batch (the
+ * order on each stream is unchanged; the call returns when everything is enqueued; WS_BATCH_THREADS=0 / 1 forces it off / on).
+ * d_targets[i] receives view i (device memory, format of the batch);
  * targets may repeat with period frames_in_flight (a ring), since a slot's frames are ordered on its stream. */
 typedef struct ws_view_batch ws_view_batch;
 int ws_view_batch_create(ws_context* ctx, ws_color_format format, uint32_t sh_deg, int compressed,
