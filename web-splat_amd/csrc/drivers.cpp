@@ -358,32 +358,50 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
     const int want_threads = b->ctx->batch_threads;
     if (group == 1 && slots >= 2 && num_views >= 2 * slots && want_threads != 0 &&
         (want_threads > 0 || pc->num_points <= BATCH_THREADS_MAX_POINTS)) {
-        if (b->workers.empty()) {
-            b->workers.resize(slots);
-            for (size_t s2 = 0; s2 < slots; ++s2) b->workers[s2].th = std::thread(batch_worker, b, s2);
+        bool have_workers = !b->workers.empty();
+        if (!have_workers) {
+            try {  // (no C++ exception crosses the ABI: a host that cannot start threads keeps the one-thread path)
+                std::vector<ws_view_batch::Worker> ws_(slots);
+                b->workers.swap(ws_);
+                for (size_t s2 = 0; s2 < slots; ++s2) b->workers[s2].th = std::thread(batch_worker, b, s2);
+                have_workers = true;
+            } catch (...) {
+                {
+                    std::lock_guard<std::mutex> lk(b->m);
+                    b->quit = true;
+                }
+                b->cv_work.notify_all();
+                for (auto& w : b->workers)
+                    if (w.th.joinable()) w.th.join();
+                b->workers.clear();
+                b->quit = false;
+                b->ctx->batch_threads = 0;
+            }
         }
-        {
-            std::lock_guard<std::mutex> lk(b->m);
-            b->job.pc = pc;
-            b->job.views = views;
-            b->job.targets = d_targets;
-            b->job.num_views = num_views;
-            b->job.pitch = row_pitch_bytes;
-            b->job.background = background;
-            b->job.first = b->next;
-            for (auto& w : b->workers) w.rc = WS_OK;
-            b->pending = (uint32_t)slots;
-            ++b->generation;
+        if (have_workers) {
+            {
+                std::lock_guard<std::mutex> lk(b->m);
+                b->job.pc = pc;
+                b->job.views = views;
+                b->job.targets = d_targets;
+                b->job.num_views = num_views;
+                b->job.pitch = row_pitch_bytes;
+                b->job.background = background;
+                b->job.first = b->next;
+                for (auto& w : b->workers) w.rc = WS_OK;
+                b->pending = (uint32_t)slots;
+                ++b->generation;
+            }
+            b->cv_work.notify_all();
+            {
+                std::unique_lock<std::mutex> lk(b->m);
+                b->cv_done.wait(lk, [&] { return b->pending == 0; });
+            }
+            b->next += num_views;
+            for (auto& w : b->workers)
+                if (w.rc) return fail(w.rc, w.err);
+            return WS_OK;
         }
-        b->cv_work.notify_all();
-        {
-            std::unique_lock<std::mutex> lk(b->m);
-            b->cv_done.wait(lk, [&] { return b->pending == 0; });
-        }
-        b->next += num_views;
-        for (auto& w : b->workers)
-            if (w.rc) return fail(w.rc, w.err);
-        return WS_OK;
     }
     uint32_t i = 0;
     while (i < num_views) {
