@@ -77,7 +77,7 @@ int main() {
     CK(hipMalloc(&err, 4));
     // where do consecutive workgroups land?  (the barrier groups by blockIdx & 7; k_sort's tiles assume b % 8 = XCD)
     {
-        CK(hipMemset(a, 0xFF, 1024 * 4));
+        CK(hipMemsetAsync(a, 0xFF, 1024 * 4, st));  // (stream-ordered: `st` does not synchronise with the NULL stream)
         hipLaunchKernelGGL(k_xcc, dim3(256), dim3(256), 0, st, a);
         CK(hipStreamSynchronize(st));
         std::vector<uint32_t> h(256);
