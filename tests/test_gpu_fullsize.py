@@ -497,12 +497,16 @@ def test_c3_full_image_vs_oracle(ws, ctx, oracle):
     _SCENE_CACHE.clear()
 
 
-def test_frame_graph_replay_equals_launch_by_launch(ws, oracle, monkeypatch):
+@pytest.mark.parametrize("depth_sort", ["scan", "onesweep"])
+def test_frame_graph_replay_equals_launch_by_launch(ws, oracle, monkeypatch, depth_sort):
     """prepare() on a real stream replays a captured frame graph (one graph launch + one kernel-argument update per
     frame, a ring of executable graphs); twelve frames enqueued back to back on ONE stream -- three times the ring --
     must give, view by view, the images of the launch-by-launch path (WS_GRAPH=0), and so must a second point cloud and
-    a second viewport on the same renderer (the graph is re-captured)."""
+    a second viewport on the same renderer (the graph is re-captured).  `onesweep`: the fat-tile depth sort's epoch-tagged
+    count rows need the frame's look-back epoch, which a replayed graph takes from device memory (FrameCounters::epoch,
+    written by K1) instead of from the captured kernel argument."""
     import ctypes as C
+    monkeypatch.setenv("WS_DEPTH_SORT", depth_sort)
     hip = C.CDLL("libamdhip64.so")
     cams = synth.orbit_cameras(12, 800, 600, 800.0, 800.0)
     results = {}
