@@ -1046,22 +1046,6 @@ int launch_empty(hipStream_t stream) {
     return WS_OK;
 }
 
-// The per-frame clear of the zero arena as a plain kernel launch (16-byte stores): hipMemsetAsync goes through the runtime's
-// blit manager, which costs the enqueueing thread about twice a kernel launch (profiles/r04/frame_clear_ab.txt).
-namespace {
-__global__ __launch_bounds__(256) void k_frame_clear(uint4* __restrict__ p, uint32_t n16) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-}  // namespace
-int launch_frame_clear(void* arena, size_t bytes, hipStream_t stream) {
-    const uint32_t n16 = (uint32_t)(bytes / 16u);  // (the arena is allocated in whole 16-byte units)
-    if (n16 == 0u) return WS_OK;
-    hipLaunchKernelGGL(k_frame_clear, dim3((n16 + 255u) / 256u), dim3(256), 0, stream, reinterpret_cast<uint4*>(arena), n16);
-    WS_HIP(hipGetLastError());
-    return WS_OK;
-}
-
 uint32_t bin_prefix_blocks(uint32_t max_points) {
     const uint32_t items = BIN_THREADS * BIN_IPT;
     return (max_points + items - 1) / items;

@@ -306,7 +306,7 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     if ((rc = dmalloc(&r->debug_consumed, (size_t)r->tiles_x * r->tiles_y))) return rc;
     if ((rc = dmalloc(&r->debug_walked, (size_t)r->tiles_x * r->tiles_y * 17))) return rc;
     // the per-frame zero arena: counters | depth histograms | tile histograms | tile ranges
-    r->zero_bytes = (sizeof(FrameZero) + (size_t)r->tiles_x * r->tiles_y * sizeof(uint2) + 15u) & ~(size_t)15u;  // whole 16-B units (k_frame_clear)
+    r->zero_bytes = sizeof(FrameZero) + (size_t)r->tiles_x * r->tiles_y * sizeof(uint2);
     WS_HIP(hipMalloc(reinterpret_cast<void**>(&r->zero), r->zero_bytes));
     WS_HIP(hipMemset(r->zero, 0, r->zero_bytes));
     r->counters = &r->zero->counters;
@@ -401,7 +401,6 @@ int ws_context_create(int hip_device, ws_context** out) {
     }
     ctx->batch_k1 = env_int("WS_BATCH_K1", 1);
     ctx->batch_threads = env_int("WS_BATCH_THREADS", -1);
-    if (const char* fc = std::getenv("WS_FRAME_CLEAR")) ctx->frame_clear_kernel = std::strcmp(fc, "memset") == 0 ? 0 : 1;
     if (ctx->batch_k1 < 1 || ctx->batch_k1 > K1_MAX_VIEWS) ctx->batch_k1 = 1;
     {
         const char* fm = std::getenv("WS_FOOTPRINT");  // ellipse | rect (default)
@@ -835,11 +834,7 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     if (phase != FRAME_REST) {
         // GPURSSorter::record_reset_indirect_buffer (gpu_rs.rs:720-727): keys_size = 0, dispatch = 0 -- here ONE
         // memset clears the counters, every ticket, both sorts' digit histograms and the tile ranges
-        if (r->ctx->frame_clear_kernel) {
-            if ((rc = launch_frame_clear(r->zero, r->zero_bytes, stream))) return rc;
-        } else {
-            WS_HIP(hipMemsetAsync(r->zero, 0, r->zero_bytes, stream));
-        }
+        WS_HIP(hipMemsetAsync(r->zero, 0, r->zero_bytes, stream));
         if (phase == FRAME_CLEAR) return WS_OK;
         if (km) km->begin(stream, true);
         if (r->timers) WS_HIP(hipEventRecord(r->ev[0], stream));

@@ -368,7 +368,6 @@ struct BlendParams {
 };
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
 int launch_empty(hipStream_t stream);
-int launch_frame_clear(void* arena, size_t bytes, hipStream_t stream);  // bytes: a multiple of 16
 int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, float tile_y0, uint32_t qw, uint32_t qh,
                       float rec[10], uint32_t* mask);
 
@@ -416,7 +415,6 @@ struct ws_context {
     int blend_lds_pad_kb = 0; // WS_BLEND_LDS_PAD_KB (tuning): unused dynamic LDS per blend workgroup
     int footprint = 0;        // WS_FOOTPRINT=ellipse: FP_ELLIPSE (the default is FP_RECT_PACKED, FP_RECT_COUNT for wide viewports)
     int batch_k1 = 1;         // WS_BATCH_K1=n: a view batch runs K1 once for groups of n frames (1 = every frame its own K1)
-    int frame_clear_kernel = 1; // WS_FRAME_CLEAR=memset: the per-frame arena clear through hipMemsetAsync instead of k_frame_clear
     int batch_threads = -1;   // WS_BATCH_THREADS: a view batch enqueues every slot's frames from its own host thread; -1 = for
                               //   point clouds of at most 512 Ki Gaussians (where one thread's launch rate is the limit), 0 / 1 = never / always
     bool tile_sort_wide = false; // WS_TILE_SORT=wide: single-pass tile-id sort up to 2048 binning tiles (launch_tile_sort_wide)
