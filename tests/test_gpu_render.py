@@ -335,60 +335,6 @@ def test_switched_paths_draw_the_default_image_bit_for_bit(ws, ctx, oracle, env,
         c.close()
 
 
-@pytest.mark.parametrize("kind", ["c2", "c3", "hd", "odd"])
-def test_two_pixels_per_lane_blend_draws_the_same_image(ws, ctx, oracle, kind, monkeypatch):
-    """WS_BLEND_PPL=2 (k_blend2): a 32x32 tile composited by eight waves, each owning two quadrants (two pixels per lane),
-    four tiles resident per CU instead of two.  The same records reach the same pixels in the same order; a wave stops when
-    BOTH its quadrants are saturated, so the granularity of the early-out differs: the image equals the default path's within
-    2 x T_MIN and the oracle's within the stated tolerance, on multi-tile splats, pixel-sized splats, a coarse-binned 1080p
-    frame and a viewport that is not a multiple of the tile (rows 16..31 of the last tile row partly outside)."""
-    if kind == "c2":
-        rows, viewport = synth.scene_c2(n=200_000, seed=21), (1283, 721)
-        cj = synth.orbit_cameras(8, viewport[0], viewport[1], 900.0, 900.0)[3]
-    elif kind == "hd":
-        rows, viewport = synth.scene_c2(n=400_000, seed=23), (1920, 1080)
-        cj = synth.orbit_cameras(8, viewport[0], viewport[1], 1920.0, 1920.0)[5]
-    elif kind == "odd":
-        rows, viewport = synth.scene_c1(n=20_000, seed=24), (333, 210)
-        cj = synth.camera_c1(*viewport)
-        cj.fx = cj.fy = 333.0
-    else:
-        rows, viewport = synth.scene_c3(n=300_000, seed=22), (640, 480)
-        cj = synth.look_at_camera(0, [0.0, 0.0, -9.0], [0, 0, 0], viewport[0], viewport[1], 520.0, 520.0)
-    sc = scenes.Scene(ws, oracle, rows, 3, cj, viewport)
-    bg = (0.1, 0.2, 0.3, 1.0)
-    pc, want, st0 = _render(ws, ctx, sc, background=bg)
-    pc.close()
-    monkeypatch.setenv("WS_BLEND_PPL", "2")
-    c = ws.Context(0)
-    try:
-        pc = ws.PointCloud(c, sc.gpc)
-        for fmt in ("rgba32float", "rgba16float", "rgba8unorm"):
-            r = ws.GaussianRenderer(c, fmt, 3, False)
-            try:
-                for frame in range(2):
-                    r.prepare(pc, sc.args)
-                    r.render(pc, background=bg)
-                    img = r.download_target()
-                    st = r.frame_stats()
-                    assert st["num_visible"] == st0["num_visible"] and st["num_tile_entries"] == st0["num_tile_entries"]
-                    assert st["overflow"] == 0 and r.errors()[0] == 0
-                    if fmt == "rgba32float":
-                        assert float(np.abs(img - want).max()) <= 2.0 / 16384.0 * 1.6 + 1e-6, (kind, frame, float(np.abs(img - want).max()))
-                    elif fmt == "rgba16float":
-                        assert float(np.abs(img.astype(np.float32) - want).max()) <= 2e-3 + 2.0 / 16384.0 * 1.6
-                    else:
-                        assert float(np.abs(img.astype(np.float32) / 255.0 - np.clip(want, 0, 1)).max()) <= 0.5 / 255 + 2.0 / 16384.0 * 1.6 + 1e-6
-                if fmt == "rgba32float":
-                    ref, ofr_ = sc.oracle_image(pc, background=bg)
-                    _assert_close(img, ref, proof=sc.proof(ofr_, bg))
-            finally:
-                r.close()
-        pc.close()
-    finally:
-        c.close()
-
-
 def test_many_tiles_32bit_keys(ws, oracle, monkeypatch):
     """65536 tiles (4096x4096 at 16x16): the tile sort switches from 16-bit to 32-bit tile ids, two 8-bit passes."""
     monkeypatch.setenv("WS_TILE_SHAPE", "2x2")

@@ -726,149 +726,6 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     if (DMA) wait_vector_loads();  // a prefetch the tile did not consume must have landed before the workgroup's LDS is released
 }
 
-// ---- k_blend2: a 32x32 tile by EIGHT waves, two quadrants (two pixels per lane) each (WS_BLEND_PPL=2; round 4 experiment) ----
-// k_blend gives every 8x8 quadrant of a 32x32 tile its own wave: 16 waves per tile, two tiles resident per CU, and for the
-// median tile half of a workgroup's life is the start-up chain (range -> entry indices -> Splat records) with one other
-// tile to hide it behind.  Here a wave owns the quadrants (qx, qy) and (qx, qy + 2) -- lane l composites pixel (x, y) and
-// pixel (x, y + 16) -- so a tile is a 512-thread workgroup and FOUR tiles are resident per CU (same list, same staging, same
-// D).  A wave's list holds the records that reach either of its quadrants, each entry flagged with which (the record is
-// wave-uniform, so "composite pixel A / pixel B" are scalar branches: a record that reaches one quadrant costs one
-// evaluation, as in k_blend); the record's two LDS reads and the loop are shared by both pixels; compaction and barriers
-// involve half the waves.
-template <int FORMAT>
-__global__ __launch_bounds__(512, 8) void k_blend2(const BlendParams p) {
-    constexpr int QW = 4, QH = 4, NW = 8, STAGE = 512, SLOTS = STAGE + 1, TW = 32, TH = 32, LCAP = 512;  // (512 threads: all stage)
-    __shared__ float4 s_rec[2 * SLOTS];
-    __shared__ __attribute__((aligned(16))) uint16_t s_m[STAGE];
-    __shared__ __attribute__((aligned(16))) uint32_t s_list[NW][LCAP + 16];
-
-    if (blockIdx.x == 0 && threadIdx.x == 0 && p.sticky) {
-        const uint32_t bits = p.counters->overflow;
-        if (bits) {
-            atomicOr(p.sticky, bits);
-            if (bits & 1u) atomicMax(p.sticky + 1, p.counters->entries_needed);
-        }
-    }
-    const BlendShape shape = blend_shape(QW, QH);
-    const BlendBlock blk = blend_block_of(blockIdx.x, p.tiles_x, p.tiles_y, shape, 0u);
-    if (!blk.valid) return;  // block-uniform
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int qx = wave & 3, qya = wave >> 2, qyb = qya + 2;
-    const float lx = (float)(qx * 8 + (lane & 7)) + 0.5f;
-    const float lya = (float)(qya * 8 + (lane >> 3)) + 0.5f;
-    const float lyb = lya + 16.0f;
-    const uint32_t bita = 1u << (qya * QW + qx), bitb = 1u << (qyb * QW + qx);
-    const uint32_t tx = (blk.bx << shape.tbx_log2) + (blk.w & ((1u << shape.tbx_log2) - 1u));
-    const uint32_t ty = (blk.by << shape.tby_log2) + (blk.w >> shape.tbx_log2);
-    if (tx >= p.tiles_x || ty >= p.tiles_y) return;  // block-uniform
-    uint2 range = p.tile_ranges[tile_list_index(p, tx, ty)];
-    range.x = range.y ? 0xFFFFFFFFu - range.x : 0u;
-    if (tid == 0) {
-        s_rec[STAGE] = make_float4(0.0f, 0.0f, 1.0e9f, 0.0f);
-        s_rec[SLOTS + STAGE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    const float W = (float)p.width, H = (float)p.height;
-    uint32_t* my_list = s_list[wave];
-    const uint32_t px = tx * TW + qx * 8 + (lane & 7);
-    const uint32_t pya = ty * TH + qya * 8 + (lane >> 3);
-    float Ta = (px < p.width && pya < p.height) ? 1.0f : 0.0f, cra = 0.0f, cga = 0.0f, cba = 0.0f;
-    float Tb = (px < p.width && pya + 16u < p.height) ? 1.0f : 0.0f, crb = 0.0f, cgb = 0.0f, cbb = 0.0f;
-    const float tile_x0 = (float)(tx * TW), tile_y0 = (float)(ty * TH);
-
-    RawSplat raw = {{0u, 0u, 0u, 0u}, 0u};
-    if (range.y > range.x) raw = blend_fetch_raw<STAGE>(p, range, range.y, tid);
-    uint32_t hi = range.y;
-    uint32_t idx_next = 0u;
-    if (range.y > range.x)
-        idx_next = blend_entry_idx<STAGE>(p, range, range.y - range.x > (uint32_t)STAGE ? range.y - (uint32_t)STAGE : range.x, tid);
-    while (hi > range.x) {
-        const uint32_t nb = (hi - range.x) < (uint32_t)STAGE ? (hi - range.x) : (uint32_t)STAGE;
-        const uint32_t hi_next = hi - nb;
-        {
-            uint32_t mask = 0u;
-            if ((uint32_t)tid < nb) {
-                const stage::Staged s = stage::decode<QW, QH>(raw.a.x, raw.a.y, raw.a.z, raw.a.w, raw.w4, W, H, tile_x0, tile_y0, CUT_A2);
-                mask = s.mask;
-                s_rec[tid] = make_float4(s.i00, s.i01, s.c0, s.i10);
-                s_rec[SLOTS + tid] = make_float4(s.i11, s.c1, __uint_as_float(raw.a.w), __uint_as_float(raw.w4));
-            }
-            s_m[((uint32_t)tid & 63u) * (LCAP / 64) + ((uint32_t)tid >> 6)] = (uint16_t)mask;
-            raw = blend_gather(p, idx_next);  // unconditional (clamped address): see k_blend
-            idx_next = blend_entry_idx<STAGE>(p, range, hi_next - range.x > (uint32_t)STAGE ? hi_next - (uint32_t)STAGE : range.x, tid);
-        }
-        __syncthreads();
-        if (__ballot(Ta >= T_MIN || Tb >= T_MIN) != 0ull) {
-            const uint2* mp = reinterpret_cast<const uint2*>(s_m + (uint32_t)lane * (LCAP / 64));
-            uint32_t n = 0;
-            uint32_t slot16 = (uint32_t)lane * 16u;
-            asm volatile("" : "+v"(slot16));
-#pragma unroll
-            for (int h = 0; h < LCAP / 256; ++h) {
-                const uint2 mm = mp[h];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = h * 4 + q;
-                    const uint32_t word = ((q & 2) ? mm.y : mm.x) >> ((q & 1) * 16);
-                    const uint32_t fl = ((word & bita) ? 1u : 0u) | ((word & bitb) ? 2u : 0u);
-                    const unsigned long long bl = __ballot(fl != 0u);
-                    const uint32_t pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
-                    if (fl) my_list[pos] = (slot16 + (uint32_t)r * 1024u) | fl;  // byte offset of the record (16-B units) | which pixels
-                    n += (uint32_t)__popcll(bl);
-                }
-            }
-            if (n > 0u) {
-                if (lane < 4 && ((n + (uint32_t)lane) >> 2) == (n >> 2) && (n & 3u)) my_list[n + lane] = (uint32_t)STAGE * 16u;  // null record, no pixel
-                const uint32_t n4 = (n + 3u) >> 2;
-                const uint4* lp = reinterpret_cast<const uint4*>(my_list);
-                uint4 o = lp[0];
-                uint4 on = lp[n4 > 1u ? 1u : 0u];
-                BlendRec cur = blend_load_rec<SLOTS>(s_rec, o.x & ~15u);
-                for (uint32_t g = 0; g < n4; ++g) {
-                    const BlendRec r1 = blend_load_rec<SLOTS>(s_rec, o.y & ~15u);
-                    {
-                        const uint32_t f = __builtin_amdgcn_readfirstlane(o.x);
-                        if (f & 1u) blend_composite(cur, lx, lya, Ta, cra, cga, cba);
-                        if (f & 2u) blend_composite(cur, lx, lyb, Tb, crb, cgb, cbb);
-                    }
-                    const BlendRec r2 = blend_load_rec<SLOTS>(s_rec, o.z & ~15u);
-                    {
-                        const uint32_t f = __builtin_amdgcn_readfirstlane(o.y);
-                        if (f & 1u) blend_composite(r1, lx, lya, Ta, cra, cga, cba);
-                        if (f & 2u) blend_composite(r1, lx, lyb, Tb, crb, cgb, cbb);
-                    }
-                    const BlendRec r3 = blend_load_rec<SLOTS>(s_rec, o.w & ~15u);
-                    {
-                        const uint32_t f = __builtin_amdgcn_readfirstlane(o.z);
-                        if (f & 1u) blend_composite(r2, lx, lya, Ta, cra, cga, cba);
-                        if (f & 2u) blend_composite(r2, lx, lyb, Tb, crb, cgb, cbb);
-                    }
-                    cur = blend_load_rec<SLOTS>(s_rec, on.x & ~15u);
-                    {
-                        const uint32_t f = __builtin_amdgcn_readfirstlane(o.w);
-                        if (f & 1u) blend_composite(r3, lx, lya, Ta, cra, cga, cba);
-                        if (f & 2u) blend_composite(r3, lx, lyb, Tb, crb, cgb, cbb);
-                    }
-                    if (__ballot(Ta >= T_MIN || Tb >= T_MIN) == 0ull) break;
-                    o = on;
-                    on = lp[g + 2u < n4 ? g + 2u : n4 - 1u];
-                }
-            }
-        }
-        hi = hi_next;
-        if (__syncthreads_and((Ta < T_MIN && Tb < T_MIN) ? 1 : 0)) break;
-    }
-    {
-        const uint32_t sx = tx * TW + (uint32_t)lx, sya = ty * TH + (uint32_t)lya;
-        if (sx < p.width && sya < p.height)
-            store_pixel<FORMAT>(p, sx, sya, cra + p.background[0] * Ta, cga + p.background[1] * Ta, cba + p.background[2] * Ta,
-                                (1.0f - Ta) + p.background[3] * Ta);
-        if (sx < p.width && sya + 16u < p.height)
-            store_pixel<FORMAT>(p, sx, sya + 16u, crb + p.background[0] * Tb, cgb + p.background[1] * Tb, cbb + p.background[2] * Tb,
-                                (1.0f - Tb) + p.background[3] * Tb);
-    }
-}
-
 // ---- k_blend_q: one WAVE per 8x8 quadrant, no LDS, no barriers -------------------------------------------
 // Measured on MI355X (profiles/): the 256-thread kernel above is bound by the serial latency of one tile (two
 // barriers per 256-splat batch, three dependent LDS reads per splat), not by VALU (26 % busy) or LDS bandwidth.
@@ -1310,19 +1167,6 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
                 break;
             default:
                 return fail(WS_ERR_INVALID, "blend: unknown colour format");
-        }
-        WS_HIP(hipGetLastError());
-        return WS_OK;
-    }
-    if (p.ppl == 2 && p.qw == 4u && p.qh == 4u && p.range_row_shift == 0u && !p.dma && !p.debug_consumed && !p.debug_walked &&
-        (p.tpw_log2 >= 0 ? p.tpw_log2 == 0 : blend_tpw_log2(p.tiles_x, p.tiles_y, blend_shape(4, 4)) == 0u)) {
-        // WS_BLEND_PPL=2: eight waves per 32x32 tile, two pixels per lane (k_blend2)
-        const uint32_t grid = blend_grid_blocks(p.tiles_x, p.tiles_y, blend_shape(4, 4), 0u);
-        switch (p.format) {
-            case WS_FORMAT_RGBA32_FLOAT: hipLaunchKernelGGL(k_blend2<WS_FORMAT_RGBA32_FLOAT>, dim3(grid), dim3(512), 0, stream, p); break;
-            case WS_FORMAT_RGBA16_FLOAT: hipLaunchKernelGGL(k_blend2<WS_FORMAT_RGBA16_FLOAT>, dim3(grid), dim3(512), 0, stream, p); break;
-            case WS_FORMAT_RGBA8_UNORM: hipLaunchKernelGGL(k_blend2<WS_FORMAT_RGBA8_UNORM>, dim3(grid), dim3(512), 0, stream, p); break;
-            default: return fail(WS_ERR_INVALID, "blend: unknown colour format");
         }
         WS_HIP(hipGetLastError());
         return WS_OK;

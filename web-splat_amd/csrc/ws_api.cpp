@@ -395,7 +395,6 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->use_graph = env_int("WS_GRAPH", 0);
     ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
     ctx->blend_dma = env_int("WS_BLEND_DMA", 0) ? 1 : 0;
-    ctx->blend_ppl = env_int("WS_BLEND_PPL", 1) == 2 ? 2 : 1;
     {
         const char* bs = std::getenv("WS_BIN_SHIFT");  // 0 | 1 | auto (default): binning at twice the blend's tile size
         ctx->bin_request = !bs ? BIN_AUTO : (std::strcmp(bs, "1") == 0 ? BIN_ALWAYS : (std::strcmp(bs, "0") == 0 ? BIN_NEVER : BIN_AUTO));
@@ -1215,7 +1214,6 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
     bp.lds_pad_kb = r->ctx->blend_lds_pad_kb;
     bp.dma = r->ctx->blend_dma;
-    bp.ppl = r->ctx->blend_ppl;
     bp.num_cus = r->ctx->num_cus;
     bp.range_row_shift = 0;
     bp.bin_tiles_x = r->tiles_x;

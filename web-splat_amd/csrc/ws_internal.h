@@ -357,7 +357,6 @@ struct BlendParams {
     int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
     int lds_pad_kb;             // tuning: extra (unused) dynamic LDS per workgroup, limits workgroups per CU
     int dma;                    // stage the Splat records with gfx950's LDS-DMA (global_load_lds) instead of through VGPRs
-    int ppl;                    // pixels per lane: 2 = k_blend2 (eight waves per 32x32 tile; 4x4 tiles, one tile per workgroup)
     int num_cus;
     uint32_t bin_tiles_x;       // binning tiles per row at the blend's tile size (the frame may bin at twice that: FrameCounters::bin_shift)
     uint32_t range_row_shift;   // 0, or 1 = "split" mode: tiles_y counts HALF binning tiles (32x16 px, 8 waves) and the list of
@@ -421,7 +420,6 @@ struct ws_context {
     bool tile_sort_wide = false; // WS_TILE_SORT=wide: single-pass tile-id sort up to 2048 binning tiles (launch_tile_sort_wide)
     int bin_request = 1;      // WS_BIN_SHIFT=0 | auto (default) | 1: BinRequest for frames that can use coarse binning
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
-    int blend_ppl = 1;        // WS_BLEND_PPL=2: k_blend2, eight waves per 32x32 tile with two pixels per lane (round 4)
     int blend_split = -1;     // WS_BLEND_SPLIT: 4x4 binning tiles composited by two 4x2 workgroups each; -1 = when tiles < 2 x CUs
     int num_cus = 256;
     int use_graph = 0;        // WS_GRAPH=1: prepare() on a real stream replays a captured frame graph instead of enqueueing 22
