@@ -335,6 +335,88 @@ def test_switched_paths_draw_the_default_image_bit_for_bit(ws, ctx, oracle, env,
         c.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"WS_DEPTH_SORT": "onesweep"}, {"WS_DEPTH_SORT": "coop"}, {"WS_TILE_SORT": "wide"},
+                                 {"WS_BLEND_VARIANT": "1"}])
+def test_degenerate_frames(ws, oracle, env, monkeypatch):
+    """The ragged ends of the frame: a camera that looks AWAY from the cloud (nothing visible: every kernel behind K1 runs on a
+    device-side count of zero), a one-Gaussian cloud, and a cloud whose visible splats all sit in the 1.2x cull margin with
+    their footprints off screen (V > 0, no tile entry at all).  The image is the clear colour exactly where nothing is drawn,
+    the counters say so, no error bit is set, and a normal frame on the same renderer afterwards is unharmed -- in every
+    depth-sort / tile-sort / blend form."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = ws.Context(0)
+    bg = (0.25, 0.5, 0.125, 1.0)
+    try:
+        sc = scenes.c1(ws, oracle, n=5000, viewport=(320, 240), seed=31)
+        pc = ws.PointCloud(c, sc.gpc)
+        r = ws.GaussianRenderer(c, "rgba32float", 3, False)
+        try:
+            import dataclasses
+            # 1. looking away: the same camera turned by 180 degrees about the y axis
+            cam = sc.args.camera
+            away_cj = synth.look_at_camera(0, [0.0, 0.0, -3.0], [0.0, 0.0, -9.0], 320, 240, 320.0, 320.0)
+            away = ws.PerspectiveCamera.from_scene_camera(away_cj.position, away_cj.rotation, away_cj.fx, away_cj.fy, 320, 240)
+            away.znear, away.zfar = cam.znear, cam.zfar
+            args_away = dataclasses.replace(sc.args, camera=away)
+            r.prepare(pc, args_away)
+            r.render(pc, background=bg)
+            img = r.download_target()
+            st = r.frame_stats()
+            assert st["num_visible"] == 0 and st["num_tile_entries"] == 0 and st["overflow"] == 0 and r.errors()[0] == 0
+            assert np.array_equal(img, np.broadcast_to(np.array(bg, dtype=np.float32), img.shape))
+            # 2. a normal frame afterwards, then the empty one again (scratch and epochs are reused)
+            r.prepare(pc, sc.args)
+            r.render(pc, background=bg)
+            good = r.download_target()
+            ref, ofr_ = sc.oracle_image(pc, background=bg)
+            _assert_close(good, ref, proof=sc.proof(ofr_, bg))
+            r.prepare(pc, args_away)
+            r.render(pc, background=bg)
+            assert np.array_equal(r.download_target(), img)
+        finally:
+            r.close()
+            pc.close()
+        # 3. one Gaussian
+        row = np.zeros((1, 62), dtype=np.float32)
+        row[0, 0:3] = [0.5, 0.0, 0.0]
+        row[0, 6:9] = [1.0, 0.5, -0.5]
+        row[0, 54] = 2.0
+        row[0, 55:58] = np.log(0.05)
+        row[0, 58:62] = [1, 0, 0, 0]
+        cj = synth.look_at_camera(0, [0.5, 0.0, -2.0], [0.5, 0, 0], 128, 128, 256.0, 256.0)
+        one = scenes.Scene(ws, oracle, row, 3, cj, (128, 128))
+        pc1, img1, st1 = _render(ws, c, one, background=bg)
+        try:
+            assert st1["num_visible"] == 1 and st1["num_tile_entries"] >= 1
+            ref1, ofr1 = one.oracle_image(pc1, background=bg)
+            _assert_close(img1, ref1, proof=one.proof(ofr1, bg))
+        finally:
+            pc1.close()
+        # 4. visible by the cull test (centre within 1.2 x the clip bounds) but every footprint off screen: small splats just
+        #    beyond the right edge of the image
+        rows = synth.scene_c1(n=2000, seed=32)
+        rows[:, 0] = 1.62 + 0.05 * rows[:, 0]     # x: a slab at 1.08..1.17 x the half-width at the cloud's depth (z = 0, camera at -3, tan = 0.5)
+        rows[:, 1] *= 0.5
+        rows[:, 2] *= 0.05
+        rows[:, 55:58] = np.log(0.002)
+        cj = synth.camera_c1(320, 240)
+        cj.fx = cj.fy = 320.0
+        edge = scenes.Scene(ws, oracle, rows, 3, cj, (320, 240))
+        pce, imge, ste = _render(ws, c, edge, background=bg)
+        try:
+            assert ste["overflow"] == 0
+            refe, ofre = edge.oracle_image(pce, background=bg)
+            assert ste["num_visible"] == len(ofre[1])            # the cull test agrees with the oracle's
+            if ste["num_visible"] > 0 and ste["num_tile_entries"] == 0:
+                assert np.array_equal(imge, np.broadcast_to(np.array(bg, dtype=np.float32), imge.shape))
+            _assert_close(imge, refe, proof=edge.proof(ofre, bg))
+        finally:
+            pce.close()
+    finally:
+        c.close()
+
+
 def test_many_tiles_32bit_keys(ws, oracle, monkeypatch):
     """65536 tiles (4096x4096 at 16x16): the tile sort switches from 16-bit to 32-bit tile ids, two 8-bit passes."""
     monkeypatch.setenv("WS_TILE_SHAPE", "2x2")
