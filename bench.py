@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the render hot path (prepare + render) on N MI355X GPUs of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W      (N > 1 from a plain shell: bench.py starts its own N ranks,
+                                                      one per GPU, through torch.distributed.run on 127.0.0.1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+                                                     (the driver's form: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env)
 
 A "step" is one frame = one pass of the hot path (K1 preprocess -> depth radix sort -> tile binning ->
 tile blend) over one camera view of the synthetic scene, inputs resident in HBM, output left in HBM.
@@ -197,12 +199,98 @@ def cpu_quota():
         return None
 
 
+def _visible_device_ordinals():
+    """HIP device index -> position among the node's GPUs (KFD order), honouring HIP/ROCR/CUDA_VISIBLE_DEVICES lists of
+    plain integers; None when a variable holds something else (UUIDs)."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            try:
+                return [int(x) for x in v.split(",") if x.strip() != ""]
+            except ValueError:
+                return None
+    return None
+
+
+def gpu_numa_nodes(topology_root="/sys/class/kfd/kfd/topology/nodes", pci_root="/sys/bus/pci/devices"):
+    """NUMA node of every GPU of this host, in HIP's enumeration order (the KFD topology nodes that have SIMDs, by node id;
+    a GPU's PCI address is `domain` + `location_id` of its properties file, its NUMA node /sys/bus/pci/devices/<bdf>/numa_node).
+    -> list of ints (-1 = the platform does not say), [] when there is no KFD topology (no GPU / not Linux)."""
+    out = []
+    try:
+        ids = sorted(int(d) for d in os.listdir(topology_root) if d.isdigit())
+    except OSError:
+        return out
+    for i in ids:
+        try:
+            props = dict(ln.split()[:2] for ln in open(f"{topology_root}/{i}/properties") if len(ln.split()) >= 2)
+        except OSError:   # (a node of another container's GPU: not readable, not ours)
+            continue
+        if int(props.get("simd_count", "0")) == 0:
+            continue  # a CPU node
+        loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+        try:
+            out.append(int(open(f"{pci_root}/{bdf}/numa_node").read()))
+        except (OSError, ValueError):
+            out.append(-1)
+    return out
+
+
+def _cpus_of_numa_node(node):
+    try:
+        txt = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+    except OSError:
+        return None
+    cpus = set()
+    for part in txt.split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            cpus.update(range(int(a), int(b) + 1))
+        elif part:
+            cpus.add(int(part))
+    return cpus
+
+
+def numa_share(local_rank, local_world, allowed, gpu_nodes=None, cpus_of_node=_cpus_of_numa_node, physical=None):
+    """The logical CPUs rank `local_rank` of `local_world` takes: the ranks whose GPUs hang off the same NUMA node split THAT
+    node's physical cores (of the allowed set) among themselves, in rank order; when the platform does not say where the GPUs
+    are (or a node has fewer cores than ranks) the ranks split all allowed cores as before.  Pure function of sysfs, so every
+    rank computes the same partition without talking to the others.  -> (sorted cpus, note)"""
+    physical = physical or _physical_cores
+    if gpu_nodes is None:
+        gpu_nodes = gpu_numa_nodes()
+        vis = _visible_device_ordinals()
+        if vis is not None and gpu_nodes and all(0 <= v < len(gpu_nodes) for v in vis):
+            gpu_nodes = [gpu_nodes[v] for v in vis]
+    node_of = [gpu_nodes[r] if r < len(gpu_nodes) else -1 for r in range(local_world)]
+    my_node = node_of[local_rank]
+    if my_node >= 0 and all(n >= 0 for n in node_of):
+        node_cpus = cpus_of_node(my_node)
+        peers = [r for r in range(local_world) if node_of[r] == my_node]   # ranks that share this node, in rank order
+        if node_cpus:
+            cores = physical(sorted(set(allowed) & node_cpus))
+            if len(cores) >= len(peers):
+                j = peers.index(local_rank)
+                lo, hi = j * len(cores) // len(peers), (j + 1) * len(cores) // len(peers)
+                return (sorted(c for g in cores[lo:hi] for c in g),
+                        f"NUMA node {my_node} (this rank's GPU), physical cores {lo}..{hi - 1} of the node's {len(cores)} "
+                        f"shared by ranks {peers}")
+    cores = physical(allowed)
+    if len(cores) < local_world:
+        return None, f"{len(cores)} cores for {local_world} ranks: not pinned"
+    lo, hi = local_rank * len(cores) // local_world, (local_rank + 1) * len(cores) // local_world
+    return (sorted(c for g in cores[lo:hi] for c in g),
+            f"physical cores {lo}..{hi - 1} of {len(cores)} (GPU NUMA placement unknown: equal slices of all allowed cores)")
+
+
 def pin_host_share(local_rank, local_world):
     """Eight ranks on one node share its host cores: each rank builds the scene with an OpenMP team, then runs ONE enqueue
-    thread (~65 % busy at 7000 frames/s) beside the HIP runtime's helper threads.  Left alone, every rank's team spans every
-    core and the enqueue threads migrate between them.  Rank r of w takes the r-th of w equal slices of the PHYSICAL cores
-    this process may run on (taskset / cgroup respected), all SMT siblings included, and sizes its OpenMP team to the slice;
-    must run before torch / the library load (OMP_NUM_THREADS is read when the OpenMP runtime starts).
+    thread beside the HIP runtime's helper threads.  Left alone, every rank's team spans every core and the enqueue threads
+    migrate between them.  Rank r takes its share of the PHYSICAL cores of the NUMA node its GPU hangs off (numa_share;
+    taskset / cgroup respected, all SMT siblings included) and sizes its OpenMP team to the share; must run before torch /
+    the library load (OMP_NUM_THREADS is read when the OpenMP runtime starts, the HIP runtime's helper threads inherit the
+    affinity of the thread that initialises it).
     -> (cpus of the share, note)"""
     try:
         allowed = sorted(os.sched_getaffinity(0))
@@ -215,11 +303,9 @@ def pin_host_share(local_rank, local_world):
     if local_world <= 1:
         os.environ.setdefault("OMP_NUM_THREADS", str(min(len(allowed), team_cap) if team_cap else len(allowed)))
         return allowed, f"one rank: all {len(allowed)} allowed CPUs" + (f", cgroup quota {quota:g} CPUs" if quota else "")
-    cores = _physical_cores(allowed)
-    if len(cores) < local_world:
-        return allowed, f"{len(cores)} cores for {local_world} ranks: not pinned"
-    lo, hi = local_rank * len(cores) // local_world, (local_rank + 1) * len(cores) // local_world
-    share = sorted(c for g in cores[lo:hi] for c in g)
+    share, where = numa_share(local_rank, local_world, allowed)
+    if not share:
+        return allowed, where
     os.sched_setaffinity(0, share)
     try:  # (a smaller team asked for by the caller stays)
         want = min(int(os.environ.get("OMP_NUM_THREADS", len(share))), len(share))
@@ -228,7 +314,57 @@ def pin_host_share(local_rank, local_world):
     if team_cap:
         want = min(want, team_cap)
     os.environ["OMP_NUM_THREADS"] = str(max(want, 1))
-    return share, f"rank-local share: physical cores {lo}..{hi - 1} of {len(cores)} ({len(share)} logical CPUs), OMP_NUM_THREADS={os.environ['OMP_NUM_THREADS']}" + (f", cgroup quota {quota:g} CPUs" if quota else "")
+    return share, (f"rank-local share: {where} ({len(share)} logical CPUs), OMP_NUM_THREADS={os.environ['OMP_NUM_THREADS']}"
+                   + (f", cgroup quota {quota:g} CPUs" if quota else ""))
+
+
+def thread_cpu_times():
+    """{tid: (comm, cpu seconds)} of every thread of this process (/proc/self/task/*/stat: utime + stime)."""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        tids = os.listdir("/proc/self/task")
+    except OSError:
+        return out
+    for t in tids:
+        try:
+            st = open(f"/proc/self/task/{t}/stat").read()
+        except OSError:
+            continue
+        comm = st[st.index("(") + 1:st.rindex(")")]
+        f = st[st.rindex(")") + 2:].split()
+        out[int(t)] = (comm, (int(f[11]) + int(f[12])) / tick)   # fields 14, 15 of proc(5): utime, stime
+    return out
+
+
+def thread_busy(before, after, elapsed, floor=0.02):
+    """Threads that used more than `floor` cores between two thread_cpu_times() snapshots: [{"thread", "cores"}], busiest
+    first (clock ticks are 10 ms: meaningful over regions of >= 0.1 s)."""
+    rows = []
+    for tid, (comm, t1) in after.items():
+        d = t1 - before.get(tid, (comm, 0.0))[1]
+        if elapsed > 0 and d / elapsed >= floor:
+            rows.append({"thread": comm + (" (main)" if tid == os.getpid() else ""), "cores": round(d / elapsed, 3)})
+    return sorted(rows, key=lambda r: -r["cores"])
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` from a plain shell (no RANK / WORLD_SIZE in the environment): become the launcher of N
+    ranks, one per GPU -- exec torch.distributed.run with the same arguments (the process is REPLACED: same pid, same
+    stdout, the caller's timeout still applies).  Rank 0 prints the one result line; the other ranks and the launcher write
+    to stderr only."""
+    env = dict(os.environ)
+    if "OMP_NUM_THREADS" not in env:
+        # torch.distributed.run would set it to 1 for every rank; pin_host_share() caps it to the rank's share anyway
+        q = cpu_quota()
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        env["OMP_NUM_THREADS"] = str(max(1, int(min(q or ncpu, ncpu) / n)))
+    env["WS_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks through torch.distributed.run on 127.0.0.1", file=sys.stderr)
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
 
 
 def _free_port():
@@ -246,8 +382,8 @@ def init_distributed(a, torch):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world == 1 and a.gpus > 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if world != a.gpus and world == 1 and a.gpus > 1:   # (main() self-launches before it gets here)
+        raise SystemExit("--gpus N > 1 needs N ranks: run `python bench.py --gpus N` from a shell without RANK / WORLD_SIZE set")
     backend = "gloo" if (a.dry_run or a.dist_backend == "gloo") else "nccl"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
@@ -312,7 +448,13 @@ def main():
                          "compares the bytes (a view's image must not depend on the rank that draws it)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU only (backend gloo): sharding, planning, barrier and reduction without rendering")
+    ap.add_argument("--host-wait", default=os.environ.get("WS_BENCH_HOST_WAIT", "block"), choices=("block", "spin"),
+                    help="how the host waits for the device at the end of the timed region: block (interrupt-driven, the "
+                         "analogue of the reference's device.poll(Wait), bin/measure.rs:147; default) or spin (the HIP "
+                         "runtime's default: a core busy for as long as the wait lasts)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        self_launch(sys.argv[1:], a.gpus)   # does not return
 
     # stdout carries exactly ONE line, the result: everything else that writes to file descriptor 1 -- RCCL prints a
     # version banner through C stdio, flushed at exit -- is sent to stderr for the life of the process.
@@ -345,6 +487,7 @@ def main():
         pitch = w * 16
     else:
         ctx = ws.Context(local_rank)
+        ctx.set_host_wait(a.host_wait)
         pc = ws.PointCloud(ctx, gpc)
         tdtype = {"rgba32float": torch.float32, "rgba16float": torch.float16, "rgba8unorm": torch.uint8}[a.format]
         # A view batch (ws_view_batch_*): one renderer (private scratch) + one HIP stream per frame in flight, the
@@ -449,6 +592,10 @@ def main():
     # TCP round trip, measured at 0.15-0.33 ms on ONE rank (profiles/r04/short_run_probe.txt), 5-10 % of the 3-ms region of
     # `--steps 20`, and it is not frames.
     barrier()
+    if os.environ.get("WS_BENCH_MARK_FILE"):   # scripts/host_thread_probe.sh: "the timed region starts now" (pid inside)
+        with open(os.environ["WS_BENCH_MARK_FILE"], "w") as f:
+            f.write(str(os.getpid()))
+    thr0 = thread_cpu_times()
     cpu0 = time.process_time()   # CPU time of ALL threads of this process (enqueue thread + the HIP runtime's helpers)
     t0 = time.perf_counter()
     submit(timed)   # exactly K frames, enqueued back to back, one sync at the end
@@ -456,6 +603,7 @@ def main():
     device_sync()
     elapsed = time.perf_counter() - t0
     cpu_busy = (time.process_time() - cpu0) / max(elapsed, 1e-9)   # host cores this rank kept busy during the timed region
+    host_threads = thread_busy(thr0, thread_cpu_times(), elapsed)   # ... and which threads they were (rank 0's; >= 0.1 s regions)
     barrier()
     if os.environ.get("WS_BENCH_DEBUG"):
         print(f"[bench debug] enqueue {t_enq * 1e3:.3f} ms, total {elapsed * 1e3:.3f} ms for {a.steps} frames; closing bracket: "
@@ -491,6 +639,8 @@ def main():
                        # cores one rank keeps busy while it renders (MAX over ranks) and what the container grants in total:
                        # world x busy above the quota means the ranks throttle each other, whatever the core count says
                        "host_cores_busy_per_rank": cpu_busy, "host_cpu_quota": cpu_quota(),
+                       "host_threads": host_threads if elapsed >= 0.1 else None, "host_wait": a.host_wait,
+                       "frame_submission": os.environ.get("WS_GRAPH", "0") not in ("", "0") and "graph replay (WS_GRAPH)" or "launch by launch",
                        "timing_barrier": ("none (one process, --no-dist): device synchronize on both sides" if dist is None else
                                           ("host barrier (gloo group)" if host_pg is not None else f"{dist.get_backend()} barrier")
                                           + " + device synchronize in front of the region; behind it device synchronize, the "

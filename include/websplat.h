@@ -174,6 +174,13 @@ uint32_t ws_abi_version(void);
 int ws_context_create(int hip_device, ws_context** out);
 void ws_context_destroy(ws_context* ctx);
 int ws_sync(ws_context* ctx, void* stream); /* device.poll(Wait) */
+/* How a host thread of this process waits for the context's device in ws_sync / hipStreamSynchronize / the read-backs:
+ * WS_HOST_WAIT_BLOCK sleeps until the completion interrupt -- what device.poll(wgpu::PollType::Wait) does behind
+ * queue.submit (bin/measure.rs:147) -- WS_HOST_WAIT_SPIN polls (the HIP runtime's default: lowest wake-up latency, one
+ * host core busy for as long as the wait lasts).  A process-wide property of the HIP device (hipSetDeviceFlags): eight
+ * ranks of one node that wait spinning keep eight cores busy doing nothing. */
+typedef enum ws_host_wait { WS_HOST_WAIT_SPIN = 0, WS_HOST_WAIT_BLOCK = 1 } ws_host_wait;
+int ws_context_set_host_wait(ws_context* ctx, ws_host_wait mode);
 int ws_device_info(ws_context* ctx, char* name, size_t name_len, uint32_t* num_cus, uint64_t* hbm_bytes);
 /* plain device buffers for callers without their own allocator (tests, C++ drivers);
  * the analogue of device.create_buffer + queue.write_buffer + DownloadBuffer */
@@ -370,6 +377,15 @@ int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t*
  * per tile, 16 at the default tile), walked[t * 17 + 16] = sum over the tile's batches of the most any of its waves
  * composited in that batch -- the lock-step cost of the per-batch barriers.  Syncs. */
 int ws_renderer_download_wave_stats(ws_renderer* r, uint32_t tile_capacity, uint32_t* walked);
+/* analysis: the next render() launches the time-stamped build of the compositing kernel (production form: 32x32 tiles,
+ * rgba32float target, the frame's own binning) and every wave of every tile leaves 16 words: cycles (shader clock) spent in
+ * [0] the tile-range load, [1] the first batch's dependent gather chain, [2] later batches' gather waits, [3] decode,
+ * [4] the staging barrier, [5] compaction, [6] the walk, [7] the end-of-batch vote, [8] the pixel store; [9] batches,
+ * [10] records walked, [11] / [12] shader-clock stamps at start / end, [13] / [14] the 100-MHz clock at start / end,
+ * [15] XCC id << 28 | HW_ID.  The counterpart of the reference's GPUStopwatch (utils.rs:26-134) below kernel granularity.
+ * times[(t * 16 + w) * 16 + k] for blend tile t (row-major), wave w.  Syncs. */
+int ws_renderer_enable_blend_timing(ws_renderer* r, int enable);
+int ws_renderer_download_blend_timing(ws_renderer* r, uint32_t tile_capacity, uint32_t* times, uint32_t* num_tiles);
 /* parity read-back of the binning result: binning tile t's depth-ordered (far -> near) splat list is
  * entries[begin[t] .. end[t]) (store indices, as `sorted` of ws_renderer_download_frame); t is row-major over
  * ceil(viewport / binning tile) (ws_renderer_binning_tile; the tile count comes from ws_renderer_download_tile_stats).

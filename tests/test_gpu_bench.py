@@ -232,27 +232,62 @@ def test_automatic_entry_capacity_grows_to_an_overflowed_frames_demand(ws, ctx, 
         pc.close()
 
 
+def test_entry_capacity_grows_without_anyone_polling(ws, ctx, oracle):
+    """no render loop polls ws_renderer_errors on its own, so a view heavier than the automatic capacity kept
+    dropping its NEAREST splats frame after frame.  The blend now posts an overflowed frame's demand to a host-visible
+    mailbox word and prepare() reads it (no synchronisation): a plain prepare / render loop that never looks at the error
+    words or the frame statistics draws completely from the second or third frame on; the overflowed frames stay flagged."""
+    import scenes
+    rows = synth.scene_c1(n=150_000, seed=31)
+    rows[:, 55:58] = np.log(0.6)
+    rows[:, 54] = -3.0
+    sc = scenes.c1(ws, oracle, n=150_000, viewport=(640, 480), seed=31)
+    sc.gpc = ws.GenericGaussianPointCloud.from_ply_rows(rows, 3)
+    pc = ws.PointCloud(ctx, sc.gpc)
+    r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    big = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    try:
+        for _ in range(4):                   # a caller that only draws
+            r.prepare(pc, sc.args)
+            r.render(pc)
+            ctx.sync()
+        st = r.frame_stats()
+        assert st["overflow"] == 0 and st["tile_entries_capacity"] > 8 << 20, st
+        assert st["tile_entries_capacity"] >= st["num_tile_entries"]
+        assert r.errors(reset=True)[0] & 1   # the first frame(s) did overflow, and say so
+        big.set_tile_entry_capacity(2 * st["num_tile_entries"])
+        big.prepare(pc, sc.args)
+        big.render(pc)
+        assert np.array_equal(r.download_target(), big.download_target())
+        # the demand belongs to this scene and viewport: another viewport starts from the formula again
+        small = scenes.c1(ws, oracle, n=150_000, viewport=(320, 240), seed=31)
+        r.prepare(pc, small.args)
+        r.render(pc)
+        assert r.frame_stats()["tile_entries_capacity"] == 8 << 20
+    finally:
+        big.close()
+        r.close()
+        pc.close()
+
+
 def test_two_ranks_share_one_gpu_and_draw_identical_views():
-    """The N-rank path of bench.py with REAL frames on a one-GPU box: two processes launched exactly as the driver
-    launches the 8-GPU run (torch.distributed.run, one process per rank), both rendering their shard of the views on
+    """The N-rank path of bench.py with REAL frames on a one-GPU box: two processes (one per rank, started by bench.py
+    itself through torch.distributed.run, as the driver's launcher would), both rendering their shard of the views on
     cuda:0 (--single-device), the collectives on host tensors (--dist-backend gloo: RCCL refuses two ranks on one device).
     Rank 1 draws the odd views, rank 0 the even ones; afterwards every rank draws the first view of every shard and rank 0
     compares the digests: a view's image does not depend on the rank (view_shard_determinism).  The 1 -> 8 GPU
     curve itself stays unmeasured on this box."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "30",
+    # from a plain shell, as the driver starts the N = 1 line: bench.py launches its own two ranks (round-4 verdict item 1;
+    # the torch.distributed.run form of the same job is covered on CPU by tests/test_shard.py)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "30",
            "--warmup", "6", "--views", "8", "--no-cpu-baseline", "--dist-backend", "gloo", "--single-device",
            "--check-shard-determinism"]
-    env = dict(os.environ, OMP_NUM_THREADS="4")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    env["OMP_NUM_THREADS"] = "4"
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines) == 1 and p.stdout.count("\n") == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 30 and out["scaling"] == "weak" and out["value"] > 0
     cfg = out["config"]

@@ -141,6 +141,30 @@ def test_measure_reports_fps(ws, ctx, oracle, tmp_path):
         pc.close()
 
 
+def test_measure_survives_a_scene_heavier_than_the_automatic_capacity(ws, ctx, oracle, tmp_path):
+    """ws_measure creates fresh renderers per call and used to return WS_ERR_OVERFLOW for good on a scene that
+    needs more (tile, splat) entries than the automatic capacity (here ~25 k splats that each cover a few hundred binning
+    tiles of the 2048x2048 target: several times 8 M entries).  It now grows every slot to the largest demand seen and runs
+    the procedure again: a rate comes back, and it is a rate over frames that dropped nothing."""
+    rows = synth.scene_c1(n=25_000, seed=5)
+    rows[:, 55:58] = np.log(0.45)
+    rows[:, 54] = -3.0
+    ply = str(tmp_path / "heavy.ply")
+    synth.write_ply(ply, rows, 3)
+    cams = synth.orbit_cameras(3, 200, 150, 180.0, 180.0, radius=3.0, height_off=0.3)
+    cj = str(tmp_path / "cameras.json")
+    synth.write_cameras_json(cj, cams)
+    pc = ws.PointCloud.load_ply(ctx, ply)
+    scene = ws.Scene.from_json(cj)
+    try:
+        for fif in (1, 2):
+            fps = ws.measure(ctx, pc, scene, num_samples=2, frames_in_flight=fif)
+            assert np.isfinite(fps) and fps > 0.5, fps
+    finally:
+        scene.close()
+        pc.close()
+
+
 @pytest.mark.parametrize("fmt", ["rgba16float", "rgba32float", "rgba8unorm"])
 def test_texture_readback_and_display(ws, ctx, oracle, fmt):
     """bin/render.rs:222-236 (truncating read-back) and Display::render (renderer.rs:548-582): byte-exact against the

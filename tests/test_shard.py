@@ -135,3 +135,79 @@ def test_ranks_take_disjoint_shares_of_the_physical_cores():
     assert len(seen) == len(set(seen))
     off = run(1, 2, {"WS_BENCH_PIN": "0"})
     assert off["aff"] == allowed and "not pinned" in off["note"]
+
+
+def test_bench_starts_its_own_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2 ...` with no launcher in the command and no RANK / WORLD_SIZE in the environment (the form
+    the driver uses at N = 1): bench.py becomes the launcher of its two ranks (round-4 verdict item 1) and stdout still
+    carries exactly one line, rank 0's."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "c1", "--steps", "40",
+           "--warmup", "4", "--views", "9", "--streams", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR",
+                                                            "MASTER_PORT", "OMP_NUM_THREADS")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.count("\n") == 1 and p.stdout.startswith("{"), p.stdout     # ONE line and nothing else on stdout
+    out = json.loads(p.stdout)
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["steps"] == 40
+    assert out["config"]["rank_views"] == [[0, 2, 4, 6, 8], [1, 3, 5, 7]]
+    assert "starting 2 ranks" in p.stderr
+
+
+def test_ranks_split_the_cores_of_their_gpus_numa_node():
+    """bench.numa_share (round-4 verdict item 2c): the ranks whose GPUs hang off one NUMA node split THAT node's physical cores;
+    every rank computes the same partition from sysfs alone.  Synthetic topology: 2 nodes x 8 cores x 2 SMT, GPUs 0-3 on node 1,
+    GPUs 4-7 on node 0 (the crossed layout the one-GPU box showed: GPU 0 on node 1)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    allowed = list(range(32))
+    node_cpus = {0: set(range(0, 8)) | set(range(16, 24)), 1: set(range(8, 16)) | set(range(24, 32))}
+
+    def physical(cpus):   # core c has SMT siblings c and c + 16
+        cores = {}
+        for c in cpus:
+            cores.setdefault(c % 16, []).append(c)
+        return [sorted(cores[k]) for k in sorted(cores)]
+    gpu_nodes = [1, 1, 1, 1, 0, 0, 0, 0]
+    shares = [bench.numa_share(r, 8, allowed, gpu_nodes=gpu_nodes, cpus_of_node=node_cpus.get, physical=physical)[0] for r in range(8)]
+    for r, s in enumerate(shares):
+        assert s and set(s) <= node_cpus[gpu_nodes[r]], (r, s)           # on the GPU's own node
+        assert len(s) == 4 and {c % 16 for c in s} == {c % 16 for c in s if c < 16}   # two whole cores, siblings together
+    flat = [c for s in shares for c in s]
+    assert sorted(flat) == allowed                                        # disjoint and covering
+    # a restricted affinity mask (taskset / cpuset) is respected
+    s0, _ = bench.numa_share(0, 8, [8, 9, 10, 11, 24, 25, 26, 27] + list(range(0, 8)) + list(range(16, 24)), gpu_nodes=gpu_nodes,
+                             cpus_of_node=node_cpus.get, physical=physical)
+    assert s0 == [8, 24]
+    # unknown placement (-1) or a node with fewer cores than ranks: equal slices of everything, as before
+    s, note = bench.numa_share(1, 2, allowed, gpu_nodes=[-1, -1], cpus_of_node=node_cpus.get, physical=physical)
+    assert s == sorted(list(range(8, 16)) + list(range(24, 32))) and "unknown" in note
+    s, note = bench.numa_share(0, 2, allowed, gpu_nodes=[], cpus_of_node=node_cpus.get, physical=physical)
+    assert s == sorted(list(range(0, 8)) + list(range(16, 24)))
+    assert bench.gpu_numa_nodes(topology_root="/nonexistent") == []
+
+
+def test_thread_cpu_accounting():
+    """bench.thread_cpu_times / thread_busy: a thread that burns CPU shows up by name with about one core."""
+    import threading
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    stop = []
+
+    def burn():
+        while not stop:
+            pass
+    t0 = bench.thread_cpu_times()
+    assert os.getpid() in t0
+    th = threading.Thread(target=burn, name="burner")
+    w0 = time.perf_counter()
+    th.start()
+    time.sleep(0.5)
+    t1 = bench.thread_cpu_times()
+    el = time.perf_counter() - w0
+    stop.append(1)
+    th.join()
+    rows = bench.thread_busy(t0, t1, el)
+    assert rows and 0.5 < rows[0]["cores"] < 1.3, rows

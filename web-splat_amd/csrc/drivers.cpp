@@ -193,7 +193,10 @@ int ws_measure(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, 
             rc = fail(WS_ERR_HIP, "ws_measure: hipStreamCreate failed");
     }
     const float clear[4] = {0, 0, 0, 0};
-    if (rc == WS_OK) {
+    // The measurement, at most three times: a run whose frames overflowed the (automatic) tile-entry capacity is not a rate --
+    // every slot's renderer is given 1.25 x the largest demand any slot saw and the WHOLE procedure runs again (a
+    // scene heavier than the automatic capacity used to fail here for good, each call starting from fresh renderers).
+    for (int attempt = 0; rc == WS_OK; ++attempt) {
         const auto start = std::chrono::steady_clock::now();  // before the warm-up frame (bin/measure.rs:50)
         ws_splatting_args a;
         offline_args(cams[0], pc, W, H, &a);
@@ -211,11 +214,20 @@ int ws_measure(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, 
         if (rc == WS_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(WS_ERR_HIP, "ws_measure: device sync failed");  // device.poll(Wait)
         const float secs = std::chrono::duration<float>(std::chrono::steady_clock::now() - start).count();
         if (rc == WS_OK) *fps = 1.0f / (secs / ((float)n * (float)num_samples));
+        uint32_t all_bits = 0, demand = 0;
         for (uint32_t k = 0; k < frames_in_flight && rc == WS_OK; ++k) {  // a rate over frames that dropped entries is not a rate
             uint32_t bits = 0;
-            rc = ws_renderer_errors(rs[k], &bits, nullptr, 0);
-            if (rc == WS_OK && bits) rc = fail(WS_ERR_OVERFLOW, "ws_measure: frames reported device-side errors (tile-entry overflow or a look-back time-out)");
+            rc = ws_renderer_errors(rs[k], &bits, nullptr, 1);
+            all_bits |= bits;
+            demand = std::max(demand, ws_internal_renderer_demand(rs[k]));
         }
+        if (rc != WS_OK || all_bits == 0) break;
+        if ((all_bits & ~1u) != 0 || attempt == 2 || demand == 0) {
+            rc = fail(WS_ERR_OVERFLOW, "ws_measure: frames reported device-side errors (tile-entry overflow or a look-back time-out)");
+            break;
+        }
+        for (uint32_t k = 0; k < frames_in_flight; ++k)
+            ws_renderer_set_tile_entry_capacity(rs[k], (uint64_t)demand + demand / 4 + 4096);
     }
     for (uint32_t k = 0; k < frames_in_flight; ++k) {
         if (rs[k]) ws_renderer_destroy(rs[k]);

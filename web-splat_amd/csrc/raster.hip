@@ -345,6 +345,85 @@ __device__ __forceinline__ void store_pixel(const BlendParams& p, uint32_t px, u
     }
 }
 
+// ---- k_blend_order: the compositing workgroups in longest-list-first order --------------------------------------------------
+// The hardware starts the blend's workgroups in blockIdx order, two per CU, and a frame has ~4x (1080p) more tiles than the
+// chip has slots.  Tiles take 10 ... 40 us on the headline scene and 2 ... 290 us on c3, so in image order the kernel ends
+// with a tail in which most slots idle while the last dense tiles finish: measured with the time-stamped build
+// (profiles/r05/blend_wait_breakdown_*.json), 24 % (hd1m) and 31 % (c3) of the kernel's span.  A tile's cost grows with the
+// length of its list (until the tile saturates), and the lists are known before the blend starts: ONE workgroup counting-
+// sorts the tiles by list length, longest first (the classic LPT rule of makespan scheduling), and leaves for every
+// blockIdx of the blend the tile it composites together with that tile's entry range -- the blend's first scalar load
+// returns all three, so its start-up chain is as long as before.  The image does not depend on the order.
+constexpr int ORDER_THREADS = 1024;
+constexpr int ORDER_CLASSES = 2048;   // list length / 16, capped: lengths beyond 32 k share the first class
+__global__ __launch_bounds__(ORDER_THREADS) void k_blend_order(const uint2* __restrict__ tile_ranges,
+                                                               const FrameCounters* __restrict__ counters, uint32_t tiles_x,
+                                                               uint32_t tiles_y, uint32_t bin_tiles_x, uint4* __restrict__ order,
+                                                               uint32_t nblocks) {
+    __shared__ uint32_t s_cnt[ORDER_CLASSES];
+    __shared__ uint32_t s_wave[ORDER_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t c = tid; c < (uint32_t)ORDER_CLASSES; c += ORDER_THREADS) s_cnt[c] = 0u;
+    __syncthreads();
+    const uint32_t s = counters->bin_shift;
+    const uint32_t btx = s ? (bin_tiles_x + 1u) >> 1 : bin_tiles_x;
+    const uint32_t ntiles = tiles_x * tiles_y;
+    auto range_of = [&](uint32_t t, uint32_t& tx, uint32_t& ty) -> uint2 {
+        tx = t % tiles_x;
+        ty = t / tiles_x;
+        uint2 r = tile_ranges[(ty >> s) * btx + (tx >> s)];
+        r.x = r.y ? 0xFFFFFFFFu - r.x : 0u;
+        return r;
+    };
+    auto class_of = [](uint2 r) -> uint32_t {  // class 0 = the longest lists
+        const uint32_t c = (r.y - r.x) >> 4;
+        return (uint32_t)(ORDER_CLASSES - 1) - (c < (uint32_t)ORDER_CLASSES ? c : (uint32_t)(ORDER_CLASSES - 1));
+    };
+    for (uint32_t t = tid; t < ntiles; t += ORDER_THREADS) {
+        uint32_t tx, ty;
+        atomicAdd(&s_cnt[class_of(range_of(t, tx, ty))], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over the classes, two per thread
+    const uint32_t c0 = s_cnt[2u * tid], c1 = s_cnt[2u * tid + 1u];
+    uint32_t incl = c0 + c1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0u;
+    for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
+    const uint32_t excl = base + incl - (c0 + c1);
+    __syncthreads();
+    s_cnt[2u * tid] = excl;
+    s_cnt[2u * tid + 1u] = excl + c0;
+    __syncthreads();
+    for (uint32_t t = tid; t < ntiles; t += ORDER_THREADS) {
+        uint32_t tx, ty;
+        const uint2 r = range_of(t, tx, ty);
+        const uint32_t pos = atomicAdd(&s_cnt[class_of(r)], 1u);   // (the order inside a class is arbitrary; the image does not see it)
+        order[pos] = make_uint4(tx | (ty << 16), r.x, r.y, 0u);
+    }
+    for (uint32_t b = ntiles + tid; b < nblocks; b += ORDER_THREADS) order[b] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+}
+
+// The last kernel of a frame folds the frame's error bits (per-frame zero arena) into the renderer's sticky words, which no
+// per-frame memset clears: [0] the bits, [1] the largest entry demand of an overflowed frame.  The demand is ALSO posted --
+// a plain system-scope store by this one thread -- to a host-visible mailbox word (pinned, mapped memory) that the next
+// prepare() reads without any device synchronisation: a renderer whose frames overflow its entry list grows the list by
+// itself, whether or not its caller ever polls ws_renderer_errors.
+__device__ __forceinline__ void fold_frame_errors(const BlendParams& p, uint32_t bits) {
+    atomicOr(p.sticky, bits);
+    if (bits & 1u) {
+        const uint32_t need = p.counters->entries_needed;
+        const uint32_t before = atomicMax(p.sticky + 1, need);  // what a retry (or the next prepare) allocates
+        if (p.demand_mailbox) __hip_atomic_store(p.demand_mailbox, need > before ? need : before, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // raw words of one staged entry: the 20-B Splat record (pointcloud.rs:352-358)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 struct RawSplat {
@@ -447,8 +526,30 @@ __device__ __forceinline__ void blend_composite(const BlendRec& r, float lx, flo
 #ifndef WS_BLEND_STAGE_MAX
 #define WS_BLEND_STAGE_MAX 512
 #endif
-template <int FORMAT, int QW, int QH, bool MULTI, bool CAPTURE, bool DMA>
+// ---- TIMING build of k_blend (ws_renderer_enable_blend_timing; analysis only, never on a production launch) -------------
+// Wave-uniform time stamps (s_memtime: the shader clock) bracket the phases of a tile -- range load, the first batch's
+// dependent gather chain, later batches' gather waits, decode, staging barrier, compaction, walk, end-of-batch vote, pixel
+// store -- and every wave leaves its sums in p.debug_timing[(tile * waves + wave) * BLEND_TIMING_WORDS + ...]
+// (scripts/blend_wait_breakdown.py).  The stamp waits for the wave's own scalar / LDS traffic (lgkmcnt), never for vector
+// loads: the staging prefetch stays in flight across the walk exactly as in the production kernel.
+template <bool ON>
+__device__ __forceinline__ uint32_t blend_stamp() {
+    if (!ON) return 0u;
+    uint64_t t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return (uint32_t)t;
+}
+template <int FORMAT, int QW, int QH, bool MULTI, bool CAPTURE, bool DMA, bool TIMING = false>
 __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const BlendParams p, const uint32_t tpw_log2_arg) {
+    static_assert(!TIMING || (!MULTI && !DMA && !CAPTURE), "the timing build instruments the production form only");
+    uint32_t tm[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // TIMING: cycles per phase, this wave (SGPRs)
+    uint32_t tm_batches = 0u, tm_real0 = 0u;
+    const uint32_t tm_start = blend_stamp<TIMING>();
+    if (TIMING) {
+        uint64_t rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");  // 100 MHz: calibrates the shader clock
+        tm_real0 = (uint32_t)rt;
+    }
     const uint32_t tpw_log2 = MULTI ? tpw_log2_arg : 0u;  // MULTI = several tiles per workgroup (4K-class tile counts)
     constexpr int NW = QW * QH;                  // waves = quadrants
     constexpr int NT = 64 * NW;
@@ -481,10 +582,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     // back to back can be checked once at the end (ws_renderer_errors / ws_view_batch_errors).
     if (blockIdx.x == 0 && threadIdx.x == 0 && p.sticky) {
         const uint32_t bits = p.counters->overflow;
-        if (bits) {
-            atomicOr(p.sticky, bits);
-            if (bits & 1u) atomicMax(p.sticky + 1, p.counters->entries_needed);  // what a retry (or the next prepare) allocates
-        }
+        if (bits) fold_frame_errors(p, bits);
     }
     const BlendShape shape = blend_shape(QW, QH);
     const BlendBlock blk = blend_block_of(blockIdx.x, p.tiles_x, p.tiles_y, shape, tpw_log2);
@@ -502,7 +600,12 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     // round trip instead of one per tile.
     uint2 range_one = make_uint2(0u, 0u);
     uint32_t code_one = 0xFFFFFFFFu;
-    if (!MULTI) {
+    if (!MULTI && QW == 4 && QH == 4 && p.order) {
+        // longest list first (k_blend_order): tile and range of this blockIdx in ONE scalar load
+        const uint4 o = p.order[blockIdx.x];
+        code_one = o.x;
+        range_one = make_uint2(o.y, o.z);
+    } else if (!MULTI) {
         const uint32_t slot = blk.w;
         const uint32_t tx = (blk.bx << shape.tbx_log2) + (slot & ((1u << shape.tbx_log2) - 1u));
         const uint32_t ty = (blk.by << shape.tby_log2) + (slot >> shape.tbx_log2);
@@ -531,6 +634,13 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         s_rec[SLOTS + STAGE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (MULTI) __syncthreads();
+    uint32_t tm_last = tm_start;
+    if (TIMING) {
+        asm volatile("" ::"s"(range_one.x), "s"(range_one.y));  // the tile's range has arrived (scalar loads)
+        const uint32_t t = blend_stamp<TIMING>();
+        tm[0] = t - tm_last;
+        tm_last = t;
+    }
     const float W = (float)p.width, H = (float)p.height;
     uint32_t* my_list = s_list[wave];
 
@@ -588,6 +698,16 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     while (hi > range.x) {
         const uint32_t nb = (hi - range.x) < (uint32_t)STAGE ? (hi - range.x) : (uint32_t)STAGE;
         const uint32_t hi_next = hi - nb;
+        if (TIMING) {
+            // the batch's Splat records (and the index load behind them) have landed: first batch = the tile's dependent
+            // chain index -> record, later batches = whatever the prefetch did not hide
+            wait_vector_loads();
+            const uint32_t t = blend_stamp<TIMING>();
+            if (tm_batches) tm[2] += t - tm_last;
+            else tm[1] += t - tm_last;
+            tm_last = t;
+            ++tm_batches;
+        }
         if (stager) {
             uint32_t mask = 0u;
             uint32_t idx_nt = 0u;
@@ -620,8 +740,18 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
             else raw = blend_gather(p, idx_next);
             idx_next = blend_entry_idx<STAGE>(p, range, hi_next - range.x > (uint32_t)STAGE ? hi_next - (uint32_t)STAGE : range.x, tid);
         }
+        if (TIMING) {
+            const uint32_t t = blend_stamp<TIMING>();
+            tm[3] += t - tm_last;  // decode + LDS stores + issue of the next batch's gathers
+            tm_last = t;
+        }
         if (DMA) wg_barrier_keep_loads();
         else __syncthreads();
+        if (TIMING) {
+            const uint32_t t = blend_stamp<TIMING>();
+            tm[4] += t - tm_last;  // staging barrier: waiting for the slowest stager
+            tm_last = t;
+        }
         const uint32_t dbg_before = dbg_walked;
         // a wave whose 64 pixels are saturated only keeps staging
         for (uint32_t sub = 0; sub < nb && __ballot(T >= T_MIN) != 0ull; sub += (uint32_t)LCAP) {
@@ -646,6 +776,11 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
                     n += (uint32_t)__popcll(bal);
                 }
             }
+            if (TIMING) {
+                const uint32_t t = blend_stamp<TIMING>();
+                tm[5] += t - tm_last;  // compaction (mask reads, ballots, list writes)
+                tm_last = t;
+            }
             if (n > 0u) {
                 if (lane < 4 && ((n + (uint32_t)lane) >> 2) == (n >> 2) && (n & 3u)) my_list[n + lane] = (uint32_t)STAGE * 16u;  // pad to x4
                 const uint32_t n4 = (n + 3u) >> 2;
@@ -666,7 +801,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
                     blend_composite(r3, lx, ly, T, cr, cg, cb);
                     // the quadrant is saturated: nothing behind can add more than T_MIN (one compare per four pairs;
                     // on dense tiles this stops the walk well inside the staged batch)
-                    if ((CAPTURE && p.debug_walked)) dbg_walked += 4u;
+                    if ((CAPTURE && p.debug_walked) || TIMING) dbg_walked += 4u;
                     if (__ballot(T >= T_MIN) == 0ull) break;
                     o = on;
                     on = lp[g + 2u < n4 ? g + 2u : n4 - 1u];
@@ -675,6 +810,11 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         }
         hi = hi_next;
         if ((CAPTURE && p.debug_walked) && lane == 0) atomicMax(&s_dbg_max, dbg_walked - dbg_before);
+        if (TIMING) {
+            const uint32_t t = blend_stamp<TIMING>();
+            tm[6] += t - tm_last;  // walk
+            tm_last = t;
+        }
         bool all_done;
         if (DMA) {  // __syncthreads_and() without the release fence that would drain the staging DMA
             const bool wave_alive = __ballot(T >= T_MIN) != 0ull;  // (evaluated by ALL lanes, not behind `lane == 0 &&`)
@@ -691,6 +831,11 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
             if (tid == 0) s_dbg_max = 0u;
             __syncthreads();
         }
+        if (TIMING) {
+            const uint32_t t = blend_stamp<TIMING>();
+            tm[7] += t - tm_last;  // end-of-batch vote: waiting for the wave with the longest walk
+            tm_last = t;
+        }
         if (all_done) break;
     }
     if ((CAPTURE && p.debug_consumed) && tid == 0) p.debug_consumed[tile] = range.y - hi;
@@ -706,6 +851,28 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
             // begin_render_pass(clear = background) then "over": dst = src + dst * (1 - src.a), all four channels
             store_pixel<FORMAT>(p, sx, sy, cr + p.background[0] * T, cg + p.background[1] * T, cb + p.background[2] * T,
                                 (1.0f - T) + p.background[3] * T);
+        }
+    }
+    if (TIMING && p.debug_timing) {
+        const uint32_t t = blend_stamp<TIMING>();
+        tm[8] = t - tm_last;
+        uint64_t rt;
+        uint32_t xcc, hw;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if (lane < BLEND_TIMING_WORDS) {
+            uint32_t v = 0u;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) v = lane == i ? tm[i] : v;
+            v = lane == 9 ? tm_batches : v;
+            v = lane == 10 ? dbg_walked : v;
+            v = lane == 11 ? tm_start : v;
+            v = lane == 12 ? t : v;
+            v = lane == 13 ? tm_real0 : v;
+            v = lane == 14 ? (uint32_t)rt : v;
+            v = lane == 15 ? ((xcc & 0xFu) << 28) | (hw & 0x0FFFFFFFu) : v;
+            p.debug_timing[((size_t)tile * NW + wave) * BLEND_TIMING_WORDS + lane] = v;
         }
     }
     }  // tile inside the image
@@ -778,10 +945,7 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
     const uint32_t b = blockIdx.x;
     if (b == 0 && threadIdx.x == 0 && p.sticky) {  // as in k_blend
         const uint32_t bits = p.counters->overflow;
-        if (bits) {
-            atomicOr(p.sticky, bits);
-            if (bits & 1u) atomicMax(p.sticky + 1, p.counters->entries_needed);  // what a retry (or the next prepare) allocates
-        }
+        if (bits) fold_frame_errors(p, bits);
     }
     const uint32_t xcd = b & 7u, j = b >> 3;
     const uint32_t nq = p.qw * p.qh;
@@ -923,10 +1087,7 @@ __global__ __launch_bounds__(64) void k_blend_strict(const BlendParams p) {
     const uint32_t b = blockIdx.x;
     if (b == 0 && threadIdx.x == 0 && p.sticky) {  // as in k_blend
         const uint32_t bits = p.counters->overflow;
-        if (bits) {
-            atomicOr(p.sticky, bits);
-            if (bits & 1u) atomicMax(p.sticky + 1, p.counters->entries_needed);  // what a retry (or the next prepare) allocates
-        }
+        if (bits) fold_frame_errors(p, bits);
     }
     const uint32_t xcd = b & 7u, j = b >> 3;
     const uint32_t nq = p.qw * p.qh;
@@ -1093,6 +1254,17 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     return WS_OK;
 }
 
+uint32_t blend_order_blocks(uint32_t tiles_x, uint32_t tiles_y) { return blend_grid_blocks(tiles_x, tiles_y, blend_shape(4, 4), 0u); }
+
+int launch_blend_order(const uint2* tile_ranges, const FrameCounters* counters, uint32_t tiles_x, uint32_t tiles_y, uint4* order,
+                       hipStream_t stream) {
+    if (tiles_x * tiles_y == 0u) return WS_OK;
+    hipLaunchKernelGGL(k_blend_order, dim3(1), dim3(ORDER_THREADS), 0, stream, tile_ranges, counters, tiles_x, tiles_y, tiles_x, order,
+                       blend_order_blocks(tiles_x, tiles_y));
+    WS_HIP(hipGetLastError());
+    return WS_OK;
+}
+
 template <int QW, int QH>
 static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
     const BlendShape sh = blend_shape(QW, QH);
@@ -1103,6 +1275,14 @@ static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
     const bool capture = p.debug_consumed != nullptr || p.debug_walked != nullptr;  // analysis build of the kernel
     // tuning knob (WS_BLEND_LDS_PAD_KB): unused dynamic LDS that lowers the number of blend workgroups per CU
     const size_t pad = (size_t)p.lds_pad_kb * 1024u;
+    if (p.debug_timing) {  // analysis: the production form (one tile per workgroup, f32 target, 32x32) with time stamps
+        if (QW != 4 || QH != 4 || p.format != WS_FORMAT_RGBA32_FLOAT || capture || tpw_log2 > 0u || p.dma)
+            return fail(WS_ERR_UNSUPPORTED, "blend timing: 32x32 tiles, rgba32float target, one tile per workgroup, no capture / DMA");
+        hipLaunchKernelGGL((k_blend<WS_FORMAT_RGBA32_FLOAT, 4, 4, false, false, false, true>), dim3(grid), dim3(1024), pad, stream, p,
+                           tpw_log2);
+        WS_HIP(hipGetLastError());
+        return WS_OK;
+    }
 #define WS_LAUNCH_BLEND(FMT)                                                                                              \
     if (capture)                                                                                                          \
         hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, true, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);    \

@@ -141,6 +141,8 @@ struct ws_renderer {
     uint32_t* sticky = nullptr;      // two device words that survive the per-frame memset (ws_renderer_errors): [0] error bits
                                      // of all frames since the last reset, [1] the largest entries_needed of an overflowed frame
     uint32_t needed_seen = 0;        // host copy of [1]: the automatic entry capacity grows to it at the next prepare()
+    uint32_t* demand_mailbox = nullptr;      // pinned host word the blend posts [1] to (device-visible address: demand_mailbox_dev);
+    uint32_t* demand_mailbox_dev = nullptr;  //   prepare() reads it without a sync, so the capacity grows without anyone polling
 
     // The frame's launch sequence of prepare() (memset + 21 kernels), captured once per (point cloud, scratch) and replayed:
     // only K1's arguments change from frame to frame (camera / settings uniforms, epoch).  A ring of executable graphs,
@@ -174,6 +176,11 @@ struct ws_renderer {
     bool capture = false;
     uint32_t* debug_consumed = nullptr;  // [tiles], capture mode only
     uint32_t* debug_walked = nullptr;    // [tiles][17], capture mode only
+    uint4* blend_order = nullptr;        // [blend_order_blocks]: the blend's tiles, longest list first (k_blend_order)
+    bool blend_order_valid = false;      // the last prepared frame wrote it
+    bool blend_timing = false;           // ws_renderer_enable_blend_timing: render() launches the time-stamped blend
+    uint32_t* debug_timing = nullptr;    // [tiles][16][BLEND_TIMING_WORDS], allocated on first use
+    uint32_t debug_timing_tiles = 0;
     bool timers = false;
     KernelMarks marks;               // per-kernel events, timers level 2
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -249,6 +256,10 @@ static void renderer_free_scratch(ws_renderer* r) {
     dfree(r->evals_b);
     dfree(r->debug_consumed);
     dfree(r->debug_walked);
+    dfree(r->debug_timing);
+    r->debug_timing_tiles = 0;
+    dfree(r->blend_order);
+    r->blend_order_valid = false;
     if (r->zero) (void)hipFree(r->zero);
     r->zero = nullptr;
     r->tile_ranges = nullptr;
@@ -270,6 +281,20 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
         // in the sticky words, and once a read-back (ws_renderer_errors) has seen it the next prepare() allocates 1.25 x that.
         const double mpix = (double)vw * (double)vh / (1200.0 * 800.0);
         want_cap = std::max<uint64_t>(8ull << 20, (uint64_t)(4.0 * (double)n * std::max(1.0, mpix)));
+        // an overflowed frame's demand arrives by the mailbox (no sync, no polling by the caller) or by ws_renderer_errors.
+        // It belongs to THIS point-cloud size and viewport: another scene or target size starts from the formula again
+        // (one heavy frame must not inflate the scratch for the renderer's lifetime).
+        if (r->zero && (r->cap_points != n || r->vw != vw || r->vh != vh)) {
+            r->needed_seen = 0;
+            if (r->demand_mailbox) {
+                WS_HIP(hipDeviceSynchronize());
+                *reinterpret_cast<volatile uint32_t*>(r->demand_mailbox) = 0u;
+                WS_HIP(hipMemset(r->sticky + 1, 0, sizeof(uint32_t)));
+            }
+        } else if (r->demand_mailbox) {
+            const uint32_t posted = *reinterpret_cast<volatile uint32_t*>(r->demand_mailbox);
+            if (posted > r->needed_seen) r->needed_seen = posted;
+        }
         if (r->needed_seen) want_cap = std::max<uint64_t>(want_cap, (uint64_t)r->needed_seen + r->needed_seen / 4 + 4096);
     }
     // look-back words carry 30-bit counts (lookback.h): keep D below 2^30
@@ -303,6 +328,7 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     const uint32_t tile_w = QUAD * r->ctx->tile_qw, tile_h = QUAD * r->ctx->tile_qh;
     r->tiles_x = (vw + tile_w - 1) / tile_w;
     r->tiles_y = (vh + tile_h - 1) / tile_h;
+    if ((rc = dmalloc(&r->blend_order, (size_t)blend_order_blocks(r->tiles_x, r->tiles_y) + 8))) return rc;
     if ((rc = dmalloc(&r->debug_consumed, (size_t)r->tiles_x * r->tiles_y))) return rc;
     if ((rc = dmalloc(&r->debug_walked, (size_t)r->tiles_x * r->tiles_y * 17))) return rc;
     // the per-frame zero arena: counters | depth histograms | tile histograms | tile ranges
@@ -393,6 +419,7 @@ int ws_context_create(int hip_device, ws_context** out) {
     ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
     if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
     ctx->use_graph = env_int("WS_GRAPH", 0);
+    ctx->blend_order = env_int("WS_BLEND_ORDER", 1);  // 0: the blend's workgroups in image order (A/B)
     ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
     ctx->blend_dma = env_int("WS_BLEND_DMA", 0) ? 1 : 0;
     {
@@ -473,6 +500,14 @@ int ws_debug_footprint(const uint32_t splat[3], float viewport_w, float viewport
 int ws_sync(ws_context* ctx, void* stream) {
     if (!ctx) return fail(WS_ERR_INVALID, "ws_sync: null context");
     WS_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return WS_OK;
+}
+
+int ws_context_set_host_wait(ws_context* ctx, ws_host_wait mode) {
+    if (!ctx) return fail(WS_ERR_INVALID, "ws_context_set_host_wait: null context");
+    if (mode != WS_HOST_WAIT_SPIN && mode != WS_HOST_WAIT_BLOCK) return fail(WS_ERR_INVALID, "ws_context_set_host_wait: unknown mode");
+    WS_HIP(hipSetDevice(ctx->device));
+    WS_HIP(hipSetDeviceFlags(mode == WS_HOST_WAIT_BLOCK ? hipDeviceScheduleBlockingSync : hipDeviceScheduleSpin));
     return WS_OK;
 }
 
@@ -765,6 +800,17 @@ int ws_renderer_create(ws_context* ctx, ws_color_format format, uint32_t sh_deg,
         ws_renderer_destroy(r);
         return fail(WS_ERR_HIP, "ws_renderer_create: error word allocation failed");
     }
+    // the demand mailbox (optional: without pinned memory the capacity still grows through ws_renderer_errors)
+    if (hipHostMalloc(reinterpret_cast<void**>(&r->demand_mailbox), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+        *r->demand_mailbox = 0u;
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&r->demand_mailbox_dev), r->demand_mailbox, 0) != hipSuccess) {
+            (void)hipHostFree(r->demand_mailbox);
+            r->demand_mailbox = r->demand_mailbox_dev = nullptr;
+        }
+    } else {
+        r->demand_mailbox = nullptr;
+    }
+    (void)hipGetLastError();
     *out = r;
     return WS_OK;
 }
@@ -774,6 +820,7 @@ void ws_renderer_destroy(ws_renderer* r) {
     (void)hipDeviceSynchronize();
     renderer_free_scratch(r);
     dfree(r->sticky);
+    if (r->demand_mailbox) (void)hipHostFree(r->demand_mailbox);
     for (auto& e : r->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : r->ev_group)
@@ -814,6 +861,24 @@ int ws_renderer_enable_capture(ws_renderer* r, int enable) {
     if (r->capture != (enable != 0)) r->prepared = false;
     r->capture = enable != 0;
     return WS_OK;
+}
+
+int ws_renderer_enable_blend_timing(ws_renderer* r, int enable) {
+    if (!r) return fail(WS_ERR_INVALID, "ws_renderer_enable_blend_timing: null renderer");
+    r->blend_timing = enable != 0;
+    return WS_OK;
+}
+
+int ws_renderer_download_blend_timing(ws_renderer* r, uint32_t tile_capacity, uint32_t* times, uint32_t* num_tiles) {
+    if (!r) return fail(WS_ERR_INVALID, "ws_renderer_download_blend_timing: null renderer");
+    const uint32_t nt = r->tiles_x * r->tiles_y;
+    if (num_tiles) *num_tiles = nt;
+    if (!times) return WS_OK;
+    if (!r->prepared || !r->blend_timing || !r->debug_timing || r->debug_timing_tiles != nt)
+        return fail(WS_ERR_STATE, "ws_renderer_download_blend_timing: needs ws_renderer_enable_blend_timing and a rendered frame");
+    if (tile_capacity < nt) return fail(WS_ERR_INVALID, "ws_renderer_download_blend_timing: capacity smaller than the tile count");
+    WS_HIP(hipStreamSynchronize(r->last_stream));
+    return copy_d2h(times, r->debug_timing, (size_t)nt * 16 * BLEND_TIMING_WORDS * sizeof(uint32_t), r->last_stream);
 }
 
 int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries) {
@@ -957,6 +1022,14 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
                                        "tiles:", r->tile_ranges, ntiles, digit_bits, key16)))
         return rc;
     r->entries_sorted = evv;  // the last pass wrote the per-tile ranges instead of the sorted tile ids
+    // the compositing workgroups in longest-list-first order (one tile per workgroup at the 32x32 tile: every frame up to
+    // 1080p-class tile counts; 4K-class frames composite several tiles per workgroup and keep the image order)
+    r->blend_order_valid = false;
+    if (r->ctx->blend_order && r->ctx->tile_qw == 4 && r->ctx->tile_qh == 4 && ntiles <= 16384u && r->ctx->blend_tpw_log2 <= 0) {
+        if ((rc = launch_blend_order(r->tile_ranges, r->counters, r->tiles_x, r->tiles_y, r->blend_order, stream))) return rc;
+        km_mark(km, "k_blend_order");
+        r->blend_order_valid = true;
+    }
     if (r->timers) {
         WS_HIP(hipEventRecord(r->ev[3], stream));
         r->ev_prepare_valid = true;
@@ -1133,6 +1206,13 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
 
 }  // extern "C"
 
+uint32_t ws_internal_renderer_demand(const ws_renderer* r) {
+    if (!r) return 0u;
+    uint32_t d = r->needed_seen;
+    if (r->demand_mailbox) d = std::max(d, (uint32_t)*reinterpret_cast<volatile const uint32_t*>(r->demand_mailbox));
+    return d;
+}
+
 // prepare() for a GROUP of renderers drawing different views of ONE scene (a view batch): each renderer's frame runs on
 // its own stream as usual, but K1 runs ONCE for the whole group (k_preprocess_multi: the scene is read from HBM once
 // instead of once per view), on the first renderer's stream, between "every arena is cleared" and "the rest of every
@@ -1230,8 +1310,23 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     }
     bp.counters = r->counters;
     bp.sticky = r->sticky;
+    bp.demand_mailbox = r->demand_mailbox_dev;
+    bp.order = (r->blend_order_valid && bp.qw == 4 && bp.qh == 4 && bp.range_row_shift == 0 && !r->capture) ? r->blend_order : nullptr;
     bp.debug_consumed = r->capture ? r->debug_consumed : nullptr;
     bp.debug_walked = r->capture ? r->debug_walked : nullptr;
+    bp.debug_timing = nullptr;
+    if (r->blend_timing && !r->capture) {
+        const uint32_t nt = r->tiles_x * r->tiles_y;
+        if (r->debug_timing_tiles != nt) {
+            WS_HIP(hipStreamSynchronize(stream));
+            dfree(r->debug_timing);
+            int rc_ = dmalloc(&r->debug_timing, (size_t)nt * 16 * BLEND_TIMING_WORDS);
+            if (rc_) return rc_;
+            r->debug_timing_tiles = nt;
+        }
+        WS_HIP(hipMemsetAsync(r->debug_timing, 0, (size_t)nt * 16 * BLEND_TIMING_WORDS * sizeof(uint32_t), stream));
+        bp.debug_timing = r->debug_timing;
+    }
     if (bp.debug_consumed) {
         WS_HIP(hipMemsetAsync(r->debug_consumed, 0, (size_t)r->tiles_x * r->tiles_y * sizeof(uint32_t), stream));
         WS_HIP(hipMemsetAsync(r->debug_walked, 0, (size_t)r->tiles_x * r->tiles_y * 17 * sizeof(uint32_t), stream));

@@ -363,10 +363,19 @@ struct BlendParams {
                                 //   blend tile (tx, ty) is the binning tile's (tx, ty >> 1): two workgroups share one list
     const FrameCounters* counters;  // this frame's counters: the error bits are folded into *sticky by the blend
     uint32_t* sticky;           // per-renderer error word that is NOT zeroed per frame (ws_renderer_errors)
+    uint32_t* demand_mailbox;   // nullptr, or a host-visible (pinned, mapped) word: the entry demand of overflowed frames
+    const uint4* order;         // nullptr, or [blockIdx] -> (tx | ty << 16, begin, end, -) longest list first (k_blend_order;
+                                //   4x4 tiles, one tile per workgroup, not split)
     uint32_t* debug_consumed;   // nullptr, or [tiles]: entries of each tile's list the blend walked (capture mode)
     uint32_t* debug_walked;     // nullptr, or [tiles][17]: records walked per wave, [16] = sum over batches of the per-batch maximum
+    uint32_t* debug_timing;     // nullptr, or [tiles][16 waves][BLEND_TIMING_WORDS]: per-wave phase times (ws_renderer_enable_blend_timing)
 };
+constexpr int BLEND_TIMING_WORDS = 16;
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
+// the blend's workgroups in longest-list-first order (raster.hip k_blend_order): order[blend_order_blocks(..)]
+uint32_t blend_order_blocks(uint32_t tiles_x, uint32_t tiles_y);
+int launch_blend_order(const uint2* tile_ranges, const FrameCounters* counters, uint32_t tiles_x, uint32_t tiles_y, uint4* order,
+                       hipStream_t stream);
 int launch_empty(hipStream_t stream);
 int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, float tile_y0, uint32_t qw, uint32_t qh,
                       float rec[10], uint32_t* mask);
@@ -394,6 +403,9 @@ struct ws_renderer;
 struct ws_pointcloud;
 int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_pointcloud* pc, const ws_splatting_args* views,
                               hipStream_t const* streams);
+// the largest tile-entry demand an overflowed frame of this renderer has left so far (0 = none), as last seen by
+// ws_renderer_errors or a prepare() (ws_api.cpp)
+uint32_t ws_internal_renderer_demand(const ws_renderer* r);
 
 // opaque handle definitions -------------------------------------------------------------------------
 // The depth sort of a frame (V keys + store index + footprint word):
@@ -422,6 +434,7 @@ struct ws_context {
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
     int blend_split = -1;     // WS_BLEND_SPLIT: 4x4 binning tiles composited by two 4x2 workgroups each; -1 = when tiles < 2 x CUs
     int num_cus = 256;
+    int blend_order = 1;      // WS_BLEND_ORDER=0: the blend's workgroups in image order instead of longest list first (A/B)
     int use_graph = 0;        // WS_GRAPH=1: prepare() on a real stream replays a captured frame graph instead of enqueueing 22
                               //   launches (opt-in: on ROCm 7.2 legacy-NULL-stream work between two launches of a used
                               //   executable graph makes the next launch fault)

@@ -153,12 +153,15 @@ SIGNATURES = {
     "ws_context_destroy": (None, [_P]),
     "ws_context_tile_size": (C.c_int, [_P, _u32p, _u32p]),
     "ws_renderer_download_wave_stats": (C.c_int, [_P, C.c_uint32, _u32p]),
+    "ws_renderer_enable_blend_timing": (C.c_int, [_P, C.c_int]),
+    "ws_renderer_download_blend_timing": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "ws_debug_stage_splat": (C.c_int, [_u32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                        _f32p, _u32p]),
     "ws_debug_packed_rect": (C.c_int, [C.c_uint32, _u32p, _u32p, _u32p]),
     "ws_debug_binning_decision": (C.c_int, [C.c_uint32, _u32p, _u32p, C.c_uint32, _u32p]),
     "ws_debug_footprint": (C.c_int, [_u32p, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p]),
     "ws_sync": (C.c_int, [_P, _P]),
+    "ws_context_set_host_wait": (C.c_int, [_P, C.c_int]),
     "ws_device_info": (C.c_int, [_P, C.c_char_p, C.c_size_t, _u32p, C.POINTER(C.c_uint64)]),
     "ws_device_malloc": (C.c_int, [_P, C.c_size_t, _PP]),
     "ws_device_free": (C.c_int, [_P, _P]),

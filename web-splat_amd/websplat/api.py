@@ -191,6 +191,10 @@ class Context:
     def sync(self, stream=None):
         check(lib.ws_sync(self.handle, C.c_void_p(stream or 0)))
 
+    def set_host_wait(self, mode):
+        """'block' (sleep until the completion interrupt: device.poll(Wait), bin/measure.rs:147) or 'spin' (HIP's default)."""
+        check(lib.ws_context_set_host_wait(self.handle, {"spin": 0, "block": 1}[mode]))
+
     def tile_size(self):
         """(width, height) of the binning tile in pixels (32x32 unless WS_TILE_SHAPE says otherwise)."""
         w, h = C.c_uint32(), C.c_uint32()
@@ -603,6 +607,17 @@ class GaussianRenderer:
         check(lib.ws_renderer_download_tile_stats(self.handle, 0, None, None, C.byref(nt)))
         out = np.zeros((nt.value, 17), dtype=np.uint32)
         check(lib.ws_renderer_download_wave_stats(self.handle, nt.value, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def enable_blend_timing(self, on=True):
+        check(lib.ws_renderer_enable_blend_timing(self.handle, 1 if on else 0))
+
+    def blend_timing(self):
+        """[tiles, 16 waves, 16 words] uint32 of the last render() under enable_blend_timing (layout: websplat.h)."""
+        nt = C.c_uint32()
+        check(lib.ws_renderer_download_blend_timing(self.handle, 0, None, C.byref(nt)))
+        out = np.zeros((nt.value, 16, 16), dtype=np.uint32)
+        check(lib.ws_renderer_download_blend_timing(self.handle, nt.value, out.ctypes.data_as(C.c_void_p), None))
         return out
 
     def tile_stats(self, with_consumed=False):
