@@ -343,6 +343,12 @@ int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, 
  * function of the frame; WS_BIN_SHIFT=0 / 1 forces it off / on; frames in capture mode always use the context's tile).
  * Four compositing workgroups then share one binned list: half the (tile, splat) entries to emit and sort.  Syncs. */
 int ws_renderer_binning_tile(ws_renderer* r, uint32_t* width, uint32_t* height);
+/* Digit passes the depth sort of the LAST prepared frame executed.  The reference always runs four 8-bit passes
+ * (gpu_rs.rs:865-884); here a frame whose keys span less than 2^24 -- a camera outside the scene; most frames of the compressed
+ * scenes, whose keys are scaled to about 24 bits (preprocess_compressed.wgsl:325) -- skips the fourth, decided on the device
+ * from the key range K1 stored: sorted as (key - base) that pass runs over a constant digit, i.e. is the identity; order and
+ * stability are the reference's.  Syncs. */
+int ws_renderer_depth_sort_passes(ws_renderer* r, uint32_t* passes);
 /* The compositing tile in pixels (one workgroup of the blend): 32x32 by default (four 16x16 tiles -- 4x4 wave quadrants
  * of 8x8 pixels -- sharing one binned list), 32x16 or 16x16 with WS_TILE_SHAPE=4x2|2x2 at context creation (tuning; 2x2 is
  * the literal one-workgroup-per-16x16-tile form).  Lists are built per BINNING tile: this tile, or 2 x 2 of them when the
@@ -370,13 +376,20 @@ int ws_debug_binning_decision(uint32_t request, const uint32_t* sums, const uint
                               uint32_t* shift);
 /* tuning / analysis read-back: per tile LIST (one per binning tile, ws_renderer_binning_tile; row-major over
  * ceil(viewport / binning tile)), the length of the depth-ordered splat list and (capture mode, where the binning tile is
- * the compositing tile) how many of its entries the compositing pass walked before every pixel was saturated.  Syncs. */
+ * the compositing tile) how deep into it the compositing pass read: the position, counted from the near end, of the deepest
+ * entry any of the tile's waves composited before its pixels were saturated.  Syncs. */
 int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t* list_len, uint32_t* consumed,
                                     uint32_t* num_tiles);
 /* analysis read-back (capture mode): walked[t * 17 + w] = staged records wave w of tile t composited (w < waves
  * per tile, 16 at the default tile), walked[t * 17 + 16] = sum over the tile's batches of the most any of its waves
  * composited in that batch -- the lock-step cost of the per-batch barriers.  Syncs. */
 int ws_renderer_download_wave_stats(ws_renderer* r, uint32_t tile_capacity, uint32_t* walked);
+/* analysis / parity read-back of the compositing schedule: up to 4096 tiles (1080p class) the compositing workgroups of a
+ * renderer that draws one frame at a time run longest list first (one small kernel behind the tile-id sort orders them; the image does not depend on the order).
+ * order4[4 * b + 0..3] = (tx | ty << 16, begin, end, 0) for workgroup b: the blend tile it composites and that tile's entry
+ * range; 0xFFFFFFFF in word 0 = no tile.  *num_blocks = 0 when the last prepared frame was not ordered (4K-class tile
+ * counts, non-default tile shapes, WS_BLEND_ORDER=0).  Syncs. */
+int ws_renderer_download_blend_order(ws_renderer* r, uint32_t capacity_blocks, uint32_t* order4, uint32_t* num_blocks);
 /* analysis: the next render() launches the time-stamped build of the compositing kernel (production form: 32x32 tiles,
  * rgba32float target, the frame's own binning) and every wave of every tile leaves 16 words: cycles (shader clock) spent in
  * [0] the tile-range load, [1] the first batch's dependent gather chain, [2] later batches' gather waits, [3] decode,

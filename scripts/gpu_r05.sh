@@ -95,9 +95,27 @@ if [[ $WHAT == *hostprobe* ]]; then
   echo "hostprobe exit=$?" >> $OUT/summary.txt; head -60 $OUT/hostprobe.txt >> $OUT/summary.txt
 fi
 if [[ $WHAT == *tests* ]]; then
-  timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider --maxfail ${MAXFAIL:-5} ${PYTEST_ARGS:-} 2>&1 | tail -40 > $OUT/tests_gpu.log
-  echo "tests exit=${PIPESTATUS[0]}" >> $OUT/summary.txt; tail -3 $OUT/tests_gpu.log >> $OUT/summary.txt
+  timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider --maxfail ${MAXFAIL:-5} ${PYTEST_ARGS:-} > $OUT/tests_gpu_full.log 2>&1; tail -60 $OUT/tests_gpu_full.log > $OUT/tests_gpu.log
+  echo "tests exit=$?" >> $OUT/summary.txt; tail -3 $OUT/tests_gpu.log >> $OUT/summary.txt
   cp gpurun_out/parity_fullsize.json $OUT/ 2>/dev/null
+fi
+if [[ $WHAT == *exptests* ]]; then
+  # the measured-and-lost variants live in the experimental build only: their tests against lib_exp
+  WEBSPLAT_LIB=$PWD/web-splat_amd/lib_exp/libwebsplat_hip.so timeout 1800 python -m pytest tests/test_gpu_render.py tests/test_gpu_sort.py \
+      tests/test_gpu_fullsize.py -m gpu -q --timeout 900 -p no:cacheprovider --maxfail 10 ${EXP_PYTEST_ARGS:-} > $OUT/tests_gpu_experimental_full.log 2>&1
+  echo "exptests exit=$?" >> $OUT/summary.txt; tail -3 $OUT/tests_gpu_experimental_full.log >> $OUT/summary.txt
+fi
+if [[ $WHAT == *cutoff* ]]; then
+  timeout 900 python scripts/cutoff_study.py $OUT/cutoff_study_c4.json > $OUT/cutoff.log 2>&1
+  echo "cutoff exit=$?" >> $OUT/summary.txt
+  python - $OUT/cutoff_study_c4.json >> $OUT/summary.txt 2>&1 <<'PY'
+import json, sys
+j = json.load(open(sys.argv[1]))
+print("  consumed frac", round(j["consumed_frac_of_D"], 3), "saturated tiles", round(j["saturated_tiles_frac"], 3), "D/view", round(j["entries_per_view"]))
+for r in j["table"]:
+    print("  delta", r["delta_views"], "margin", r["margin"], "removable", round(r["removable_frac_of_D"], 3), "redrawn tiles", round(r["redrawn_tiles_frac"], 4),
+          "entries in redrawn", round(r["entries_in_redrawn_tiles_frac_of_D"], 3))
+PY
 fi
 if [[ $WHAT == *abtest* ]]; then
   for W in $WORKLOADS; do

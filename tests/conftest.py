@@ -13,6 +13,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
 
 
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    """The measured-and-lost variants (WS_DEPTH_SORT=onesweep|coop, WS_BLEND_VARIANT, WS_BLEND_DMA, WS_BATCH_K1,
+    WS_FOOTPRINT=ellipse, WS_TILE_SORT=wide) are compiled only into the experimental build (make -C web-splat_amd experimental);
+    the product library refuses their switches at ws_context_create.  Their tests run when WEBSPLAT_LIB points at
+    lib_exp/libwebsplat_hip.so and are reported as SKIPPED, not failed, against the product library."""
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.failed and call.excinfo is not None and "only in the experimental build" in str(call.excinfo.value):
+        rep.outcome = "skipped"
+        rep.longrepr = (str(item.fspath), item.location[1] or 0,
+                        "Skipped: measured-and-lost variant, experimental build only (WEBSPLAT_LIB=.../lib_exp/libwebsplat_hip.so)")
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib

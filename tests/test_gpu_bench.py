@@ -117,9 +117,43 @@ def test_bench_holds_its_rate_on_a_sliver_of_the_host(tmp_path):
     assert shared["config"]["host_cpus"] == len(mine)
     assert shared["config"]["host_bound"] is False, rep
     assert shared["value"] >= 0.93 * free["value"], rep
-    # eight such ranks fit the host: cores busy per rank x 8 stays below what the box has (and, where a quota exists, the
-    # record carries it so that a throttled 8-GPU run can be told from a slow one)
-    assert 8 * shared["config"]["host_cores_busy_per_rank"] <= len(cores), rep
+    # eight such ranks fit the host with room to spare: cores busy per rank x 8 stays below three quarters of what the
+    # CONTAINER may use -- the cgroup quota where there is one (16 CPUs on this build's boxes, whatever the 256 in the affinity
+    # mask say: round-4 verdict item 2) -- and one rank stays below one core (round 4: 1.9; round 5: the host's run-ahead is
+    # bounded by sleeping on a mailbox word, ws_view_batch)
+    assert shared["config"]["host_cores_busy_per_rank"] <= 1.0, rep
+    assert 8 * shared["config"]["host_cores_busy_per_rank"] <= 0.75 * min(len(cores), quota), rep
+
+
+def test_eight_ranks_fit_the_hosts_quota():
+    """Round-4 verdict item 2(d): eight processes -- launched by bench.py itself from a plain shell, each with its own scene,
+    view batch and submission thread, all drawing on the one GPU of this box (--single-device; the collectives on host
+    tensors) -- must together stay inside what the container may use of the host: the sum of the cores the ranks keep busy
+    is below three quarters of the cgroup quota.  The GPU is shared eight ways here, so the frame rate says nothing; frames
+    per CPU-second is what the record keeps (gpurun_out/eight_rank_stand_in.json)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cores = _cpu_groups()
+    quota = bench.cpu_quota() or float(len(cores))
+    if quota < 8 or len(cores) < 16:
+        pytest.skip("needs a host share of at least 8 CPUs / 16 physical cores")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "OMP_NUM_THREADS")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--single-device", "--dist-backend", "gloo",
+                        "--workload", "c2", "--steps", "400", "--warmup", "20", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 8 and cfg["error_bits"] == 0
+    busy = cfg["host_cores_busy_per_rank"]                    # MAX over the ranks
+    rep = {"ranks": 8, "workload": cfg["workload"], "frames_per_s_all_ranks_one_gpu": out["value"], "host_cpu_quota": quota,
+           "host_cores_busy_per_rank_max": busy, "sum_upper_bound": 8 * busy,
+           "frames_per_cpu_second": out["value"] / max(8 * busy, 1e-9), "host_affinity_rank0": cfg["host_affinity"]}
+    with open(os.path.join(ROOT, "gpurun_out", "eight_rank_stand_in.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert 8 * busy <= 0.75 * quota, rep
 
 
 def test_bench_real_scene_hook(tmp_path):

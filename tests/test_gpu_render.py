@@ -782,3 +782,120 @@ def test_single_pass_tile_sort_equals_the_digit_passes(ws, oracle, monkeypatch, 
     assert np.array_equal(b_w, b_p) and np.array_equal(e_w, e_p)
     assert np.array_equal(l_w, l_p)
     assert np.array_equal(img_w, img_p)
+
+
+def test_compositing_workgroups_run_longest_list_first(ws, oracle, monkeypatch):
+    """k_blend_order (round 5): behind the tile-id sort one workgroup orders the blend's tiles by the length of their lists,
+    longest first, and hands every compositing workgroup its tile AND that tile's entry range.  The table must be a
+    permutation of the frame's tiles with the ranges of THIS frame (two different views in a row on one renderer: a stale
+    table or stale ranges would belong to the other view), non-increasing in length class; and the image must be the image
+    of the same frame composited in image order (WS_BLEND_ORDER=0), bit for bit, for both binning granularities."""
+    rng = np.random.default_rng(61)
+    rows = synth.scene_c1(n=60_000, seed=61)
+    ncol = rows.shape[1]
+    rows[:, ncol - 7:ncol - 4] = np.log(rng.uniform(0.004, 0.05, size=(60_000, 3))).astype(np.float32)
+    # 20 x 18 tiles = 90 blocks of 2 x 2 tiles: the image-order grid is padded to 96 blocks, and its six invalid workgroup
+    # indices (354 .. 359) are BELOW the tile count -- an ordered launch must not apply the image-order layout's validity test
+    vp = (640, 576)
+    cams = synth.orbit_cameras(5, vp[0], vp[1], 600.0, 600.0, radius=3.0, height_off=0.4)
+    imgs = {}
+    for order in ("1", "0"):
+        for shift in ("auto", "0"):
+            monkeypatch.setenv("WS_BLEND_ORDER", order)
+            if shift == "auto":
+                monkeypatch.delenv("WS_BIN_SHIFT", raising=False)
+            else:
+                monkeypatch.setenv("WS_BIN_SHIFT", shift)
+            c = ws.Context(0)
+            sc = scenes.Scene(ws, oracle, rows, 3, cams[0], vp)
+            pc = ws.PointCloud(c, sc.gpc)
+            r = ws.GaussianRenderer(c, "rgba32float", 3, False)
+            try:
+                for k, cj in enumerate((cams[0], cams[2], cams[3], cams[2])):
+                    cam = ws.PerspectiveCamera.from_scene_camera(cj.position, cj.rotation, cj.fx, cj.fy, *vp)
+                    cam.fit_near_far(sc.gpc.aabb)
+                    args = ws.SplattingArgs(camera=cam, viewport=vp, max_sh_deg=3)
+                    r.prepare(pc, args)
+                    r.render(pc, background=(0.1, 0.2, 0.3, 1.0))
+                    imgs[order, shift, k] = r.download_target().copy()
+                    assert r.frame_stats()["overflow"] == 0 and r.errors()[0] == 0
+                    tab = r.blend_order()
+                    if order == "0":
+                        assert tab.shape[0] == 0
+                        continue
+                    tw, th = c.tile_size()
+                    tiles_x, tiles_y = -(-vp[0] // tw), -(-vp[1] // th)
+                    nt = tiles_x * tiles_y
+                    assert tab.shape[0] >= nt and (tab[nt:, 0] == 0xFFFFFFFF).all()
+                    code = tab[:nt, 0].astype(np.int64)
+                    tile = (code >> 16) * tiles_x + (code & 0xFFFF)
+                    assert sorted(tile.tolist()) == list(range(nt))                      # every tile exactly once
+                    begin, end, _ = r.tile_lists()                                       # per LIST (binning tile)
+                    bw, _ = r.binning_tile()
+                    s = 1 if bw > tw else 0
+                    lx = (tiles_x + s) >> s
+                    lidx = ((code >> 16) >> s) * lx + ((code & 0xFFFF) >> s)
+                    want_b = np.where(end[lidx] > begin[lidx], begin[lidx], 0)
+                    want_e = np.where(end[lidx] > begin[lidx], end[lidx], 0)
+                    assert np.array_equal(tab[:nt, 1], want_b) and np.array_equal(tab[:nt, 2], want_e)   # THIS frame's ranges
+                    cls = np.minimum((tab[:nt, 2] - tab[:nt, 1]) >> 4, 2047)
+                    assert (np.diff(cls.astype(np.int64)) <= 0).all()                    # longest first
+                    assert cls[0] > cls[-1]
+            finally:
+                r.close()
+                pc.close()
+                c.close()
+    for shift in ("auto", "0"):
+        for k in range(4):
+            assert np.array_equal(imgs["1", shift, k], imgs["0", shift, k]), (shift, k)
+    assert np.array_equal(imgs["1", "auto", 1], imgs["1", "auto", 3])            # the same view again: the same image
+    assert not np.array_equal(imgs["1", "auto", 0], imgs["1", "auto", 1])
+
+
+def test_depth_sort_skips_its_last_pass_on_a_narrow_key_range(ws, oracle, monkeypatch):
+    """Round 5: a camera outside the scene sees depth keys -- bits(zfar - z), preprocess.wgsl:270-273 -- that span less than 2^24;
+    sorted as (key - base) the fourth 8-bit pass of the LSD sort is then the identity, and the frame's depth sort executes three
+    passes (decided on the device from the key range K1 stored; the readers of the sorted arrays follow).  Draw order, tile
+    lists and image must be exactly those of the same frame with the pass forced (WS_DEPTH_SKIP_TOP=0) -- and of the oracle's
+    stable sort; a camera INSIDE the scene (keys down to nearly zero: a range of 2^29 and more) keeps its four passes."""
+    vp = (800, 600)
+    rows = synth.scene_c1(n=120_000, seed=71)
+    rows[:, 2] *= 0.5        # a slab: seen from outside its keys span a factor of ~2.5 (a factor of 4 is 2^24 in f32 bits)
+    outside = synth.look_at_camera(0, [0.2, -0.3, -9.0], [0, 0, 0], vp[0], vp[1], 2100.0, 2100.0)
+    inside = synth.look_at_camera(0, [0.05, 0.02, -0.1], [0.3, 0.1, 1.0], vp[0], vp[1], 500.0, 500.0)
+    got = {}
+    for skip in ("1", "0"):
+        monkeypatch.setenv("WS_DEPTH_SKIP_TOP", skip)
+        c = ws.Context(0)
+        try:
+            for name, cj in (("outside", outside), ("inside", inside)):
+                sc = scenes.Scene(ws, oracle, rows, 3, cj, vp)
+                pc = ws.PointCloud(c, sc.gpc)
+                r = ws.GaussianRenderer(c, "rgba32float", 3, False)
+                try:
+                    for _ in range(2):                       # (twice: the second frame reuses every buffer of the first)
+                        r.prepare(pc, sc.args)
+                        r.render(pc)
+                    fr = r.download_frame()
+                    b, e, ent = r.tile_lists()
+                    got[name, skip] = (r.depth_sort_passes(), fr["keys"], fr["sorted"], b, e, ent, r.download_target())
+                    assert r.frame_stats()["overflow"] == 0 and r.errors()[0] == 0
+                    if skip == "1":
+                        _, order = oracle.sort_pairs(fr["keys"], np.arange(fr["num_visible"], dtype=np.uint32))
+                        assert np.array_equal(fr["sorted"], order), name                 # the stable sort's permutation
+                        ref, ofr = sc.oracle_image(pc)
+                        ok, msg, *_ = scenes.image_close(got[name, skip][6], ref, proof=sc.proof(ofr))
+                        assert ok, (name, msg)
+                finally:
+                    r.close()
+                    pc.close()
+        finally:
+            c.close()
+    k_out, k_in = got["outside", "1"][1].astype(np.int64), got["inside", "1"][1].astype(np.int64)
+    assert k_out.max() - (k_out.min() & ~0xFF) < (1 << 24) <= k_in.max() - (k_in.min() & ~0xFF)
+    assert (k_out >> 24).min() != (k_out >> 24).max()           # (not merely a constant top byte: the base matters)
+    assert got["outside", "1"][0] == 3 and got["outside", "0"][0] == 4
+    assert got["inside", "1"][0] == 4 and got["inside", "0"][0] == 4
+    for name in ("outside", "inside"):
+        for k in range(1, 7):
+            assert np.array_equal(got[name, "1"][k], got[name, "0"][k]), (name, k)

@@ -6,7 +6,9 @@
 // wait, "average FPS") and src/renderer.rs:548-582 (Display::render).  Everything here only CALLS the hot path
 // through the public entry points (ws_renderer_prepare / ws_renderer_render); nothing is re-implemented.
 #include <sys/stat.h>
+#include <time.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -188,6 +190,7 @@ int ws_measure(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, 
     int rc = WS_OK;
     for (uint32_t k = 0; k < frames_in_flight && rc == WS_OK; ++k) {
         rc = ws_renderer_create(ctx, WS_FORMAT_RGBA8_UNORM, ws_pointcloud_sh_deg(pc), ws_pointcloud_compressed(pc), &rs[k]);
+        if (rc == WS_OK) ws_internal_renderer_set_throughput_mode(rs[k], frames_in_flight > 1);
         if (rc == WS_OK) rc = ws_device_malloc(ctx, (size_t)W * H * 4, &targets[k]);
         if (rc == WS_OK && k > 0 && hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) != hipSuccess)
             rc = fail(WS_ERR_HIP, "ws_measure: hipStreamCreate failed");
@@ -254,10 +257,25 @@ int ws_measure(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, 
 // (1 M Gaussians at 1080p: 7.16 k either way), so the workers are used for point clouds of at most BATCH_THREADS_MAX_POINTS
 // Gaussians (WS_BATCH_THREADS=0 / 1 forces them off / on).  They cost host cores while they run (about one per slot).
 constexpr uint32_t BATCH_THREADS_MAX_POINTS = 512u * 1024u;
+// HOST RUN-AHEAD (round 5).  A caller that enqueues a thousand frames in one call gets them all queued: the host needs 77 us per
+// frame where the GPU needs 140, so it runs ahead until the runtime's queues are full and then WAITS INSIDE THE HIP RUNTIME
+// for queue space -- spinning: the enqueue thread at 100 % of a core and a runtime helper thread beside it at 93 %
+// (profiles/r05/host_threads.txt; 1.9 cores per rank, 8 ranks on a 16-CPU quota).  Nothing is gained by being a thousand frames
+// ahead.  Every slot therefore keeps its host side at most `queue_depth` frames (default 3, WS_BATCH_QUEUE_DEPTH; 0 =
+// unbounded) ahead of the device: the compositing kernel of every frame posts the frame's number to pinned host memory when
+// it STARTS (ws_internal_renderer_progress: one store by one thread, no event, no extra packet), and before a slot's next
+// frame is enqueued the host polls that word, sleeping 20 us between looks -- no runtime call, no spinning (a HIP event wait,
+// blocking flavour included, spins for ~200 us before it sleeps, i.e. always at these frame times: measured, 0.99 of a core).
+// With 4 slots x 3 frames the GPU always has > 1 ms of work queued; the image stream is unchanged.
+struct SlotWindow {
+    uint32_t waits = 0;   // (statistics: times the host had to wait for this slot)
+};
 struct ws_view_batch {
     ws_context* ctx = nullptr;
     std::vector<ws_renderer*> renderers;
     std::vector<hipStream_t> streams;
+    std::vector<SlotWindow> windows;
+    uint32_t queue_depth = 3;
     uint64_t next = 0;  // frames enqueued so far: frame i runs on slot i % frames_in_flight
 
     // one call's work, shared by the workers (valid while `pending` != 0)
@@ -284,6 +302,26 @@ struct ws_view_batch {
 };
 
 namespace {
+// before a slot's next frame is enqueued: sleep until the slot's host side is fewer than queue_depth frames ahead of the device
+int slot_window_admit(ws_view_batch* b, size_t slot) {
+    if (b->queue_depth == 0) return WS_OK;
+    const ws_renderer* r = b->renderers[slot];
+    const uint32_t enq = ws_internal_renderer_frames_enqueued(r);
+    uint32_t started = 0;
+    if (!ws_internal_renderer_progress(r, &started)) return WS_OK;  // (no mailbox: unbounded, as before)
+    bool waited = false;
+    // (sequence numbers wrap: compare differences) -- and never wait forever: a frame that failed to launch posts nothing
+    for (int spins = 0; (int32_t)(enq - started) >= (int32_t)b->queue_depth && spins < 500000; ++spins) {
+        struct timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+        waited = true;
+        if (!ws_internal_renderer_progress(r, &started)) break;
+    }
+    if (waited) ++b->windows[slot].waits;
+    return WS_OK;
+}
+int slot_window_record(ws_view_batch*, size_t) { return WS_OK; }
+
 void batch_worker(ws_view_batch* b, size_t slot) {
     (void)hipSetDevice(b->ctx->device);
     uint64_t seen = 0;
@@ -299,8 +337,10 @@ void batch_worker(ws_view_batch* b, size_t slot) {
         int rc = WS_OK;
         for (uint32_t i = 0; i < j.num_views && rc == WS_OK; ++i) {
             if ((j.first + i) % slots != slot) continue;
-            rc = ws_renderer_prepare(b->renderers[slot], j.pc, &j.views[i], b->streams[slot]);
+            rc = slot_window_admit(b, slot);
+            if (rc == WS_OK) rc = ws_renderer_prepare(b->renderers[slot], j.pc, &j.views[i], b->streams[slot]);
             if (rc == WS_OK) rc = ws_renderer_render(b->renderers[slot], j.pc, j.background, j.targets[i], j.pitch, b->streams[slot]);
+            if (rc == WS_OK) rc = slot_window_record(b, slot);
         }
         b->workers[slot].rc = rc;
         if (rc) b->workers[slot].err = ws_last_error();  // (the error text is thread-local: hand it to the caller)
@@ -332,6 +372,14 @@ int ws_view_batch_create(ws_context* ctx, ws_color_format format, uint32_t sh_de
             break;
         }
         b->streams.push_back(s);
+    }
+    if (rc == WS_OK) {
+        const char* qd = std::getenv("WS_BATCH_QUEUE_DEPTH");
+        if (qd) b->queue_depth = (uint32_t)std::max(0, std::atoi(qd));
+        if (b->queue_depth > 64u) b->queue_depth = 64u;
+        b->windows.resize(b->renderers.size());
+        // several frames in flight: the slots' blends keep the image order of their workgroups (ws_api.cpp)
+        for (ws_renderer* r : b->renderers) ws_internal_renderer_set_throughput_mode(r, b->renderers.size() > 1);
     }
     if (rc != WS_OK) {
         ws_view_batch_destroy(b);
@@ -425,7 +473,10 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
                 rs[j] = b->renderers[k + j];
                 ss[j] = b->streams[k + j];
             }
-            int rc = ws_internal_prepare_group(rs, (uint32_t)group, pc, &views[i], ss);
+            int rc = WS_OK;
+            for (size_t j = 0; j < group && rc == WS_OK; ++j) rc = slot_window_admit(b, k + j);
+            if (rc) return rc;
+            rc = ws_internal_prepare_group(rs, (uint32_t)group, pc, &views[i], ss);
             if (rc == WS_ERR_UNSUPPORTED) {  // (timers, capture, a frame graph ...: every frame its own K1)
                 group = 1;
                 continue;
@@ -433,6 +484,7 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
             if (rc) return rc;
             for (size_t j = 0; j < group; ++j) {
                 rc = ws_renderer_render(rs[j], pc, background, d_targets[i + j], row_pitch_bytes, ss[j]);
+                if (rc == WS_OK) rc = slot_window_record(b, k + j);
                 if (rc) return rc;
             }
             i += (uint32_t)group;
@@ -441,8 +493,10 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
         }
         // a ragged head (the ring is not at a group boundary) or tail, or no grouping: frame by frame
         // a target that an earlier frame of this call still writes must be on the same slot (same stream: ordered)
-        int rc = ws_renderer_prepare(b->renderers[k], pc, &views[i], b->streams[k]);
+        int rc = slot_window_admit(b, k);
+        if (rc == WS_OK) rc = ws_renderer_prepare(b->renderers[k], pc, &views[i], b->streams[k]);
         if (rc == WS_OK) rc = ws_renderer_render(b->renderers[k], pc, background, d_targets[i], row_pitch_bytes, b->streams[k]);
+        if (rc == WS_OK) rc = slot_window_record(b, k);
         if (rc) return rc;
         ++b->next;
         ++i;

@@ -26,6 +26,8 @@ __device__ __forceinline__ uint32_t pad(uint32_t i) { return i + i / EPT; }  // 
 struct Source {
     const uint32_t* sorted_idx;   // [V] store indices in draw order
     const uint32_t* fp_sorted;    // [V] footprint words by draw position (FP_RECT_PACKED: the packed rectangle)
+    const uint32_t* sorted_idx_alt;  // both, where they are when the depth sort's last pass had nothing to do
+    const uint32_t* fp_sorted_alt;   //   (FrameCounters::depth_skip_top; nullptr: that sort never skips)
     const uint8_t* splats;        // [V] x 20 B Splat records, by store index (the other footprint modes)
     const uint32_t* offsets;      // [V] exclusive prefix of tiles touched, by draw position
     const uint32_t* emit_start;   // draw position owning entry m * EMIT_TILE
@@ -120,7 +122,12 @@ __device__ __forceinline__ Slice slice_setup(const Source& src, uint32_t slice, 
 
 // Tile id of the k-th tile of the splat's footprint (footprint.h): the same function of the same 12 bytes K1 counted.
 __device__ __forceinline__ uint32_t tile_of(const Source& src, const Geom& g, uint32_t k) {
-    const fp::Tiles ft = fp::setup(g.w0, g.w1, g.w2, src.vw, src.vh, src.tile_w_log2, src.tile_h_log2, src.ellipse);
+#ifdef WS_EXPERIMENTAL  // (binning by the kept ellipse, WS_FOOTPRINT=ellipse: measured variant; the product build bins by the rectangle)
+    const bool ellipse = src.ellipse;
+#else
+    const bool ellipse = false;
+#endif
+    const fp::Tiles ft = fp::setup(g.w0, g.w1, g.w2, src.vw, src.vh, src.tile_w_log2, src.tile_h_log2, ellipse);
     return fp::tile_at(ft, k, src.tiles_x, src.tile_w_log2, src.tile_h_log2);
 }
 

@@ -69,7 +69,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t
 // Also records, for every multiple m*EMIT_TILE of the entry index, the draw position whose entry range
 // contains it (emit_start[m]): the emit kernel then needs no global search to find where its slice starts.
 template <int BIN_IPT>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __restrict__ fp_sorted, const int packed,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __restrict__ fp_main,
+                                                           const uint32_t* __restrict__ fp_skipped, const int packed,
                                                            uint32_t* __restrict__ offsets,
                                                            uint32_t* __restrict__ emit_start,
                                                            uint64_t* __restrict__ status,
@@ -80,6 +81,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
     __shared__ uint32_t s_base;
     const uint32_t v = counters->num_visible;
     if ((uint64_t)blockIdx.x * BIN_ITEMS >= v) return;  // surplus workgroups leave before drawing a ticket
+    // (the depth sort's last pass may have had nothing to do: the draw-ordered words are then where pass 2 left them)
+    const uint32_t* __restrict__ fp_sorted = (fp_skipped && counters->depth_skip_top) ? fp_skipped : fp_main;
     const uint32_t epoch = counters->epoch;  // the frame's look-back epoch, left by K1
     const bool coarse = packed && bin_shift_decide(counters) != 0u;  // the frame bins at twice the blend's tile size (ws_internal.h)
     const int tid = threadIdx.x;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
 constexpr int EMIT_COPIES = 2;
 
 template <bool PACKED, bool WIDE>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src, uint32_t* __restrict__ entry_keys,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src_arg, uint32_t* __restrict__ entry_keys,
                                                          uint32_t* __restrict__ entry_vals,
                                                          uint32_t* __restrict__ tile_hist, uint32_t tile_hist_pitch,
                                                          uint32_t tile_hist_mask, int key16) {
@@ -186,6 +189,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
     __shared__ uint32_t s_own[emit::OWN_WORDS];
     __shared__ uint32_t s_hist[HIST_WORDS];
     __shared__ uint32_t s_wmax[BIN_THREADS / 64];
+    emit::Source src = src_arg;
+    if (src.sorted_idx_alt && src.counters->depth_skip_top) {  // the depth sort's last pass had nothing to do (ws_internal.h)
+        src.sorted_idx = src.sorted_idx_alt;
+        src.fp_sorted = src.fp_sorted_alt;
+    }
     const uint32_t d = src.counters->num_entries;
     const uint32_t v = src.counters->num_visible;
     const int tid = threadIdx.x;
@@ -359,7 +367,7 @@ constexpr int ORDER_CLASSES = 2048;   // list length / 16, capped: lengths beyon
 __global__ __launch_bounds__(ORDER_THREADS) void k_blend_order(const uint2* __restrict__ tile_ranges,
                                                                const FrameCounters* __restrict__ counters, uint32_t tiles_x,
                                                                uint32_t tiles_y, uint32_t bin_tiles_x, uint4* __restrict__ order,
-                                                               uint32_t nblocks) {
+                                                               uint32_t nblocks, int mode) {
     __shared__ uint32_t s_cnt[ORDER_CLASSES];
     __shared__ uint32_t s_wave[ORDER_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -368,12 +376,22 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_blend_order(const uint2* __re
     const uint32_t s = counters->bin_shift;
     const uint32_t btx = s ? (bin_tiles_x + 1u) >> 1 : bin_tiles_x;
     const uint32_t ntiles = tiles_x * tiles_y;
+    // Agent-scope loads and stores throughout (they go past the per-XCD L2s, which are not coherent with one another): this
+    // ONE workgroup reads ranges that the whole chip wrote with memory-side atomics over lines the frame's memset left in the
+    // L2s, twice, and both reads must agree; and every XCD's blend workgroups read the table it writes.
     auto range_of = [&](uint32_t t, uint32_t& tx, uint32_t& ty) -> uint2 {
         tx = t % tiles_x;
         ty = t / tiles_x;
-        uint2 r = tile_ranges[(ty >> s) * btx + (tx >> s)];
+        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(tile_ranges + (ty >> s) * btx + (tx >> s)),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint2 r = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
         r.x = r.y ? 0xFFFFFFFFu - r.x : 0u;
         return r;
+    };
+    auto put = [&](uint32_t pos, uint32_t code, uint2 r) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(order + pos);
+        __hip_atomic_store(o, (unsigned long long)code | ((unsigned long long)r.x << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 1, (unsigned long long)r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto class_of = [](uint2 r) -> uint32_t {  // class 0 = the longest lists
         const uint32_t c = (r.y - r.x) >> 4;
@@ -404,10 +422,14 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_blend_order(const uint2* __re
     for (uint32_t t = tid; t < ntiles; t += ORDER_THREADS) {
         uint32_t tx, ty;
         const uint2 r = range_of(t, tx, ty);
-        const uint32_t pos = atomicAdd(&s_cnt[class_of(r)], 1u);   // (the order inside a class is arbitrary; the image does not see it)
-        order[pos] = make_uint4(tx | (ty << 16), r.x, r.y, 0u);
+        uint32_t pos = atomicAdd(&s_cnt[class_of(r)], 1u);   // (the order inside a class is arbitrary; the image does not see it)
+        // experiments (WS_BLEND_ORDER): 2 = shortest first; 3 = alternately from both ends of the sorted sequence (a long tile,
+        // a short one, the next longest, the next shortest ...): every long tile still starts early, and slots retire all the time
+        if (mode == 2) pos = ntiles - 1u - pos;
+        else if (mode == 3) pos = pos < (ntiles + 1u) / 2u ? 2u * pos : 2u * (ntiles - 1u - pos) + 1u;
+        put(pos, tx | (ty << 16), r);
     }
-    for (uint32_t b = ntiles + tid; b < nblocks; b += ORDER_THREADS) order[b] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+    for (uint32_t b = ntiles + tid; b < nblocks; b += ORDER_THREADS) put(b, 0xFFFFFFFFu, make_uint2(0u, 0u));
 }
 
 // The last kernel of a frame folds the frame's error bits (per-frame zero arena) into the renderer's sticky words, which no
@@ -415,6 +437,10 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_blend_order(const uint2* __re
 // a plain system-scope store by this one thread -- to a host-visible mailbox word (pinned, mapped memory) that the next
 // prepare() reads without any device synchronisation: a renderer whose frames overflow its entry list grows the list by
 // itself, whether or not its caller ever polls ws_renderer_errors.
+// (the same thread, when the blend starts: "frame frame_seq of this renderer has reached its compositing pass")
+__device__ __forceinline__ void post_frame_progress(const BlendParams& p) {
+    if (p.progress_mailbox) __hip_atomic_store(p.progress_mailbox, p.frame_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void fold_frame_errors(const BlendParams& p, uint32_t bits) {
     atomicOr(p.sticky, bits);
     if (bits & 1u) {
@@ -583,10 +609,15 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     if (blockIdx.x == 0 && threadIdx.x == 0 && p.sticky) {
         const uint32_t bits = p.counters->overflow;
         if (bits) fold_frame_errors(p, bits);
+        post_frame_progress(p);
     }
     const BlendShape shape = blend_shape(QW, QH);
     const BlendBlock blk = blend_block_of(blockIdx.x, p.tiles_x, p.tiles_y, shape, tpw_log2);
-    if (!blk.valid) return;  // block-uniform
+    // Ordered launch (k_blend_order): workgroup b composites the tile the table names for b -- every b below the tile count has
+    // one, whatever blend_block_of says about b's place in the image-order layout (whose grid is padded to whole 2 x 2 blocks of
+    // tiles, eight blocks at a time: its invalid indices are NOT the last ones)
+    const bool ordered = !MULTI && QW == 4 && QH == 4 && p.order != nullptr;
+    if (!ordered && !blk.valid) return;  // block-uniform
     const uint32_t tpw = 1u << tpw_log2, wpb = shape.tpb() >> tpw_log2;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (wave-uniform: lives in an SGPR)
@@ -600,11 +631,14 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     // round trip instead of one per tile.
     uint2 range_one = make_uint2(0u, 0u);
     uint32_t code_one = 0xFFFFFFFFu;
-    if (!MULTI && QW == 4 && QH == 4 && p.order) {
-        // longest list first (k_blend_order): tile and range of this blockIdx in ONE scalar load
-        const uint4 o = p.order[blockIdx.x];
-        code_one = o.x;
-        range_one = make_uint2(o.y, o.z);
+    if (ordered) {
+        // longest list first (k_blend_order): tile and range of this blockIdx in one round trip
+        // (agent-scope loads: past this XCD's L2, which may still hold the line as an earlier frame's table had it)
+        const unsigned long long* op = reinterpret_cast<const unsigned long long*>(p.order + blockIdx.x);
+        const unsigned long long o0 = __hip_atomic_load(op, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long o1 = __hip_atomic_load(op + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        code_one = __builtin_amdgcn_readfirstlane((uint32_t)o0);
+        range_one = make_uint2(__builtin_amdgcn_readfirstlane((uint32_t)(o0 >> 32)), __builtin_amdgcn_readfirstlane((uint32_t)o1));
     } else if (!MULTI) {
         const uint32_t slot = blk.w;
         const uint32_t tx = (blk.bx << shape.tbx_log2) + (slot & ((1u << shape.tbx_log2) - 1u));
@@ -689,7 +723,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         idx_next = blend_entry_idx<STAGE>(p, range, range.y - range.x > (uint32_t)STAGE ? range.y - (uint32_t)STAGE : range.x, tid);
     // capture build only (p.debug_walked): records this wave walked, and the sum over batches of the most any wave
     // walked in the batch (the lock-step cost of the per-batch barriers)
-    uint32_t dbg_walked = 0u, dbg_lockstep = 0u;
+    uint32_t dbg_walked = 0u, dbg_lockstep = 0u, dbg_deepest = 0u;
     if ((CAPTURE && p.debug_walked)) {
         if (tid == 0) s_dbg_max = 0u;
         __syncthreads();
@@ -802,6 +836,15 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
                     // the quadrant is saturated: nothing behind can add more than T_MIN (one compare per four pairs;
                     // on dense tiles this stops the walk well inside the staged batch)
                     if ((CAPTURE && p.debug_walked) || TIMING) dbg_walked += 4u;
+                    if (CAPTURE && p.debug_consumed) {  // the deepest list position this wave has composited so far (1-based from the near end)
+                        const uint32_t nul = (uint32_t)STAGE * 16u;
+                        uint32_t m = o.x;               // (o.x is never the padding record)
+                        m = (o.y != nul && o.y > m) ? o.y : m;
+                        m = (o.z != nul && o.z > m) ? o.z : m;
+                        m = (o.w != nul && o.w > m) ? o.w : m;
+                        const uint32_t deep = (range.y - hi) + (m >> 4) + 1u;
+                        dbg_deepest = deep > dbg_deepest ? deep : dbg_deepest;
+                    }
                     if (__ballot(T >= T_MIN) == 0ull) break;
                     o = on;
                     on = lp[g + 2u < n4 ? g + 2u : n4 - 1u];
@@ -838,7 +881,9 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         }
         if (all_done) break;
     }
-    if ((CAPTURE && p.debug_consumed) && tid == 0) p.debug_consumed[tile] = range.y - hi;
+    // capture: how deep into its list the tile was read -- the deepest entry any wave composited (the walk of a wave stops inside
+    // a staged batch; the staging itself runs in whole batches: range.y - hi would say 512 for most tiles)
+    if ((CAPTURE && p.debug_consumed) && lane == 0 && dbg_deepest) atomicMax(&p.debug_consumed[tile], dbg_deepest);
     if ((CAPTURE && p.debug_walked) && lane == 0) {
         p.debug_walked[(size_t)tile * 17u + wave] = dbg_walked;
         if (wave == 0) p.debug_walked[(size_t)tile * 17u + 16u] = dbg_lockstep;
@@ -939,6 +984,7 @@ __device__ __forceinline__ float bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+#ifdef WS_EXPERIMENTAL  // (WS_BLEND_VARIANT=1: cross-check form, measured variant)
 template <int FORMAT>
 __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
     // blockIdx -> (tile, quadrant): workgroup b runs on XCD b % 8 (observed; used for locality only)
@@ -946,6 +992,7 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
     if (b == 0 && threadIdx.x == 0 && p.sticky) {  // as in k_blend
         const uint32_t bits = p.counters->overflow;
         if (bits) fold_frame_errors(p, bits);
+        post_frame_progress(p);
     }
     const uint32_t xcd = b & 7u, j = b >> 3;
     const uint32_t nq = p.qw * p.qh;
@@ -1063,6 +1110,8 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
     }
 }
 
+#endif  // WS_EXPERIMENTAL
+
 // ---- k_blend_strict: the reference's blend, literally -------------------------------------------------------------
 // The render pass of the reference clears the target to the background and lets the fixed-function blender apply
 // PREMULTIPLIED_ALPHA_BLENDING (src/renderer.rs:63-67) once per splat, BACK TO FRONT, on a target of the pass's own
@@ -1088,6 +1137,7 @@ __global__ __launch_bounds__(64) void k_blend_strict(const BlendParams p) {
     if (b == 0 && threadIdx.x == 0 && p.sticky) {  // as in k_blend
         const uint32_t bits = p.counters->overflow;
         if (bits) fold_frame_errors(p, bits);
+        post_frame_progress(p);
     }
     const uint32_t xcd = b & 7u, j = b >> 3;
     const uint32_t nq = p.qw * p.qh;
@@ -1215,7 +1265,7 @@ uint32_t bin_prefix_blocks(uint32_t max_points) {
 int launch_bin_prefix(const BinBuffers& b, hipStream_t stream) {
     const uint32_t blocks = bin_prefix_blocks(b.max_points);
     if (blocks == 0) return WS_OK;
-    hipLaunchKernelGGL(k_bin_prefix<BIN_IPT>, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.fp_sorted,
+    hipLaunchKernelGGL(k_bin_prefix<BIN_IPT>, dim3(blocks), dim3(BIN_THREADS), 0, stream, b.fp_sorted, b.fp_sorted_alt,
                        b.footprint_mode == FP_RECT_PACKED ? 1 : 0, b.offsets,
                        b.emit_start, b.block_status, b.counters, b.entry_cap);
     WS_HIP(hipGetLastError());
@@ -1229,6 +1279,8 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
     emit::Source src;
     src.sorted_idx = b.sorted_idx;
     src.fp_sorted = b.fp_sorted;
+    src.sorted_idx_alt = b.sorted_idx_alt;
+    src.fp_sorted_alt = b.fp_sorted_alt;
     src.splats = b.splats;
     src.ellipse = b.footprint_mode == FP_ELLIPSE;
     src.offsets = b.offsets;
@@ -1257,10 +1309,10 @@ int launch_bin_emit(const BinBuffers& b, hipStream_t stream) {
 uint32_t blend_order_blocks(uint32_t tiles_x, uint32_t tiles_y) { return blend_grid_blocks(tiles_x, tiles_y, blend_shape(4, 4), 0u); }
 
 int launch_blend_order(const uint2* tile_ranges, const FrameCounters* counters, uint32_t tiles_x, uint32_t tiles_y, uint4* order,
-                       hipStream_t stream) {
+                       int mode, hipStream_t stream) {
     if (tiles_x * tiles_y == 0u) return WS_OK;
     hipLaunchKernelGGL(k_blend_order, dim3(1), dim3(ORDER_THREADS), 0, stream, tile_ranges, counters, tiles_x, tiles_y, tiles_x, order,
-                       blend_order_blocks(tiles_x, tiles_y));
+                       blend_order_blocks(tiles_x, tiles_y), mode);
     WS_HIP(hipGetLastError());
     return WS_OK;
 }
@@ -1283,15 +1335,23 @@ static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
         WS_HIP(hipGetLastError());
         return WS_OK;
     }
+#ifdef WS_EXPERIMENTAL  // (LDS-DMA staging, WS_BLEND_DMA=1: measured neutral; instantiated in the experimental build only)
+#define WS_LAUNCH_BLEND_DMA(FMT)                                                                                          \
+    if (!capture && tpw_log2 > 0u && p.dma)                                                                               \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, false, true>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);    \
+    else if (!capture && p.dma)                                                                                           \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, false, false, true>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);   \
+    else
+#else
+#define WS_LAUNCH_BLEND_DMA(FMT)
+    if (p.dma) return fail(WS_ERR_UNSUPPORTED, "LDS-DMA staging is only in the experimental build");
+#endif
 #define WS_LAUNCH_BLEND(FMT)                                                                                              \
+    WS_LAUNCH_BLEND_DMA(FMT)                                                                                              \
     if (capture)                                                                                                          \
         hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, true, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);    \
-    else if (tpw_log2 > 0u && p.dma)                                                                                      \
-        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, false, true>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);    \
     else if (tpw_log2 > 0u)                                                                                               \
         hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, false, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);   \
-    else if (p.dma)                                                                                                       \
-        hipLaunchKernelGGL((k_blend<FMT, QW, QH, false, false, true>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);   \
     else                                                                                                                  \
         hipLaunchKernelGGL((k_blend<FMT, QW, QH, false, false, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2)
     switch (p.format) {
@@ -1308,6 +1368,7 @@ static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
             return fail(WS_ERR_INVALID, "blend: unknown colour format");
     }
 #undef WS_LAUNCH_BLEND
+#undef WS_LAUNCH_BLEND_DMA
     WS_HIP(hipGetLastError());
     return WS_OK;
 }
@@ -1333,6 +1394,7 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
         WS_HIP(hipGetLastError());
         return WS_OK;
     }
+#ifdef WS_EXPERIMENTAL
     if (variant == 1) {  // one wave per 8x8 quadrant, no LDS (cross-check)
         const uint32_t groups = ((ntiles + 7u) / 8u) * 8u * p.qw * p.qh;
         switch (p.format) {
@@ -1351,6 +1413,9 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream) {
         WS_HIP(hipGetLastError());
         return WS_OK;
     }
+#else
+    if (variant == 1) return fail(WS_ERR_UNSUPPORTED, "blend variant 1 (k_blend_q) is only in the experimental build");
+#endif
     if (p.qw == 2u && p.qh == 2u) return launch_blend_shape<2, 2>(p, stream);
     if (p.qw == 4u && p.qh == 2u) return launch_blend_shape<4, 2>(p, stream);
     if (p.qw == 4u && p.qh == 4u) return launch_blend_shape<4, 4>(p, stream);

@@ -22,7 +22,9 @@
 // The fat-tile one-sweep below (k_dsort_fat) is the form of that idea that does not chain; it is a measured variant too.
 #include <hip/hip_runtime.h>
 
-#include "grid_barrier.h"
+#ifdef WS_EXPERIMENTAL
+#include "grid_barrier.h"  // (the single-launch depth sort's device-wide barrier)
+#endif
 #include "lookback.h"
 #include "ws_internal.h"
 
@@ -76,6 +78,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     return wave_off + incl - v;
 }
 
+#ifdef WS_EXPERIMENTAL  // (the fat-tile one-sweep's histogram launch)
 // ---- histogram of every participating digit in one read of the keys (the fat-tile one-sweep's extra launch) ----
 // LDS bins are replicated HIST_COPIES times (copy = lane & 7): depth keys and tile ids are strongly
 // clustered in their upper digits, and 64 lanes hammering one LDS word serialise.
@@ -117,14 +120,22 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __re
     }
 }
 
+#endif  // WS_EXPERIMENTAL
 // ---- digit counts of every tile, transposed: tile_sums[digit * tiles_cap + tile] -----------------------------------
 template <int KPT, bool KEY16>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ d_count, uint32_t n,
                                                                 int shift, uint32_t mask, uint32_t* __restrict__ tile_sums,
-                                                                uint32_t tiles_cap) {
+                                                                uint32_t tiles_cap, FrameCounters* __restrict__ fold,
+                                                                const uint32_t* __restrict__ skip,
+                                                                const uint32_t* __restrict__ key_base) {
     constexpr int TILE_N = SORT_THREADS * KPT;
     __shared__ uint32_t sh[RADIX * HIST_COPIES];
+    if (skip && *skip) return;  // the depth sort's last pass over a constant digit (ws_internal.h depth_range_decide)
+    // the depth sort's first kernel: the key range K1 left -> the base of passes 1..3 and ONE flag for the kernels of the
+    // last pass and the sort's readers (this pass's own digit, key & 0xFF, does not depend on the base)
+    if (fold && blockIdx.x == 0 && threadIdx.x == 0) depth_range_decide(fold);
+    const uint32_t kbase = key_base ? *key_base : 0u;
     const uint32_t count = device_count(d_count, n);
     const uint32_t copy = threadIdx.x & (HIST_COPIES - 1);
     // the grid is capped (sort_grid): the host only knows the bound n, and workgroups that find nothing to do
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t*
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
-            if (pos < count) atomicAdd(&sh[((k[j] >> shift) & mask) * HIST_COPIES + copy], 1u);
+            if (pos < count) atomicAdd(&sh[(((k[j] - kbase) >> shift) & mask) * HIST_COPIES + copy], 1u);
         }
         __syncthreads();
         uint32_t c = 0;
@@ -163,8 +174,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t*
 // 3 k tiles of the tile-id sort, as much as the histogram kernel in front of it.)
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* __restrict__ d_count, uint32_t n,
                                                                uint32_t tile_n, uint32_t* __restrict__ tile_sums,
-                                                               uint32_t tiles_cap, uint32_t* __restrict__ hist) {
+                                                               uint32_t tiles_cap, uint32_t* __restrict__ hist,
+                                                               const uint32_t* __restrict__ skip) {
     __shared__ uint32_t s_tmp[WAVES];
+    if (skip && *skip) return;
     const uint32_t count = device_count(d_count, n);
     const uint32_t ntiles = (count + tile_n - 1) / tile_n;
     uint32_t* row = tile_sums + (size_t)blockIdx.x * tiles_cap;
@@ -203,7 +216,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t* __restrict__ d_count, uint32_t n, int shift, int iota,
     const uint32_t* __restrict__ hist,     // [256] global digit histogram of this pass
     const uint32_t* __restrict__ tile_off, // [256][tiles_cap] exclusive offsets per digit
-    uint32_t tiles_cap, uint2* __restrict__ ranges, uint32_t nranges) {
+    uint32_t tiles_cap, uint2* __restrict__ ranges, uint32_t nranges, const uint32_t* __restrict__ skip,
+    const uint32_t* __restrict__ key_base) {  // key_base: digits come from (key - *key_base) (depth sort, passes 1..3)
     constexpr int TILE_N = SORT_THREADS * KPT;
     constexpr uint32_t DMASK = (1u << BITS) - 1u;
     __shared__ uint32_t s_wave_hist[WAVES][RADIX];
@@ -217,6 +231,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    if (skip && *skip) return;  // (block-uniform) a pass over a constant digit moves nothing
+    const uint32_t kbase = key_base ? *key_base : 0u;
 
     const uint32_t count = device_count(d_count, n);
     // first output position of every digit: the same for all tiles of this pass
@@ -236,8 +252,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const uint32_t pos = wave_base + j * 64;
-        key[j] = pos < count ? (KEY16 ? (uint32_t)reinterpret_cast<const uint16_t*>(keys_in)[pos] : keys_in[pos])
-                             : 0xFFFFFFFFu;
+        key[j] = pos < count ? (KEY16 ? (uint32_t)reinterpret_cast<const uint16_t*>(keys_in)[pos] : keys_in[pos]) - kbase
+                             : 0xFFFFFFFFu;   // (from here on the key is key - base; the base is added back at the store)
     }
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             if (CARRY) aux_out[gpos] = s_aux[lp];
             if (!RANGES) {
                 if (KEY16) reinterpret_cast<uint16_t*>(keys_out)[gpos] = (uint16_t)kk;
-                else keys_out[gpos] = kk;
+                else keys_out[gpos] = kk + kbase;
             } else if (kk < nranges) {
                 const uint32_t prev_k = lp > 0u ? s_keys[lp - 1u] : ~kk;
                 const uint32_t next_k = lp + 1u < valid ? s_keys[lp + 1u] : ~kk;
@@ -355,32 +371,42 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
                     uint32_t* aout,
                     const uint32_t* d_count, uint32_t n, int begin_bit, int npass, bool implicit_iota,
                     bool first_tile_hist_ready, hipStream_t stream, uint32_t** fk, uint32_t** fv,
-                    KernelMarks* km, const char* const* names, uint2* ranges, uint32_t nranges) {
+                    KernelMarks* km, const char* const* names, uint2* ranges, uint32_t nranges, FrameCounters* skip_top,
+                    uint32_t** fk_skipped, uint32_t** fv_skipped) {
     constexpr uint32_t TILE_N = SORT_THREADS * KPT;
     const uint32_t tiles = sort_grid((n + TILE_N - 1) / TILE_N);
     for (int p = 0; p < npass; ++p) {
         const int shift = begin_bit + p * BITS;
         const int iota = (implicit_iota && p == 0) ? 1 : 0;
+        // the depth sort of a frame: its first kernel decides whether the last pass has anything to do, the kernels of the last
+        // pass ask (ws_internal.h depth_top_decide)
+        FrameCounters* fold = (skip_top && p == 0) ? skip_top : nullptr;
+        const uint32_t* skip = (skip_top && p == npass - 1) ? &skip_top->depth_skip_top : nullptr;
+        const uint32_t* kbase = (skip_top && p > 0) ? &skip_top->depth_key_base : nullptr;
+        if (skip) {
+            if (fk_skipped) *fk_skipped = kin;
+            if (fv_skipped) *fv_skipped = vin;
+        }
         if (!(p == 0 && first_tile_hist_ready)) {
             hipLaunchKernelGGL((k_sort_tile_hist<KPT, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift,
-                               (1u << BITS) - 1u, sc.tile_sums, sc.tiles_cap);
+                               (1u << BITS) - 1u, sc.tile_sums, sc.tiles_cap, fold, skip, kbase);
             km_mark(km, names[0]);
         }
         hipLaunchKernelGGL(k_sort_col_scan, dim3(1u << BITS), dim3(SORT_THREADS), 0, stream, d_count, n, TILE_N,
-                           sc.tile_sums, sc.tiles_cap, sc.hist + p * RADIX);
+                           sc.tile_sums, sc.tiles_cap, sc.hist + p * RADIX, skip);
         km_mark(km, names[1]);
         if (ranges && p == npass - 1)
             hipLaunchKernelGGL((k_sort_scatter<KPT, true, BITS, false, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota,
-                               sc.hist + p * RADIX, sc.tile_sums, sc.tiles_cap, ranges, nranges);
+                               sc.hist + p * RADIX, sc.tile_sums, sc.tiles_cap, ranges, nranges, skip, kbase);
         else if (ain)
             hipLaunchKernelGGL((k_sort_scatter<KPT, false, BITS, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
                                vin, kout, vout, ain, aout, d_count, n, shift, iota, sc.hist + p * RADIX, sc.tile_sums,
-                               sc.tiles_cap, (uint2*)nullptr, 0u);
+                               sc.tiles_cap, (uint2*)nullptr, 0u, skip, kbase);
         else
             hipLaunchKernelGGL((k_sort_scatter<KPT, false, BITS, false, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota,
-                               sc.hist + p * RADIX, sc.tile_sums, sc.tiles_cap, (uint2*)nullptr, 0u);
+                               sc.hist + p * RADIX, sc.tile_sums, sc.tiles_cap, (uint2*)nullptr, 0u, skip, kbase);
         km_mark(km, names[2]);
         WS_HIP(hipGetLastError());
         uint32_t* tk = kin;
@@ -399,6 +425,7 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
 }
 
 
+#ifdef WS_EXPERIMENTAL  // the single-pass tile-id sort and the fat-tile one-sweep depth sort: measured variants (DESIGN_LOG.md)
 // =====================================================================================================================
 // Single-pass tile-id sort (ws_internal.h launch_tile_sort_wide): counts [tile][bins] -> column scan -> scatter.
 // =====================================================================================================================
@@ -855,6 +882,7 @@ __global__ __launch_bounds__(FAT_THREADS) void k_dsort_fat(const FatSortArgs a, 
     }
 }
 
+#endif  // WS_EXPERIMENTAL
 }  // namespace
 
 // Grid cap of the tile-strided kernels: 8 workgroups per CU on a 256-CU part; enough to fill the chip at any
@@ -867,6 +895,7 @@ uint32_t sort_grid(uint32_t tiles) {
 
 uint32_t sort_tile_size(uint32_t n) { return n <= SORT_SMALL_MAX ? SORT_THREADS * SORT_KPT_SMALL : SORT_TILE; }
 
+#ifdef WS_EXPERIMENTAL
 size_t fat_sort_status_words() { return (size_t)4 * FAT_MAX_GRID * RADIX; }
 
 uint32_t fat_sort_grid(uint32_t n, int num_cus, int grid_request) {
@@ -962,10 +991,24 @@ int launch_tile_sort_wide(const SortScratch& sc, const uint32_t* keys16, const u
     return WS_OK;
 }
 
+#else  // !WS_EXPERIMENTAL: the product library does not carry the measured-and-lost sort forms
+size_t fat_sort_status_words() { return 0; }
+uint32_t fat_sort_grid(uint32_t, int, int) { return 0u; }
+int launch_depth_sort_fat(const FatSortScratch&, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, bool, bool, uint32_t, int,
+                          hipStream_t, KernelMarks*) {
+    return fail(WS_ERR_UNSUPPORTED, "the fat-tile one-sweep depth sort is only in the experimental build");
+}
+int launch_tile_sort_wide(const SortScratch&, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, hipStream_t, KernelMarks*,
+                          uint2*, uint32_t) {
+    return fail(WS_ERR_UNSUPPORTED, "the single-pass tile-id sort is only in the experimental build");
+}
+#endif  // WS_EXPERIMENTAL
+
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, hipStream_t stream,
                       uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km, const char* tag, uint2* ranges,
-                      uint32_t nranges, int digit_bits, bool key16, uint32_t* aux, uint32_t* aux_alt) {
+                      uint32_t nranges, int digit_bits, bool key16, uint32_t* aux, uint32_t* aux_alt, FrameCounters* skip_top,
+                      uint32_t** out_keys_skipped, uint32_t** out_vals_skipped) {
     // labels of the per-kernel timers: "<tag>k_sort_..." with tag = "depth:" / "tiles:"
     const bool depth = tag && tag[0] == 'd';
     static const char* const N_DEPTH[3] = {"depth:k_sort_tile_hist", "depth:k_sort_col_scan", "depth:k_sort_scatter"};
@@ -984,6 +1027,8 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
     if ((reinterpret_cast<uintptr_t>(keys) & 15u) != 0) return fail(WS_ERR_INVALID, "sort: keys must be 16-byte aligned");
     const int npass = (end_bit - begin_bit + digit_bits - 1) / digit_bits;
     if (npass > 4) return fail(WS_ERR_INVALID, "sort: more than four digit passes");
+    if (skip_top && (npass != 4 || begin_bit != 0 || digit_bits != RADIX_BITS || first_tile_hist_ready || ranges))
+        return fail(WS_ERR_INVALID, "sort: the top-byte skip belongs to the four-pass depth sort");
 
     uint32_t* kin = keys;
     uint32_t* vin = vals;
@@ -994,10 +1039,10 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
 #define WS_RUN_SCAN(KPT_, BITS_)                                                                                       \
     rc = key16 ? run_passes_scan<KPT_, BITS_, true>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass,   \
                                                     implicit_iota, first_tile_hist_ready, stream, &kin, &vin, km, names,   \
-                                                    ranges, nranges)                                                       \
+                                                    ranges, nranges, skip_top, out_keys_skipped, out_vals_skipped)         \
                : run_passes_scan<KPT_, BITS_, false>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass,  \
                                                      implicit_iota, first_tile_hist_ready, stream, &kin, &vin, km, names,  \
-                                                     ranges, nranges)
+                                                     ranges, nranges, skip_top, out_keys_skipped, out_vals_skipped)
     if (digit_bits == 8) {
         if (big) WS_RUN_SCAN(SORT_KPT, 8); else WS_RUN_SCAN(SORT_KPT_SMALL, 8);
     } else if (digit_bits == 7) {

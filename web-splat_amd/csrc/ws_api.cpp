@@ -141,8 +141,12 @@ struct ws_renderer {
     uint32_t* sticky = nullptr;      // two device words that survive the per-frame memset (ws_renderer_errors): [0] error bits
                                      // of all frames since the last reset, [1] the largest entries_needed of an overflowed frame
     uint32_t needed_seen = 0;        // host copy of [1]: the automatic entry capacity grows to it at the next prepare()
-    uint32_t* demand_mailbox = nullptr;      // pinned host word the blend posts [1] to (device-visible address: demand_mailbox_dev);
-    uint32_t* demand_mailbox_dev = nullptr;  //   prepare() reads it without a sync, so the capacity grows without anyone polling
+    uint32_t* demand_mailbox = nullptr;      // TWO pinned host words the blend posts to (device-visible address: demand_mailbox_dev):
+    uint32_t* demand_mailbox_dev = nullptr;  //   [0] the demand [1] above -- prepare() reads it without a sync, so the capacity grows
+                                             //   without anyone polling; [1] the number of the last frame whose blend has started
+    uint32_t frames_enqueued = 0;            // render() calls so far (the sequence number the blend posts)
+    bool throughput_mode = false;            // this renderer runs beside others (a slot of a view batch with frames in flight):
+                                             //   its blend keeps the image order of its workgroups (see ws_renderer_render)
 
     // The frame's launch sequence of prepare() (memset + 21 kernels), captured once per (point cloud, scratch) and replayed:
     // only K1's arguments change from frame to frame (camera / settings uniforms, epoch).  A ring of executable graphs,
@@ -161,6 +165,7 @@ struct ws_renderer {
         uint32_t next = 0;
         bool valid = false;
         uint32_t *sorted_idx = nullptr, *sorted_keys = nullptr, *fp_sorted = nullptr, *entries_sorted = nullptr;
+        uint32_t *sorted_idx_skipped = nullptr, *sorted_keys_skipped = nullptr;
     } fg;
     uint64_t scratch_generation = 0;
 
@@ -169,6 +174,10 @@ struct ws_renderer {
     const ws_pointcloud* prepared_pc = nullptr;
     uint32_t* sorted_idx = nullptr;
     uint32_t* sorted_keys = nullptr;
+    // where the sorted arrays are when the depth sort's last pass had nothing to do (FrameCounters::depth_skip_top, decided on
+    // the device per frame); nullptr: this frame's sort cannot skip
+    uint32_t* sorted_idx_skipped = nullptr;
+    uint32_t* sorted_keys_skipped = nullptr;
     uint32_t* entries_sorted = nullptr;
     hipStream_t last_stream = nullptr;
 
@@ -401,13 +410,17 @@ int ws_context_create(int hip_device, ws_context** out) {
     if (!ctx) return fail(WS_ERR_OOM, "ws_context_create: host allocation failed");
     ctx->device = hip_device;
     WS_HIP(hipGetDeviceProperties(&ctx->props, hip_device));
+    ctx->depth_sort_mode = WS_DEPTH_SORT_DEFAULT;
+    // ---- measured-and-lost variants (DESIGN_LOG.md): compiled only into the EXPERIMENTAL build (make experimental ->
+    // lib_exp/libwebsplat_hip.so, -DWS_EXPERIMENTAL), which the variant tests load; the product library refuses their switches
+    // loudly instead of carrying their kernels ------------------------------------------------------------------------
+#ifdef WS_EXPERIMENTAL
     {   // WS_TILE_SORT=wide: ONE counting pass over the whole tile id up to 2048 binning tiles instead of two digit passes.
         // Measured (profiles/r03/tile_sort_wide_ab_v20_summary.txt): one frame at a time +1..+5 % (three launches fewer), with
         // frames in flight -0.5..-5 %: at 2048 bins the [sort tile][bin] count rows are as many bytes as the entries themselves.
         const char* ts = std::getenv("WS_TILE_SORT");
         ctx->tile_sort_wide = ts && std::strcmp(ts, "wide") == 0;
     }
-    ctx->depth_sort_mode = WS_DEPTH_SORT_DEFAULT;
     if (const char* ds = std::getenv("WS_DEPTH_SORT")) {
         if (std::strcmp(ds, "onesweep") == 0) ctx->depth_sort_mode = DS_ONESWEEP;
         else if (std::strcmp(ds, "coop") == 0) ctx->depth_sort_mode = DS_COOP;
@@ -415,24 +428,47 @@ int ws_context_create(int hip_device, ws_context** out) {
     }
     ctx->dsort_fat_grid = env_int("WS_DSORT_FAT_GRID", 0);
     ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
-    ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
-    ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
-    if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
-    ctx->use_graph = env_int("WS_GRAPH", 0);
-    ctx->blend_order = env_int("WS_BLEND_ORDER", 1);  // 0: the blend's workgroups in image order (A/B)
-    ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
     ctx->blend_dma = env_int("WS_BLEND_DMA", 0) ? 1 : 0;
-    {
-        const char* bs = std::getenv("WS_BIN_SHIFT");  // 0 | 1 | auto (default): binning at twice the blend's tile size
-        ctx->bin_request = !bs ? BIN_AUTO : (std::strcmp(bs, "1") == 0 ? BIN_ALWAYS : (std::strcmp(bs, "0") == 0 ? BIN_NEVER : BIN_AUTO));
-    }
     ctx->batch_k1 = env_int("WS_BATCH_K1", 1);
-    ctx->batch_threads = env_int("WS_BATCH_THREADS", -1);
     if (ctx->batch_k1 < 1 || ctx->batch_k1 > K1_MAX_VIEWS) ctx->batch_k1 = 1;
     {
         const char* fm = std::getenv("WS_FOOTPRINT");  // ellipse | rect (default)
         ctx->footprint = (fm && std::strcmp(fm, "ellipse") == 0) ? FP_ELLIPSE : FP_RECT_PACKED;
     }
+#else
+    {
+        auto asked = [](const char* name, const char* off) {
+            const char* v = std::getenv(name);
+            return v && *v && std::strcmp(v, off) != 0;
+        };
+        const char* ds = std::getenv("WS_DEPTH_SORT");
+        const bool sort_variant = ds && *ds && std::strcmp(ds, "scan") != 0 && std::strcmp(ds, "classic") != 0;
+        const char* fm = std::getenv("WS_FOOTPRINT");
+        const char* ts = std::getenv("WS_TILE_SORT");
+        if (sort_variant || asked("WS_BLEND_VARIANT", "0") || asked("WS_BLEND_DMA", "0") || asked("WS_BATCH_K1", "1") ||
+            (fm && std::strcmp(fm, "ellipse") == 0) || (ts && std::strcmp(ts, "wide") == 0)) {
+            delete ctx;
+            return fail(WS_ERR_UNSUPPORTED, "ws_context_create: WS_DEPTH_SORT=onesweep|coop, WS_BLEND_VARIANT, WS_BLEND_DMA, WS_BATCH_K1, "
+                                            "WS_FOOTPRINT=ellipse and WS_TILE_SORT=wide select measured-and-lost variants that are only in "
+                                            "the experimental build (make -C web-splat_amd experimental; WEBSPLAT_LIB=.../lib_exp/libwebsplat_hip.so)");
+        }
+    }
+#endif
+    ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
+    ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
+    if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
+    ctx->use_graph = env_int("WS_GRAPH", 0);
+    ctx->depth_skip_top = env_int("WS_DEPTH_SKIP_TOP", 1);  // 0: the depth sort always runs its four passes (A/B)
+    // the blend's workgroups: -1 (default) longest list first for a renderer that draws one frame at a time, image order for
+    // the slots of a view batch with frames in flight (ws_renderer_render); 0 / 1 force image order / longest first;
+    // 2 (shortest first) and 3 (alternating) are the measured experiments of DESIGN 3.3
+    ctx->blend_order = env_int("WS_BLEND_ORDER", -1);
+    ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
+    {
+        const char* bs = std::getenv("WS_BIN_SHIFT");  // 0 | 1 | auto (default): binning at twice the blend's tile size
+        ctx->bin_request = !bs ? BIN_AUTO : (std::strcmp(bs, "1") == 0 ? BIN_ALWAYS : (std::strcmp(bs, "0") == 0 ? BIN_NEVER : BIN_AUTO));
+    }
+    ctx->batch_threads = env_int("WS_BATCH_THREADS", -1);
     ctx->num_cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
     ctx->blend_lds_pad_kb = env_int("WS_BLEND_LDS_PAD_KB", 0);
     if (ctx->blend_lds_pad_kb < 0 || ctx->blend_lds_pad_kb > 96) ctx->blend_lds_pad_kb = 0;
@@ -801,8 +837,8 @@ int ws_renderer_create(ws_context* ctx, ws_color_format format, uint32_t sh_deg,
         return fail(WS_ERR_HIP, "ws_renderer_create: error word allocation failed");
     }
     // the demand mailbox (optional: without pinned memory the capacity still grows through ws_renderer_errors)
-    if (hipHostMalloc(reinterpret_cast<void**>(&r->demand_mailbox), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
-        *r->demand_mailbox = 0u;
+    if (hipHostMalloc(reinterpret_cast<void**>(&r->demand_mailbox), 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+        r->demand_mailbox[0] = r->demand_mailbox[1] = 0u;
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&r->demand_mailbox_dev), r->demand_mailbox, 0) != hipSuccess) {
             (void)hipHostFree(r->demand_mailbox);
             r->demand_mailbox = r->demand_mailbox_dev = nullptr;
@@ -861,6 +897,17 @@ int ws_renderer_enable_capture(ws_renderer* r, int enable) {
     if (r->capture != (enable != 0)) r->prepared = false;
     r->capture = enable != 0;
     return WS_OK;
+}
+
+int ws_renderer_download_blend_order(ws_renderer* r, uint32_t capacity_blocks, uint32_t* order4, uint32_t* num_blocks) {
+    if (!r || !num_blocks) return fail(WS_ERR_INVALID, "ws_renderer_download_blend_order: null argument");
+    if (!r->prepared) return fail(WS_ERR_STATE, "ws_renderer_download_blend_order: no prepared frame");
+    const uint32_t nb = r->blend_order_valid ? blend_order_blocks(r->tiles_x, r->tiles_y) : 0u;
+    *num_blocks = nb;
+    if (!order4 || nb == 0) return WS_OK;
+    if (capacity_blocks < nb) return fail(WS_ERR_INVALID, "ws_renderer_download_blend_order: capacity smaller than the block count");
+    WS_HIP(hipStreamSynchronize(r->last_stream));
+    return copy_d2h(order4, r->blend_order, (size_t)nb * sizeof(uint4), r->last_stream);
 }
 
 int ws_renderer_enable_blend_timing(ws_renderer* r, int enable) {
@@ -932,15 +979,24 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
         r->sorted_idx = r->vals_a;
         r->sorted_keys = r->keys_a;
         r->fp_sorted = r->fpw_a;
+        r->sorted_idx_skipped = r->sorted_keys_skipped = nullptr;
     } else {
-        uint32_t *sk = nullptr, *sv = nullptr;
-        if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, 32,
+        // Four 8-bit passes over the 32-bit keys (gpu_rs.rs:865-884), of which the last one leaves at once on frames whose keys
+        // span less than 2^24 (decided on the device from the range K1 / K1c stored: ws_internal.h depth_range_decide;
+        // WS_DEPTH_SKIP_TOP=0 switches it off).  (K1c's keys are NOT confined to 24 bits: preprocess_compressed.wgsl:325 scales
+        // clip z, which is below znear for the nearest splats.)
+        uint32_t *sk = nullptr, *sv = nullptr, *sk2 = nullptr, *sv2 = nullptr;
+        const int key_bits = 32;
+        FrameCounters* skip_top = r->ctx->depth_skip_top ? r->counters : nullptr;
+        if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, key_bits,
                                     true, false, stream, &sk, &sv, km, "depth:", nullptr, 0, RADIX_BITS, false, r->fpw_a,
-                                    r->fpw_b)))
+                                    r->fpw_b, skip_top, &sk2, &sv2)))
             return rc;
         r->sorted_idx = sv;
         r->sorted_keys = sk;
         r->fp_sorted = (sv == r->vals_a) ? r->fpw_a : r->fpw_b;  // where the payload went
+        r->sorted_idx_skipped = skip_top ? sv2 : nullptr;
+        r->sorted_keys_skipped = skip_top ? sk2 : nullptr;
     }
     if (r->timers) WS_HIP(hipEventRecord(r->ev[2], stream));
     if (cut == 2) {  // analysis only (WS_DEBUG_CUT): the image is NOT produced
@@ -954,6 +1010,8 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     BinBuffers bb;
     bb.sorted_idx = r->sorted_idx;
     bb.fp_sorted = r->fp_sorted;
+    bb.sorted_idx_alt = r->sorted_idx_skipped;
+    bb.fp_sorted_alt = r->sorted_idx_skipped ? ((r->sorted_idx_skipped == r->vals_a) ? r->fpw_a : r->fpw_b) : nullptr;
     bb.footprint_mode = r->footprint_mode;
     bb.splats = r->splats;
     bb.vw = kp.cam.viewport[0];
@@ -1024,9 +1082,16 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     r->entries_sorted = evv;  // the last pass wrote the per-tile ranges instead of the sorted tile ids
     // the compositing workgroups in longest-list-first order (one tile per workgroup at the 32x32 tile: every frame up to
     // 1080p-class tile counts; 4K-class frames composite several tiles per workgroup and keep the image order)
+    // Longest first is what a frame drawn ALONE wants (blend -12 % hd1m, -18 % c3 / c2: no tail of idle slots).  With several
+    // frames in flight it is the wrong order, measured (profiles/r05/blend_order_ab.txt: hd1m -9 %, c3 -17 % frames/s): the first
+    // 512 workgroups are then the longest tiles, no slot retires for 40 (hd1m) to 120 us (c3), and the other frames' small
+    // dependent kernels, which live on the slots the blend's short tiles keep freeing, starve behind it.
     r->blend_order_valid = false;
-    if (r->ctx->blend_order && r->ctx->tile_qw == 4 && r->ctx->tile_qh == 4 && ntiles <= 16384u && r->ctx->blend_tpw_log2 <= 0) {
-        if ((rc = launch_blend_order(r->tile_ranges, r->counters, r->tiles_x, r->tiles_y, r->blend_order, stream))) return rc;
+    const int order_mode = r->ctx->blend_order < 0 ? (r->throughput_mode ? 0 : 1) : r->ctx->blend_order;
+    // (up to 4096 tiles = eight rounds of workgroups on this chip: beyond that the tail is a small share of the kernel and the
+    // one-workgroup ordering kernel, 3 us at 2040 tiles and 7.6 us at 8160, costs what it saves -- c5, 4K: measured)
+    if (order_mode && r->ctx->tile_qw == 4 && r->ctx->tile_qh == 4 && ntiles <= 4096u && r->ctx->blend_tpw_log2 <= 0) {
+        if ((rc = launch_blend_order(r->tile_ranges, r->counters, r->tiles_x, r->tiles_y, r->blend_order, order_mode, stream))) return rc;
         km_mark(km, "k_blend_order");
         r->blend_order_valid = true;
     }
@@ -1182,6 +1247,8 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         g.sorted_keys = r->sorted_keys;
         g.fp_sorted = r->fp_sorted;
         g.entries_sorted = r->entries_sorted;
+        g.sorted_idx_skipped = r->sorted_idx_skipped;
+        g.sorted_keys_skipped = r->sorted_keys_skipped;
         g.valid = true;
     }
     const int slot = (int)(g.next++ % ws_renderer::GRAPH_RING);
@@ -1198,6 +1265,8 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     r->sorted_keys = g.sorted_keys;
     r->fp_sorted = g.fp_sorted;
     r->entries_sorted = g.entries_sorted;
+    r->sorted_idx_skipped = g.sorted_idx_skipped;
+    r->sorted_keys_skipped = g.sorted_keys_skipped;
     r->prepared = true;
     r->prepared_pc = pc;
     r->last_stream = stream;
@@ -1205,6 +1274,16 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
 }
 
 }  // extern "C"
+
+uint32_t ws_internal_renderer_frames_enqueued(const ws_renderer* r) { return r ? r->frames_enqueued : 0u; }
+bool ws_internal_renderer_progress(const ws_renderer* r, uint32_t* started_seq) {
+    if (!r || !r->demand_mailbox) return false;
+    *started_seq = *reinterpret_cast<volatile const uint32_t*>(r->demand_mailbox + 1);
+    return true;
+}
+void ws_internal_renderer_set_throughput_mode(ws_renderer* r, bool on) {
+    if (r) r->throughput_mode = on;
+}
 
 uint32_t ws_internal_renderer_demand(const ws_renderer* r) {
     if (!r) return 0u;
@@ -1311,6 +1390,8 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.counters = r->counters;
     bp.sticky = r->sticky;
     bp.demand_mailbox = r->demand_mailbox_dev;
+    bp.progress_mailbox = r->demand_mailbox_dev ? r->demand_mailbox_dev + 1 : nullptr;
+    bp.frame_seq = r->frames_enqueued + 1u;  // (counted below, once the launch is certain)
     bp.order = (r->blend_order_valid && bp.qw == 4 && bp.qh == 4 && bp.range_row_shift == 0 && !r->capture) ? r->blend_order : nullptr;
     bp.debug_consumed = r->capture ? r->debug_consumed : nullptr;
     bp.debug_walked = r->capture ? r->debug_walked : nullptr;
@@ -1337,6 +1418,7 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     if (r->ctx->debug_cut >= 1 && r->ctx->debug_cut <= 4) return WS_OK;  // analysis only
     int rc = launch_blend(bp, r->blend_mode == WS_BLEND_TARGET_PRECISION ? 2 : r->ctx->blend_variant, stream);
     if (rc) return rc;
+    r->frames_enqueued = bp.frame_seq;
     km_mark(km, r->blend_mode == WS_BLEND_TARGET_PRECISION ? "k_blend_strict" : "k_blend");
     if (r->timers) {
         WS_HIP(hipEventRecord(r->ev[5], stream));
@@ -1379,6 +1461,19 @@ int ws_renderer_binning_tile(ws_renderer* r, uint32_t* width, uint32_t* height) 
     { int rc_ = frame_lists(r, &s, &lx, &ly); if (rc_) return rc_; }
     *width = (QUAD * r->ctx->tile_qw) << s;
     *height = (QUAD * r->ctx->tile_qh) << s;
+    return WS_OK;
+}
+
+int ws_renderer_depth_sort_passes(ws_renderer* r, uint32_t* passes) {
+    if (!r || !passes) return fail(WS_ERR_INVALID, "ws_renderer_depth_sort_passes: null argument");
+    if (!r->prepared) return fail(WS_ERR_STATE, "ws_renderer_depth_sort_passes: no prepared frame");
+    *passes = 4u;
+    if (r->sorted_idx_skipped) {
+        WS_HIP(hipStreamSynchronize(r->last_stream));
+        uint32_t skipped = 0;
+        { int rc_ = copy_d2h(&skipped, &r->counters->depth_skip_top, sizeof skipped, r->last_stream); if (rc_) return rc_; }
+        if (skipped) *passes = 3u;
+    }
     return WS_OK;
 }
 
@@ -1513,15 +1608,26 @@ int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, 
     if (src_index && !r->capture)
         return fail(WS_ERR_STATE, "ws_renderer_download_frame: src_index needs ws_renderer_enable_capture before prepare");
     if (v == 0) return WS_OK;
+    // where the frame's depth sort left its result: behind its last pass, or -- decided on the device -- behind pass 2
+    const uint32_t* sorted_idx = r->sorted_idx;
+    const uint32_t* sorted_keys = r->sorted_keys;
+    if (r->sorted_idx_skipped) {
+        uint32_t skipped = 0;
+        { int rc_ = copy_d2h(&skipped, &r->counters->depth_skip_top, sizeof skipped, r->last_stream); if (rc_) return rc_; }
+        if (skipped) {
+            sorted_idx = r->sorted_idx_skipped;
+            sorted_keys = r->sorted_keys_skipped;
+        }
+    }
     if (splats) { int rc_ = copy_d2h(splats, r->splats, (size_t)v * 20, r->last_stream); if (rc_) return rc_; }
     if (src_index) { int rc_ = copy_d2h(src_index, r->src_index, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
-    if (sorted) { int rc_ = copy_d2h(sorted, r->sorted_idx, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
+    if (sorted) { int rc_ = copy_d2h(sorted, sorted_idx, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
     if (keys) {
         // the sort permutes the keys in place; un-permute them with the sorted indices so that the caller
         // gets keys in STORE order (what preprocess wrote)
         std::vector<uint32_t> ks(v), idx(v);
-        { int rc_ = copy_d2h(ks.data(), r->sorted_keys, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
-        { int rc_ = copy_d2h(idx.data(), r->sorted_idx, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
+        { int rc_ = copy_d2h(ks.data(), sorted_keys, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
+        { int rc_ = copy_d2h(idx.data(), sorted_idx, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
         for (uint32_t i = 0; i < v; ++i)
             if (idx[i] < v) keys[idx[i]] = ks[i];
     }

@@ -76,11 +76,16 @@ struct FrameCounters {
     uint32_t bin_request;    // written by K1: BIN_NEVER / BIN_AUTO / BIN_ALWAYS (the frame's request for coarse binning)
     // --- second cache line: what the frame decided ---
     uint32_t bin_shift;      // written by k_bin_prefix: 0 = the frame binned at the blend's tile size, 1 = at twice that
-    uint32_t _pad[15];
+    uint32_t depth_skip_top; // written by the depth sort's first kernel: 1 = the frame's keys span less than 2^24 above
+                             // depth_key_base: the sort's fourth digit pass has nothing to do, the result is where pass 2 left it
+    uint32_t depth_key_base; // written with it: passes 1..3 take their digits from (key - depth_key_base) (depth_range_decide)
+    uint32_t _pad[13];
     // --- the frame's footprint totals, summed by K1: TILE_SUM_SLOTS x {sum at the blend's tile size, sum at twice that
     // size}, one 64-B line per slot.  Workgroup b adds its partial sums to slot b % 16 with two returnless atomics; all
     // K1 workgroups retire within a few microseconds of each other, and ~1000 atomics on ONE address drain one after
     // the other (~12 ns each: measured +13 us per frame), on 16 lines in 0.7 us.  k_bin_prefix adds the slots (bin_shift_decide).
+    // words [2], [3] of a slot: the range of the depth keys K1 stored -- max(~key) (= ~min; 0 = nothing reported) and
+    // max(key) -- two more returnless atomics per workgroup (depth_range_decide)
     uint32_t tile_sums[16 * 16];
 };
 constexpr int TILE_SUM_SLOTS = 16;
@@ -147,6 +152,29 @@ __host__ __device__ inline uint32_t rect_coarse(uint32_t r) {
 // 0 = bin at the blend's tile size, 1 = at twice that.  k_bin_prefix -- the first kernel that needs the answer -- derives it
 // in every workgroup and leaves it in counters->bin_shift for the kernels behind it and for the host (32 loads per
 // workgroup were measurable in the blend: -2 % frames/s on c2 / c5).
+// The depth keys are bits(zfar - z) of the visible splats (preprocess.wgsl:270-273), sorted as u32 by four 8-bit LSD passes
+// (gpu_rs.rs:865-884).  On a scene the camera sees from outside the keys of a frame span far less than 32 bits -- c3: depths
+// 4.0 .. 14.9, i.e. 0x40800000 .. 0x416EE000, a range of 2^23.9 -- and sorting (key - base) for any base <= min(key) gives the
+// same stable order.  K1 leaves max(~key) and max(key) of the keys it stores in the slots below; the depth sort's FIRST kernel
+// folds them: base = min(key) with its low byte cleared (so that the first pass's digit, key & 0xFF, is the digit of
+// key - base: that pass runs before anybody knows the base), and when max(key) - base < 2^24 the fourth pass is a pass over
+// a constant digit -- the identity: its three kernels leave at once, and the readers of the sorted arrays (k_bin_prefix,
+// k_bin_emit, the host's read-back) take them from where pass 2 left them.  Three launches and 24 of 112 B per key less on
+// such frames; order and stability are the reference's.  -> (base, skip) in the counters
+__host__ __device__ inline void depth_range_decide(FrameCounters* c) {
+    uint32_t not_min = 0u, mx = 0u;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) {
+        const uint32_t a = c->tile_sums[sl * 16 + 2], b = c->tile_sums[sl * 16 + 3];
+        not_min = a > not_min ? a : not_min;
+        mx = b > mx ? b : mx;
+    }
+    const bool known = not_min != 0u;          // (no key reported: nothing visible, or a K1 form that does not report)
+    const uint32_t base = known ? (~not_min & 0xFFFFFF00u) : 0u;
+    c->depth_key_base = base;
+    c->depth_skip_top = (known && mx >= base && (mx - base) < (1u << 24)) ? 1u : 0u;
+}
+
 __host__ __device__ inline uint32_t bin_shift_decide(const FrameCounters* c) {
     const uint32_t req = c->bin_request;
     if (req == BIN_ALWAYS) return 1u;
@@ -244,7 +272,11 @@ struct SortScratch {
 int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, const uint32_t* d_count, uint32_t n,
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, hipStream_t stream,
                       uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km = nullptr, const char* tag = "", uint2* ranges = nullptr, uint32_t nranges = 0,
-                      int digit_bits = RADIX_BITS, bool key16 = false, uint32_t* aux = nullptr, uint32_t* aux_alt = nullptr);
+                      int digit_bits = RADIX_BITS, bool key16 = false, uint32_t* aux = nullptr, uint32_t* aux_alt = nullptr,
+                      FrameCounters* skip_top = nullptr, uint32_t** out_keys_skipped = nullptr, uint32_t** out_vals_skipped = nullptr);
+//   skip_top (four 8-bit passes from bit 0 only: the depth sort of a frame): the first kernel folds K1's key-bit words into
+//     skip_top->depth_skip_top (depth_top_decide); when it is set the three kernels of the LAST pass return at once and the
+//     result is what pass 2 wrote: *out_keys_skipped / *out_vals_skipped (the companion values next to the payload).
 //   aux / aux_alt: a 4-byte companion value per pair travels with the payload; the result lands where
 //     the payload lands (aux for an even pass count, aux_alt for an odd one).
 
@@ -320,6 +352,8 @@ constexpr int EMIT_TILE = SORT_TILE;  // tile entries produced per workgroup of 
 struct BinBuffers {
     const uint32_t* sorted_idx;  // [V] store indices in draw order (far -> near)
     const uint32_t* fp_sorted;   // [N] footprint words by draw position (carried through the depth sort)
+    const uint32_t* sorted_idx_alt;  // where both are when the depth sort's last pass was skipped (FrameCounters::depth_skip_top);
+    const uint32_t* fp_sorted_alt;   //   nullptr: the sort cannot skip (compressed scenes sort 24 bits in three passes anyway)
     int footprint_mode;          // FootprintMode of those words
     const uint8_t* splats;       // [V] x 20 B Splat records (modes other than FP_RECT_PACKED: k_bin_emit re-derives the footprint from words 0..2)
     float vw, vh;                // viewport in pixels, as the camera uniform holds it
@@ -364,6 +398,8 @@ struct BlendParams {
     const FrameCounters* counters;  // this frame's counters: the error bits are folded into *sticky by the blend
     uint32_t* sticky;           // per-renderer error word that is NOT zeroed per frame (ws_renderer_errors)
     uint32_t* demand_mailbox;   // nullptr, or a host-visible (pinned, mapped) word: the entry demand of overflowed frames
+    uint32_t* progress_mailbox; // nullptr, or a host-visible word: the blend's first workgroup posts frame_seq here when it starts
+    uint32_t frame_seq;         //   (the frame's kernels in front of the blend are done: what a view batch bounds the host's run-ahead by)
     const uint4* order;         // nullptr, or [blockIdx] -> (tx | ty << 16, begin, end, -) longest list first (k_blend_order;
                                 //   4x4 tiles, one tile per workgroup, not split)
     uint32_t* debug_consumed;   // nullptr, or [tiles]: entries of each tile's list the blend walked (capture mode)
@@ -375,7 +411,7 @@ int launch_blend(const BlendParams& p, int variant, hipStream_t stream);
 // the blend's workgroups in longest-list-first order (raster.hip k_blend_order): order[blend_order_blocks(..)]
 uint32_t blend_order_blocks(uint32_t tiles_x, uint32_t tiles_y);
 int launch_blend_order(const uint2* tile_ranges, const FrameCounters* counters, uint32_t tiles_x, uint32_t tiles_y, uint4* order,
-                       hipStream_t stream);
+                       int mode, hipStream_t stream);
 int launch_empty(hipStream_t stream);
 int debug_stage_splat(const uint32_t w[5], float W, float H, float tile_x0, float tile_y0, uint32_t qw, uint32_t qh,
                       float rec[10], uint32_t* mask);
@@ -406,6 +442,13 @@ int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_point
 // the largest tile-entry demand an overflowed frame of this renderer has left so far (0 = none), as last seen by
 // ws_renderer_errors or a prepare() (ws_api.cpp)
 uint32_t ws_internal_renderer_demand(const ws_renderer* r);
+// Frames this renderer has enqueued (render() calls) and the number of the last one whose compositing kernel has STARTED on
+// the device (posted by that kernel to pinned host memory: reading it costs a load, no runtime call).  A view batch keeps a
+// slot's host side at most queue_depth frames ahead of it.  renderer_progress returns false when the renderer has no mailbox.
+uint32_t ws_internal_renderer_frames_enqueued(const ws_renderer* r);
+bool ws_internal_renderer_progress(const ws_renderer* r, uint32_t* started_seq);
+// a renderer that runs beside others (a slot of a view batch with several frames in flight): see ws_api.cpp `throughput_mode`
+void ws_internal_renderer_set_throughput_mode(ws_renderer* r, bool on);
 
 // opaque handle definitions -------------------------------------------------------------------------
 // The depth sort of a frame (V keys + store index + footprint word):
@@ -434,7 +477,8 @@ struct ws_context {
     int blend_dma = 0;        // WS_BLEND_DMA: the blend stages Splat records with LDS-DMA (global_load_lds_dwordx4 / _dword)
     int blend_split = -1;     // WS_BLEND_SPLIT: 4x4 binning tiles composited by two 4x2 workgroups each; -1 = when tiles < 2 x CUs
     int num_cus = 256;
-    int blend_order = 1;      // WS_BLEND_ORDER=0: the blend's workgroups in image order instead of longest list first (A/B)
+    int depth_skip_top = 1;   // WS_DEPTH_SKIP_TOP=0: the depth sort's last pass always runs (A/B)
+    int blend_order = -1;     // WS_BLEND_ORDER: -1 automatic (longest list first unless the renderer is a slot of a batch with frames in flight), 0 image order, 1 longest first
     int use_graph = 0;        // WS_GRAPH=1: prepare() on a real stream replays a captured frame graph instead of enqueueing 22
                               //   launches (opt-in: on ROCm 7.2 legacy-NULL-stream work between two launches of a used
                               //   executable graph makes the next launch fault)

@@ -153,6 +153,8 @@ SIGNATURES = {
     "ws_context_destroy": (None, [_P]),
     "ws_context_tile_size": (C.c_int, [_P, _u32p, _u32p]),
     "ws_renderer_download_wave_stats": (C.c_int, [_P, C.c_uint32, _u32p]),
+    "ws_renderer_download_blend_order": (C.c_int, [_P, C.c_uint32, _P, _P]),
+    "ws_renderer_depth_sort_passes": (C.c_int, [_P, _P]),
     "ws_renderer_enable_blend_timing": (C.c_int, [_P, C.c_int]),
     "ws_renderer_download_blend_timing": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "ws_debug_stage_splat": (C.c_int, [_u32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,

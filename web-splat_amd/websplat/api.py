@@ -609,6 +609,22 @@ class GaussianRenderer:
         check(lib.ws_renderer_download_wave_stats(self.handle, nt.value, out.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out
 
+    def depth_sort_passes(self) -> int:
+        """digit passes the last prepared frame's depth sort executed (websplat.h)."""
+        v = C.c_uint32()
+        check(lib.ws_renderer_depth_sort_passes(self.handle, C.byref(v)))
+        return v.value
+
+    def blend_order(self):
+        """[blocks, 4] uint32 (tx | ty << 16, begin, end, 0): the compositing workgroups' tiles, longest list first; empty when
+        the last prepared frame was not ordered (websplat.h)."""
+        nb = C.c_uint32()
+        check(lib.ws_renderer_download_blend_order(self.handle, 0, None, C.byref(nb)))
+        out = np.zeros((nb.value, 4), dtype=np.uint32)
+        if nb.value:
+            check(lib.ws_renderer_download_blend_order(self.handle, nb.value, out.ctypes.data_as(C.c_void_p), C.byref(nb)))
+        return out
+
     def enable_blend_timing(self, on=True):
         check(lib.ws_renderer_enable_blend_timing(self.handle, 1 if on else 0))
 

@@ -75,6 +75,57 @@ def scene_c3(n=5_000_000, seed=2, sh_deg=3):
     return _rows(xyz, f_dc, f_rest, opacity, log_scale, rot)
 
 
+def scene_realistic(n=1_000_000, seed=5, sh_deg=3):
+    """'realistic1m': the SIZE DISTRIBUTION of a trained indoor scene (round-4 verdict item 8), which the uniform clouds above do
+    not have -- every rate and tolerance of rounds 1-4 came from splats that span 1-6 tiles.  A trained 3DGS scene
+    (io/ply.rs:50-100 reads what the INRIA trainer writes) is mostly small surface splats plus
+      * a heavy tail of BACKGROUND-sized splats (walls, ceiling, sky dome): here 1.5 % with 8-40x the median scale, so that at
+        1920x1080 more than 1 % of the visible splats cover >= 32 tiles of 32x32 px,
+      * NEEDLES and DISCS: 15 % with an anisotropy of 10-50 : 1 (long axis sqrt(a) x the base size, the two others 1 / sqrt(a)),
+        15 % with one axis squashed 10-50x,
+      * a bimodal opacity: 45 % nearly opaque (sigmoid ~ 0.95-0.999), 35 % in between, 20 % at the pruning threshold of the
+        trainer (alpha ~ 1/255 ... 0.02: splats that contribute almost nothing but are listed, sorted and walked all the same).
+    Geometry: an object cluster on a table, a floor, two walls (surface splats lie IN their surface: discs), and floaters."""
+    rng = np.random.default_rng(seed)
+    n_obj, n_floor, n_wall = int(n * 0.45), int(n * 0.2), int(n * 0.2)
+    n_float = n - n_obj - n_floor - n_wall
+    obj = rng.standard_normal(size=(n_obj, 3)) * np.array([0.45, 0.3, 0.45]) + np.array([0.0, 0.1, 0.0])
+    floor = np.stack([rng.uniform(-5, 5, n_floor), np.full(n_floor, 0.9) + 0.01 * rng.standard_normal(n_floor),
+                      rng.uniform(-5, 5, n_floor)], axis=1)           # (camera y points down: the floor is at +y)
+    w1 = np.stack([np.full(n_wall // 2, -5.0) + 0.01 * rng.standard_normal(n_wall // 2), rng.uniform(-3, 0.9, n_wall // 2),
+                   rng.uniform(-5, 5, n_wall // 2)], axis=1)
+    nw2 = n_wall - n_wall // 2
+    w2 = np.stack([rng.uniform(-5, 5, nw2), rng.uniform(-3, 0.9, nw2), np.full(nw2, 5.0) + 0.01 * rng.standard_normal(nw2)], axis=1)
+    floaters = rng.uniform(-4.5, 4.5, size=(n_float, 3)) * np.array([1.0, 0.6, 1.0])
+    xyz = np.concatenate([obj, floor, w1, w2, floaters])
+    kind = np.concatenate([np.zeros(n_obj, int), np.ones(n_floor, int), np.full(n_wall // 2, 2), np.full(nw2, 3), np.full(n_float, 4)])
+    perm = rng.permutation(n)                                          # file order is not spatial order
+    xyz, kind = xyz[perm].astype(np.float32), kind[perm]
+    base = np.log(0.010) + 0.65 * rng.standard_normal(size=(n, 1))     # isotropic part, log-normal
+    log_scale = base + 0.25 * rng.standard_normal(size=(n, 3))
+    u = rng.uniform(size=n)
+    axis = rng.integers(0, 3, size=n)
+    stretch = np.exp(rng.uniform(np.log(10.0), np.log(50.0), size=n))
+    needle, disc = u < 0.15, (u >= 0.15) & (u < 0.30)
+    # a needle of anisotropy a: its long axis sqrt(a) x the base, the two others 1 / sqrt(a) (thin AND long, as trained edges are)
+    log_scale[needle] -= 0.5 * np.log(stretch[needle])[:, None]
+    log_scale[needle, axis[needle]] += np.log(stretch[needle])
+    log_scale[disc, axis[disc]] -= np.log(stretch[disc])
+    big = rng.uniform(size=n) < 0.015                                  # the background tail
+    log_scale[big] += np.log(rng.uniform(8.0, 40.0, size=(int(big.sum()), 1)))
+    # surface splats are flat in their surface's normal (floor: y; walls: x, z), axis-aligned rotation for those
+    rot = rng.standard_normal(size=(n, 4))
+    for k, ax in ((1, 1), (2, 0), (3, 2)):
+        m = kind == k
+        rot[m] = np.array([1.0, 0.0, 0.0, 0.0]) + 0.05 * rng.standard_normal(size=(int(m.sum()), 4))
+        log_scale[m, ax] = np.minimum(log_scale[m, ax], np.log(0.002))
+    v = rng.uniform(size=n)
+    opacity = np.where(v < 0.45, rng.normal(4.5, 1.0, size=n),
+                       np.where(v < 0.80, rng.normal(0.5, 1.5, size=n), rng.uniform(-5.6, -3.9, size=n)))
+    f_dc, f_rest = _sh(rng, n, sh_deg)
+    return _rows(xyz, f_dc, f_rest, opacity.astype(np.float32), log_scale.astype(np.float32), rot.astype(np.float32))
+
+
 @dataclass
 class SceneCamera:
     """scene.rs:13-24; rotation = 3 rows of the camera-to-world rotation (3DGS cameras.json)."""
