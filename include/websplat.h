@@ -453,7 +453,12 @@ int ws_measure(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* scene, 
  * The reference renders one view at a time on one queue (lib.rs:422-431, bin/measure.rs:98-146).  A view batch keeps
  * `frames_in_flight` frames going at once: frame i of the batch's life runs on renderer + HIP stream i mod
  * frames_in_flight (private scratch each; the point cloud is shared).  ws_view_batch_render only ENQUEUES; the caller
- * observes completion with ws_view_batch_sync.  For point clouds of at most 512 Ki Gaussians -- where the GPU needs less time
+ * observes completion with ws_view_batch_sync.  The host's RUN-AHEAD is bounded: a slot's host side stays at most 5 frames
+ * (WS_BATCH_QUEUE_DEPTH; 0 = unbounded) ahead of the device, so a call with more views than slots x 5 returns when all but
+ * the last of them have reached the device -- the caller's thread SLEEPS meanwhile (it polls a word the compositing kernel
+ * posts to pinned memory; no runtime call, no spinning: a rank costs 0.5-0.7 host cores instead of 1.9).  On an error in the
+ * middle of a call the one-thread path stops at the failing frame; with submission threads (below) the other slots still
+ * enqueue THEIR frames of the call, and the frame-to-slot position advances by num_views.  For point clouds of at most 512 Ki Gaussians -- where the GPU needs less time
  * per frame than one host thread needs to enqueue it -- every slot's frames are enqueued by a worker thread of the batch (the
  * order on each stream is unchanged; the call returns when everything is enqueued; WS_BATCH_THREADS=0 / 1 forces it off / on).
  * d_targets[i] receives view i (device memory, format of the batch);

@@ -29,16 +29,14 @@ def label_of(name):
         return "k_bin_prefix"
     if "k_bin_emit" in name:
         return "k_bin_emit"
+    if "k_blend_order" in name:
+        return "k_blend_order"
     if "k_blend" in name:
         return "k_blend"
-    if "k_dsort_hist" in name:
-        return "depth:k_dsort_hist"
-    if "k_dsort_scatter" in name:
-        return "depth:k_dsort_scatter"
-    m = re.search(r"k_sort_scatter<(false|true), (\d+), (false|true), (\d+), (false|true)(?:, (false|true))?>", name)
-    if m:  # <LOOKBACK, KPT, RANGES, BITS, CARRY, KEY16>: the depth sort carries the footprint words (CARRY) with 32-bit keys;
+    m = re.search(r"k_sort_scatter<(\d+), (false|true), (\d+), (false|true), (false|true)>", name)
+    if m:  # <KPT, RANGES, BITS, CARRY, KEY16>: the depth sort carries the footprint words (CARRY) with 32-bit keys;
         # the tile-id sort has 16-bit keys and its last pass records the tile ranges
-        carry, key16, ranges = m.group(5) == "true", m.group(6) == "true", m.group(3) == "true"
+        carry, key16, ranges = m.group(4) == "true", m.group(5) == "true", m.group(2) == "true"
         which = "tiles" if (key16 or ranges) and not carry else "depth"
         return f"{which}:k_sort_scatter"
     if "k_sort_col_scan" in name:

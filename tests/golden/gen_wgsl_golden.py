@@ -185,23 +185,22 @@ def k6_fragments(source="k1_default"):
                     if 0 <= x < w and 0 <= y < h]
             pixels = sorted(set(pixels) | set(near), key=lambda q: (q[1], q[0]))
         for (x, y) in pixels:
-            if True:
-                ndc = np.array([(x + 0.5) / w * 2.0 - 1.0, 1.0 - (y + 0.5) / h * 2.0])
-                st = Ainv @ (ndc - P[0])
-                sp = Q[0] + dQ @ st
-                spv = W.Vec([W.F32(sp[0]), W.F32(sp[1])])
-                frag = W.StructVal("VertexOutput", dict(position=W.Vec([W.F32(x + 0.5), W.F32(y + 0.5), W.F32(0), W.F32(1)]),
-                                                        screen_pos=spv, color=color))
-                try:
-                    o = m.invoke("fs_main", [frag])
-                    rec_out.append([float(c) for c in o.c])
-                    rec_keep.append(1)
-                except W.Discard:
-                    rec_out.append([0.0] * 4)
-                    rec_keep.append(0)
-                rec_splat.append(int(s))
-                rec_px.append((x, y))
-                rec_pos.append((float(spv.c[0]), float(spv.c[1])))
+            ndc = np.array([(x + 0.5) / w * 2.0 - 1.0, 1.0 - (y + 0.5) / h * 2.0])
+            st = Ainv @ (ndc - P[0])
+            sp = Q[0] + dQ @ st
+            spv = W.Vec([W.F32(sp[0]), W.F32(sp[1])])
+            frag = W.StructVal("VertexOutput", dict(position=W.Vec([W.F32(x + 0.5), W.F32(y + 0.5), W.F32(0), W.F32(1)]),
+                                                    screen_pos=spv, color=color))
+            try:
+                o = m.invoke("fs_main", [frag])
+                rec_out.append([float(c) for c in o.c])
+                rec_keep.append(1)
+            except W.Discard:
+                rec_out.append([0.0] * 4)
+                rec_keep.append(0)
+            rec_splat.append(int(s))
+            rec_px.append((x, y))
+            rec_pos.append((float(spv.c[0]), float(spv.c[1])))
     return dict(viewport=np.array([w, h], dtype=np.uint32), splats=splats, picked=pick.astype(np.uint32),
                 vertices=np.array(verts, dtype=np.float32), frag_splat=np.array(rec_splat, dtype=np.uint32),
                 frag_pixel=np.array(rec_px, dtype=np.uint32), frag_screen_pos=np.array(rec_pos, dtype=np.float32),

@@ -857,19 +857,23 @@ def test_depth_sort_skips_its_last_pass_on_a_narrow_key_range(ws, oracle, monkey
     sorted as (key - base) the fourth 8-bit pass of the LSD sort is then the identity, and the frame's depth sort executes three
     passes (decided on the device from the key range K1 stored; the readers of the sorted arrays follow).  Draw order, tile
     lists and image must be exactly those of the same frame with the pass forced (WS_DEPTH_SKIP_TOP=0) -- and of the oracle's
-    stable sort; a camera INSIDE the scene (keys down to nearly zero: a range of 2^29 and more) keeps its four passes."""
+    stable sort; the same slab with a trail of splats far behind it (keys over a factor of > 4: more than 2^24 apart) keeps
+    its four passes."""
     vp = (800, 600)
     rows = synth.scene_c1(n=120_000, seed=71)
     rows[:, 2] *= 0.5        # a slab: seen from outside its keys span a factor of ~2.5 (a factor of 4 is 2^24 in f32 bits)
     outside = synth.look_at_camera(0, [0.2, -0.3, -9.0], [0, 0, 0], vp[0], vp[1], 2100.0, 2100.0)
-    inside = synth.look_at_camera(0, [0.05, 0.02, -0.1], [0.3, 0.1, 1.0], vp[0], vp[1], 500.0, 500.0)
+    trail = synth.scene_c1(n=4000, seed=72)
+    trail[:, 0:2] *= 0.3
+    trail[:, 2] = np.random.default_rng(73).uniform(2.0, 60.0, size=4000).astype(np.float32)   # far behind the slab, along the view axis
+    rows_wide = np.concatenate([rows, trail])
     got = {}
     for skip in ("1", "0"):
         monkeypatch.setenv("WS_DEPTH_SKIP_TOP", skip)
         c = ws.Context(0)
         try:
-            for name, cj in (("outside", outside), ("inside", inside)):
-                sc = scenes.Scene(ws, oracle, rows, 3, cj, vp)
+            for name, cj, rr in (("outside", outside, rows), ("inside", outside, rows_wide)):
+                sc = scenes.Scene(ws, oracle, rr, 3, cj, vp)
                 pc = ws.PointCloud(c, sc.gpc)
                 r = ws.GaussianRenderer(c, "rgba32float", 3, False)
                 try:

@@ -261,12 +261,13 @@ constexpr uint32_t BATCH_THREADS_MAX_POINTS = 512u * 1024u;
 // frame where the GPU needs 140, so it runs ahead until the runtime's queues are full and then WAITS INSIDE THE HIP RUNTIME
 // for queue space -- spinning: the enqueue thread at 100 % of a core and a runtime helper thread beside it at 93 %
 // (profiles/r05/host_threads.txt; 1.9 cores per rank, 8 ranks on a 16-CPU quota).  Nothing is gained by being a thousand frames
-// ahead.  Every slot therefore keeps its host side at most `queue_depth` frames (default 3, WS_BATCH_QUEUE_DEPTH; 0 =
-// unbounded) ahead of the device: the compositing kernel of every frame posts the frame's number to pinned host memory when
+// ahead.  Every slot therefore keeps its host side at most `queue_depth` frames (default 5, WS_BATCH_QUEUE_DEPTH; 0 =
+// unbounded; measured 2 / 3 / 5: -2 / -1.6 ... -3 / 0 ... -1 % frames/s against unbounded, profiles/r05/host_run_ahead_ab.txt)
+// ahead of the device: the compositing kernel of every frame posts the frame's number to pinned host memory when
 // it STARTS (ws_internal_renderer_progress: one store by one thread, no event, no extra packet), and before a slot's next
 // frame is enqueued the host polls that word, sleeping 20 us between looks -- no runtime call, no spinning (a HIP event wait,
 // blocking flavour included, spins for ~200 us before it sleeps, i.e. always at these frame times: measured, 0.99 of a core).
-// With 4 slots x 3 frames the GPU always has > 1 ms of work queued; the image stream is unchanged.
+// With 4 slots x 5 frames the GPU always has > 2 ms of work queued; the image stream is unchanged.
 struct SlotWindow {
     uint32_t waits = 0;   // (statistics: times the host had to wait for this slot)
 };
@@ -275,7 +276,8 @@ struct ws_view_batch {
     std::vector<ws_renderer*> renderers;
     std::vector<hipStream_t> streams;
     std::vector<SlotWindow> windows;
-    uint32_t queue_depth = 3;
+    uint32_t queue_depth = 5;
+    bool threads_disabled = false;  // a host that could not start the submission threads: this batch enqueues from the caller's
     uint64_t next = 0;  // frames enqueued so far: frame i runs on slot i % frames_in_flight
 
     // one call's work, shared by the workers (valid while `pending` != 0)
@@ -416,7 +418,7 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
     if (group > 1 && slots % group != 0) group = 1;
     // every slot's frames enqueued by its own thread (see ws_view_batch): small scenes, enough frames to be worth a wake-up
     const int want_threads = b->ctx->batch_threads;
-    if (group == 1 && slots >= 2 && num_views >= 2 * slots && want_threads != 0 &&
+    if (group == 1 && slots >= 2 && num_views >= 2 * slots && want_threads != 0 && !b->threads_disabled &&
         (want_threads > 0 || pc->num_points <= BATCH_THREADS_MAX_POINTS)) {
         bool have_workers = !b->workers.empty();
         if (!have_workers) {
@@ -435,7 +437,7 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
                     if (w.th.joinable()) w.th.join();
                 b->workers.clear();
                 b->quit = false;
-                b->ctx->batch_threads = 0;
+                b->threads_disabled = true;  // (this batch keeps the one-thread path; the context is shared state: untouched)
             }
         }
         if (have_workers) {

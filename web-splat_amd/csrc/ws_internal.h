@@ -241,7 +241,7 @@ constexpr int SORT_KPT_SMALL = 4;                     // small inputs: 1024-key 
 #define WS_SORT_SMALL_MAX (2u << 20)
 #endif
 constexpr uint32_t SORT_SMALL_MAX = WS_SORT_SMALL_MAX;  // host-side bound n up to which the small tile is used
-uint32_t sort_tile_size(uint32_t n);                  // tile size the scan path (algo 0) uses for bound n
+uint32_t sort_tile_size(uint32_t n);                  // tile size the scan path (the production sort) uses for bound n
 
 // Single-pass tile-id sort (launch_tile_sort_wide): the whole tile id is ONE digit of up to 11 bits.
 constexpr int TILE_SORT_WIDE_MAX_BITS = 11;
