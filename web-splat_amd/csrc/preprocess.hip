@@ -538,7 +538,6 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
     __shared__ uint32_t s_cnt[K1_ITEMS][K1_THREADS / 64];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_t32[K1_THREADS / 64], s_t64[K1_THREADS / 64];
-    __shared__ uint32_t s_knmin[K1_THREADS / 64], s_kmax[K1_THREADS / 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -655,26 +654,6 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
             if (b.src_index) b.src_index[slot] = block_base + it * K1_THREADS + tid;
         }
     }
-    // ---- the range of the frame's depth keys (ws_internal.h depth_range_decide) --------------------------------------------
-    {   // (K1c too: its keys are u32(0xffffff * (1 - (clip z - znear) / (zfar - znear))), preprocess_compressed.wgsl:325 -- clip z,
-        // not view depth, so they reach past 24 bits for splats in front of clip z = znear; a frame's keys rarely span 2^24)
-        uint32_t knmin = 0u, kmax = 0u;
-#pragma unroll
-        for (int it = 0; it < K1_ITEMS; ++it)
-            if (vis[it]) {
-                knmin = max(knmin, ~so[it].key);
-                kmax = max(kmax, so[it].key);
-            }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            knmin = max(knmin, (uint32_t)__shfl_xor((int)knmin, o, 64));
-            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
-        }
-        if (lane == 0) {
-            s_knmin[wave] = knmin;
-            s_kmax[wave] = kmax;
-        }
-    }
     // ---- the frame's footprint totals at both binning granularities (ws_internal.h bin_shift_decide) -----------------
     if (FPMODE == FP_RECT_PACKED && p.bin_request == BIN_AUTO) {  // (uniform: only frames that let the device decide)
         uint32_t t32 = 0u, t64 = 0u;
@@ -692,22 +671,6 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
         if (lane == 0) {
             s_t32[wave] = t32;
             s_t64[wave] = t64;
-        }
-    }
-    {
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t knmin = 0u, kmax = 0u;
-#pragma unroll
-            for (int w = 0; w < K1_THREADS / 64; ++w) {
-                knmin = max(knmin, s_knmin[w]);
-                kmax = max(kmax, s_kmax[w]);
-            }
-            if (knmin) {  // (returnless; one pair per workgroup that stored a key)
-                uint32_t* ts = b.counters->tile_sums + (bid & (TILE_SUM_SLOTS - 1)) * TILE_SUM_STRIDE;
-                atomicMax(ts + 2, knmin);
-                atomicMax(ts + 3, kmax);
-            }
         }
     }
     if (FPMODE == FP_RECT_PACKED && p.bin_request == BIN_AUTO) {  // (here, behind the stores: the kernel's registers are free)

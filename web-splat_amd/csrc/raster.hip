@@ -180,7 +180,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
 constexpr int EMIT_COPIES = 2;
 
 template <bool PACKED, bool WIDE>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src_arg, uint32_t* __restrict__ entry_keys,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src, uint32_t* __restrict__ entry_keys,
                                                          uint32_t* __restrict__ entry_vals,
                                                          uint32_t* __restrict__ tile_hist, uint32_t tile_hist_pitch,
                                                          uint32_t tile_hist_mask, int key16) {
@@ -189,11 +189,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
     __shared__ uint32_t s_own[emit::OWN_WORDS];
     __shared__ uint32_t s_hist[HIST_WORDS];
     __shared__ uint32_t s_wmax[BIN_THREADS / 64];
-    emit::Source src = src_arg;
-    if (src.sorted_idx_alt && src.counters->depth_skip_top) {  // the depth sort's last pass had nothing to do (ws_internal.h)
-        src.sorted_idx = src.sorted_idx_alt;
-        src.fp_sorted = src.fp_sorted_alt;
-    }
+    // (the depth sort's last pass may have had nothing to do: the draw-ordered arrays are then where pass 2 left them.  Two
+    // wave-uniform pointers, selected once -- the kernel-argument block itself stays untouched in SGPRs)
+    const bool skipped = src.sorted_idx_alt && src.counters->depth_skip_top;
+    const uint32_t* __restrict__ sorted_idx = skipped ? src.sorted_idx_alt : src.sorted_idx;
+    const uint32_t* __restrict__ fp_sorted = skipped ? src.fp_sorted_alt : src.fp_sorted;
     const uint32_t d = src.counters->num_entries;
     const uint32_t v = src.counters->num_visible;
     const int tid = threadIdx.x;
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
 #pragma unroll
             for (int j = 0; j < emit::EPT; ++j) {
                 const uint32_t pos = sl.s_lo + lo[j];
-                if (PACKED) rect[j] = src.fp_sorted[pos];
-                val[j] = src.sorted_idx[pos];
+                if (PACKED) rect[j] = fp_sorted[pos];
+                val[j] = sorted_idx[pos];
             }
             if (!PACKED) {
 #pragma unroll

@@ -131,11 +131,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t*
                                                                 const uint32_t* __restrict__ key_base) {
     constexpr int TILE_N = SORT_THREADS * KPT;
     __shared__ uint32_t sh[RADIX * HIST_COPIES];
-    if (skip && *skip) return;  // the depth sort's last pass over a constant digit (ws_internal.h depth_range_decide)
-    // the depth sort's first kernel: the key range K1 left -> the base of passes 1..3 and ONE flag for the kernels of the
-    // last pass and the sort's readers (this pass's own digit, key & 0xFF, does not depend on the base)
-    if (fold && blockIdx.x == 0 && threadIdx.x == 0) depth_range_decide(fold);
-    const uint32_t kbase = key_base ? *key_base : 0u;
+    __shared__ uint32_t s_rng[2][WAVES];
+    // (base, skip and fold belong to the depth sort of a frame: 32-bit keys.  The 16-bit instantiations -- the tile-id sort --
+    // compile to exactly what they were without them.)
+    if (!KEY16 && skip && *skip) return;  // the depth sort's last pass over a constant digit (ws_internal.h depth_range_decide)
+    const uint32_t kbase = (!KEY16 && key_base) ? *key_base : 0u;
     const uint32_t count = device_count(d_count, n);
     const uint32_t copy = threadIdx.x & (HIST_COPIES - 1);
     // the grid is capped (sort_grid): the host only knows the bound n, and workgroups that find nothing to do
@@ -159,7 +159,43 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t*
             const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
             if (pos < count) atomicAdd(&sh[(((k[j] - kbase) >> shift) & mask) * HIST_COPIES + copy], 1u);
         }
+        if (!KEY16 && fold) {
+            // The depth sort's first kernel reads every key anyway: it also leaves their range -- max(~key) and max(key), two
+            // returnless atomics per tile into the 16 slotted lines of the frame counters -- for the column scan behind it to
+            // fold into the base of passes 1..3 and the skip flag of pass 3 (ws_internal.h depth_range_decide).
+            uint32_t knmin = 0u, kmax = 0u;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
+                if (pos < count) {
+                    knmin = max(knmin, ~k[j]);
+                    kmax = max(kmax, k[j]);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                knmin = max(knmin, (uint32_t)__shfl_xor((int)knmin, o, 64));
+                kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+            }
+            if ((threadIdx.x & 63) == 0) {
+                s_rng[0][threadIdx.x >> 6] = knmin;
+                s_rng[1][threadIdx.x >> 6] = kmax;
+            }
+        }
         __syncthreads();
+        if (!KEY16 && fold && threadIdx.x == 0) {
+            uint32_t knmin = 0u, kmax = 0u;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                knmin = max(knmin, s_rng[0][w]);
+                kmax = max(kmax, s_rng[1][w]);
+            }
+            if (knmin) {
+                uint32_t* ts = fold->tile_sums + (t & (TILE_SUM_SLOTS - 1)) * TILE_SUM_STRIDE;
+                atomicMax(ts + 2, knmin);
+                atomicMax(ts + 3, kmax);
+            }
+        }
         uint32_t c = 0;
 #pragma unroll
         for (int r = 0; r < HIST_COPIES; ++r) c += sh[threadIdx.x * HIST_COPIES + r];
@@ -175,9 +211,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t*
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* __restrict__ d_count, uint32_t n,
                                                                uint32_t tile_n, uint32_t* __restrict__ tile_sums,
                                                                uint32_t tiles_cap, uint32_t* __restrict__ hist,
-                                                               const uint32_t* __restrict__ skip) {
+                                                               const uint32_t* __restrict__ skip, FrameCounters* __restrict__ fold) {
     __shared__ uint32_t s_tmp[WAVES];
     if (skip && *skip) return;
+    // the depth sort's first column scan: the key range the histogram kernel in front of it left -> the base of passes 1..3 and
+    // ONE flag for the kernels of the last pass and the sort's readers
+    if (fold && blockIdx.x == 0 && threadIdx.x == 0) depth_range_decide(fold);
     const uint32_t count = device_count(d_count, n);
     const uint32_t ntiles = (count + tile_n - 1) / tile_n;
     uint32_t* row = tile_sums + (size_t)blockIdx.x * tiles_cap;
@@ -231,8 +270,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    if (skip && *skip) return;  // (block-uniform) a pass over a constant digit moves nothing
-    const uint32_t kbase = key_base ? *key_base : 0u;
+    // (base and skip belong to the depth sort of a frame, the CARRY instantiation: every other one compiles to what it was)
+    if (CARRY && skip && *skip) return;  // (block-uniform) a pass over a constant digit moves nothing
+    const uint32_t kbase = (CARRY && key_base) ? *key_base : 0u;
 
     const uint32_t count = device_count(d_count, n);
     // first output position of every digit: the same for all tiles of this pass
@@ -252,9 +292,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const uint32_t pos = wave_base + j * 64;
-        key[j] = pos < count ? (KEY16 ? (uint32_t)reinterpret_cast<const uint16_t*>(keys_in)[pos] : keys_in[pos]) - kbase
-                             : 0xFFFFFFFFu;   // (from here on the key is key - base; the base is added back at the store)
+        key[j] = pos < count ? (KEY16 ? (uint32_t)reinterpret_cast<const uint16_t*>(keys_in)[pos] : keys_in[pos])
+                             : 0xFFFFFFFFu;
     }
+    // The digit of a key is taken from key - base (the subtraction sits where the digit is computed, not behind the loads:
+    // there it made every load wait for its own data).  Padding keys (0xFFFFFFFF) keep the top digit.
+    auto digit_of = [&](uint32_t k) -> uint32_t { return ((k == 0xFFFFFFFFu ? k : k - kbase) >> shift) & DMASK; };
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const uint32_t pos = wave_base + j * 64;
@@ -289,7 +332,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-        const uint32_t d = (key[j] >> shift) & DMASK;
+        const uint32_t d = digit_of(key[j]);
         uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
 #pragma unroll
         for (int bit = 0; bit < BITS; ++bit) {
@@ -307,7 +350,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     uint32_t prev[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-        const uint32_t d = (key[j] >> shift) & DMASK;
+        const uint32_t d = digit_of(key[j]);
         prev[j] = 0u;
         if (info[j] >> 16) prev[j] = atomicAdd(&s_wave_hist[wave][d], info[j] >> 16);
     }
@@ -334,7 +377,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     // ---- reorder keys AND values through LDS (one barrier), write contiguous digit runs -------------------
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-        const uint32_t d = (key[j] >> shift) & DMASK;
+        const uint32_t d = digit_of(key[j]);
         const uint32_t lpos = s_local_excl[d] + s_wave_hist[wave][d] + rank[j];
         s_keys[lpos] = key[j];
         s_vals[lpos] = val[j];
@@ -346,14 +389,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         const uint32_t lp = k * SORT_THREADS + tid;
         const uint32_t kk = s_keys[lp];
         const uint32_t vv = s_vals[lp];
-        const uint32_t d = (kk >> shift) & DMASK;
+        const uint32_t d = digit_of(kk);
         const uint32_t gpos = s_global_base[d] + lp;
         if (lp < valid) {
             vals_out[gpos] = vv;
             if (CARRY) aux_out[gpos] = s_aux[lp];
             if (!RANGES) {
                 if (KEY16) reinterpret_cast<uint16_t*>(keys_out)[gpos] = (uint16_t)kk;
-                else keys_out[gpos] = kk + kbase;
+                else keys_out[gpos] = kk;
             } else if (kk < nranges) {
                 const uint32_t prev_k = lp > 0u ? s_keys[lp - 1u] : ~kk;
                 const uint32_t next_k = lp + 1u < valid ? s_keys[lp + 1u] : ~kk;
@@ -393,7 +436,7 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
             km_mark(km, names[0]);
         }
         hipLaunchKernelGGL(k_sort_col_scan, dim3(1u << BITS), dim3(SORT_THREADS), 0, stream, d_count, n, TILE_N,
-                           sc.tile_sums, sc.tiles_cap, sc.hist + p * RADIX, skip);
+                           sc.tile_sums, sc.tiles_cap, sc.hist + p * RADIX, skip, fold);
         km_mark(km, names[1]);
         if (ranges && p == npass - 1)
             hipLaunchKernelGGL((k_sort_scatter<KPT, true, BITS, false, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,

@@ -84,8 +84,8 @@ struct FrameCounters {
     // size}, one 64-B line per slot.  Workgroup b adds its partial sums to slot b % 16 with two returnless atomics; all
     // K1 workgroups retire within a few microseconds of each other, and ~1000 atomics on ONE address drain one after
     // the other (~12 ns each: measured +13 us per frame), on 16 lines in 0.7 us.  k_bin_prefix adds the slots (bin_shift_decide).
-    // words [2], [3] of a slot: the range of the depth keys K1 stored -- max(~key) (= ~min; 0 = nothing reported) and
-    // max(key) -- two more returnless atomics per workgroup (depth_range_decide)
+    // words [2], [3] of a slot: the range of the frame's depth keys -- max(~key) (= ~min; 0 = nothing reported) and max(key),
+    // left by the depth sort's first histogram kernel, two returnless atomics per sort tile (depth_range_decide)
     uint32_t tile_sums[16 * 16];
 };
 constexpr int TILE_SUM_SLOTS = 16;
@@ -155,9 +155,9 @@ __host__ __device__ inline uint32_t rect_coarse(uint32_t r) {
 // The depth keys are bits(zfar - z) of the visible splats (preprocess.wgsl:270-273), sorted as u32 by four 8-bit LSD passes
 // (gpu_rs.rs:865-884).  On a scene the camera sees from outside the keys of a frame span far less than 32 bits -- c3: depths
 // 4.0 .. 14.9, i.e. 0x40800000 .. 0x416EE000, a range of 2^23.9 -- and sorting (key - base) for any base <= min(key) gives the
-// same stable order.  K1 leaves max(~key) and max(key) of the keys it stores in the slots below; the depth sort's FIRST kernel
-// folds them: base = min(key) with its low byte cleared (so that the first pass's digit, key & 0xFF, is the digit of
-// key - base: that pass runs before anybody knows the base), and when max(key) - base < 2^24 the fourth pass is a pass over
+// same stable order.  The sort's FIRST kernel (the per-tile histogram of pass 0, which reads every key anyway) leaves max(~key) and
+// max(key) in the slots below; the column scan behind it folds them: base = min(key) with its low byte cleared (so that the
+// first pass's digit, key & 0xFF, is the digit of key - base: that pass runs before anybody knows the base), and when max(key) - base < 2^24 the fourth pass is a pass over
 // a constant digit -- the identity: its three kernels leave at once, and the readers of the sorted arrays (k_bin_prefix,
 // k_bin_emit, the host's read-back) take them from where pass 2 left them.  Three launches and 24 of 112 B per key less on
 // such frames; order and stability are the reference's.  -> (base, skip) in the counters
