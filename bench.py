@@ -311,7 +311,10 @@ def pin_host_share(local_rank, local_world):
     if local_world <= 1:
         os.environ.setdefault("OMP_NUM_THREADS", str(min(len(allowed), team_cap) if team_cap else len(allowed)))
         return allowed, f"one rank: all {len(allowed)} allowed CPUs" + (f", cgroup quota {quota:g} CPUs" if quota else "")
-    share, where = numa_share(local_rank, local_world, allowed)
+    try:
+        share, where = numa_share(local_rank, local_world, allowed)
+    except Exception as e:  # noqa: BLE001  (an unexpected sysfs layout must never keep a rank from starting)
+        share, where = None, f"placement lookup failed ({e!r}): not pinned"
     if not share:
         return allowed, where
     os.sched_setaffinity(0, share)
@@ -339,9 +342,12 @@ def thread_cpu_times():
             st = open(f"/proc/self/task/{t}/stat").read()
         except OSError:
             continue
-        comm = st[st.index("(") + 1:st.rindex(")")]
-        f = st[st.rindex(")") + 2:].split()
-        out[int(t)] = (comm, (int(f[11]) + int(f[12])) / tick)   # fields 14, 15 of proc(5): utime, stime
+        try:
+            comm = st[st.index("(") + 1:st.rindex(")")]
+            f = st[st.rindex(")") + 2:].split()
+            out[int(t)] = (comm, (int(f[11]) + int(f[12])) / tick)   # fields 14, 15 of proc(5): utime, stime
+        except (ValueError, IndexError):
+            continue
     return out
 
 

@@ -211,3 +211,31 @@ def test_thread_cpu_accounting():
     th.join()
     rows = bench.thread_busy(t0, t1, el)
     assert rows and 0.5 < rows[0]["cores"] < 1.3, rows
+
+
+def test_gpu_numa_nodes_from_a_kfd_topology(tmp_path):
+    """bench.gpu_numa_nodes: GPUs in HIP's enumeration order (the KFD topology nodes that have SIMDs), each one's NUMA node from
+    the PCI address its properties file encodes (`domain`, `location_id` = bus << 8 | device << 3 | function).  A fake sysfs tree
+    of an 8-GPU node: two CPU nodes, then GPUs 0-3 on node 0 and 4-7 on node 1; one GPU whose PCI entry is missing reports -1."""
+    sys.path.insert(0, ROOT)
+    import bench
+    topo, pci = tmp_path / "nodes", tmp_path / "pci"
+    for i in range(2):
+        (topo / str(i)).mkdir(parents=True)
+        (topo / str(i) / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for g in range(8):
+        bus, dev, fn = 0x05 + g * 0x20 & 0xFF, g % 3, 0
+        loc = (bus << 8) | (dev << 3) | fn
+        (topo / str(2 + g)).mkdir(parents=True)
+        (topo / str(2 + g) / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {loc}\ndomain 0\n")
+        if g != 6:
+            d = pci / f"0000:{bus:02x}:{dev:02x}.{fn}"
+            d.mkdir(parents=True)
+            (d / "numa_node").write_text(f"{0 if g < 4 else 1}\n")
+    (topo / "not_a_node").mkdir()
+    assert bench.gpu_numa_nodes(topology_root=str(topo), pci_root=str(pci)) == [0, 0, 0, 0, 1, 1, -1, 1]
+    # a rank whose own GPU's node is unknown falls back to equal slices of everything; so does every rank when any is unknown
+    allowed = list(range(32))
+    s, note = bench.numa_share(6, 8, allowed, gpu_nodes=[0, 0, 0, 0, 1, 1, -1, 1], cpus_of_node={0: set(range(16)), 1: set(range(16, 32))}.get,
+                               physical=lambda cp: [[c] for c in sorted(cp)])
+    assert s == [24, 25, 26, 27] and "unknown" in note
