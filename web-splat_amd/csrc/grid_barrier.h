@@ -16,6 +16,14 @@
 //
 // Every spin is bounded; a time-out sets `error_bit` in *error_word and lets the workgroup proceed (wrong result, flagged,
 // instead of a hung GPU).
+//
+// EXPERIMENTAL BUILD ONLY (round 5: -DWS_EXPERIMENTAL; the product library does not contain this barrier or its one user).
+// Hardware assumption, stated because the fences below are weaker than the formal model asks for: only thread 0
+// of a workgroup issues the release / acquire fences, and a group's last arriver bumps the top counter without an acquire of
+// its group line.  That is sufficient on gfx9 parts -- buffer_wbl2 / buffer_inv act on the whole CU / XCD, and __syncthreads()
+// drains the workgroup's vmcnt in front of the release -- and it is validated on gfx950 only; the data exchanged between the
+// passes are plain loads and stores.  Several single-launch sorts in flight starve each other of slots (each needs all its
+// workgroups resident): one frame at a time only.
 #pragma once
 
 #include <hip/hip_runtime.h>
