@@ -385,7 +385,8 @@ int ws_renderer_download_tile_stats(ws_renderer* r, uint32_t capacity, uint32_t*
  * composited in that batch -- the lock-step cost of the per-batch barriers.  Syncs. */
 int ws_renderer_download_wave_stats(ws_renderer* r, uint32_t tile_capacity, uint32_t* walked);
 /* analysis / parity read-back of the compositing schedule: up to 4096 tiles (1080p class) the compositing workgroups of a
- * renderer that draws one frame at a time run longest list first (one small kernel behind the tile-id sort orders them; the image does not depend on the order).
+ * renderer that draws one frame at a time (not a slot of a view batch with several slots, and its context's last prepare()
+ * calls all on one stream) run longest list first (one small kernel behind the tile-id sort orders them; the image does not depend on the order).
  * order4[4 * b + 0..3] = (tx | ty << 16, begin, end, 0) for workgroup b: the blend tile it composites and that tile's entry
  * range; 0xFFFFFFFF in word 0 = no tile.  *num_blocks = 0 when the last prepared frame was not ordered (4K-class tile
  * counts, non-default tile shapes, WS_BLEND_ORDER=0).  Syncs. */

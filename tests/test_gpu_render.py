@@ -902,3 +902,66 @@ def test_depth_sort_skips_its_last_pass_on_a_narrow_key_range(ws, oracle, monkey
     for name in ("outside", "inside"):
         for k in range(1, 7):
             assert np.array_equal(got[name, "1"][k], got[name, "0"][k]), (name, k)
+
+
+def test_workgroup_order_follows_how_the_context_is_driven(ws, oracle, monkeypatch):
+    """The automatic choice of the blend's workgroup order (round 5): a renderer that draws one frame at a time orders its tiles
+    longest list first (no tail of idle slots: blend -12 ... -18 %); renderers that draw in turn on a ring of streams -- frames
+    in flight, whether through ws_view_batch or through the caller's own loop -- keep the image order (longest-first measured
+    -9 ... -17 % frames/s there).  The library tells the two apart by whether consecutive prepare() calls of the context stay on
+    one stream; the image is the same either way."""
+    import ctypes as C
+    monkeypatch.delenv("WS_BLEND_ORDER", raising=False)
+    vp = (640, 576)
+    rng = np.random.default_rng(81)
+    rows = synth.scene_c1(n=40_000, seed=81)
+    ncol = rows.shape[1]
+    rows[:, ncol - 7:ncol - 4] = np.log(rng.uniform(0.004, 0.05, size=(40_000, 3))).astype(np.float32)
+    cams = synth.orbit_cameras(4, vp[0], vp[1], 600.0, 600.0, radius=3.0, height_off=0.4)
+    c = ws.Context(0)
+    sc = scenes.Scene(ws, oracle, rows, 3, cams[0], vp)
+    pc = ws.PointCloud(c, sc.gpc)
+    hip = C.CDLL("libamdhip64.so")
+    streams = [C.c_void_p() for _ in range(2)]
+    for s in streams:
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0  # hipStreamNonBlocking
+    rs = [ws.GaussianRenderer(c, "rgba32float", 3, False) for _ in range(2)]
+    batch = ws.ViewBatch(c, "rgba32float", 3, False, 2)
+    try:
+        # two renderers in turn on two streams: frames in flight -> image order (no table), from the first frame on
+        for i in range(6):
+            k = i % 2
+            rs[k].prepare(pc, sc.args, stream=streams[k].value)
+            rs[k].render(pc, stream=streams[k].value)
+        for k in range(2):
+            c.sync(streams[k].value)
+            assert rs[k].blend_order().shape[0] == 0
+        in_flight = rs[0].download_target().copy()
+        # one of them alone, frame after frame on its stream: after four calls it orders its tiles
+        for i in range(6):
+            rs[0].prepare(pc, sc.args, stream=streams[0].value)
+            rs[0].render(pc, stream=streams[0].value)
+        c.sync(streams[0].value)
+        assert rs[0].blend_order().shape[0] > 0
+        assert np.array_equal(rs[0].download_target(), in_flight)
+        # the slots of a view batch with two frames in flight never order, however many frames they draw
+        targets = [c.malloc(vp[0] * vp[1] * 16) for _ in range(2)]
+        try:
+            batch.render(pc, [sc.args] * 12, [targets[i % 2] for i in range(12)], vp[0] * 16)
+            batch.sync()
+            assert batch.errors() == 0
+            for slot in range(2):
+                assert batch.renderer(slot).blend_order().shape[0] == 0
+            got = c.download(targets[1], (vp[1], vp[0], 4), np.float32)
+            assert np.array_equal(got, in_flight)
+        finally:
+            for t in targets:
+                c.free(t)
+    finally:
+        batch.close()
+        for r in rs:
+            r.close()
+        for s in streams:
+            hip.hipStreamDestroy(s)
+        pc.close()
+        c.close()

@@ -982,8 +982,8 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
         r->sorted_idx_skipped = r->sorted_keys_skipped = nullptr;
     } else {
         // Four 8-bit passes over the 32-bit keys (gpu_rs.rs:865-884), of which the last one leaves at once on frames whose keys
-        // span less than 2^24 (decided on the device from the range K1 / K1c stored: ws_internal.h depth_range_decide;
-        // WS_DEPTH_SKIP_TOP=0 switches it off).  (K1c's keys are NOT confined to 24 bits: preprocess_compressed.wgsl:325 scales
+        // span less than 2^24 (decided on the device from the key range the sort's first histogram kernel leaves: ws_internal.h
+        // depth_range_decide; WS_DEPTH_SKIP_TOP=0 switches it off).  (K1c's keys are NOT confined to 24 bits: preprocess_compressed.wgsl:325 scales
         // clip z, which is below znear for the nearest splats.)
         uint32_t *sk = nullptr, *sv = nullptr, *sk2 = nullptr, *sv2 = nullptr;
         const int key_bits = 32;
@@ -1086,8 +1086,20 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     // frames in flight it is the wrong order, measured (profiles/r05/blend_order_ab.txt: hd1m -9 %, c3 -17 % frames/s): the first
     // 512 workgroups are then the longest tiles, no slot retires for 40 (hd1m) to 120 us (c3), and the other frames' small
     // dependent kernels, which live on the slots the blend's short tiles keep freeing, starve behind it.
+    // "In flight" = a slot of a view batch with several slots, or -- for renderers driven by the caller's own loop -- a context
+    // whose prepare() calls change stream from call to call (frames in flight on a ring of streams do; a renderer that draws
+    // one frame at a time stays on its stream: after four consecutive calls on one stream it orders its tiles).
     r->blend_order_valid = false;
-    const int order_mode = r->ctx->blend_order < 0 ? (r->throughput_mode ? 0 : 1) : r->ctx->blend_order;
+    bool in_flight = r->throughput_mode;
+    if (!in_flight) {
+        ws_context* c = r->ctx;
+        void* const prev = c->last_prepare_stream.exchange(static_cast<void*>(stream), std::memory_order_relaxed);
+        uint32_t run = 0;
+        if (prev == static_cast<void*>(stream)) run = c->same_stream_run.fetch_add(1u, std::memory_order_relaxed) + 1u;
+        else c->same_stream_run.store(0u, std::memory_order_relaxed);
+        in_flight = run < 4u;
+    }
+    const int order_mode = r->ctx->blend_order < 0 ? (in_flight ? 0 : 1) : r->ctx->blend_order;
     // (up to 4096 tiles = eight rounds of workgroups on this chip: beyond that the tail is a small share of the kernel and the
     // one-workgroup ordering kernel, 3 us at 2040 tiles and 7.6 us at 8160, costs what it saves -- c5, 4K: measured)
     if (order_mode && r->ctx->tile_qw == 4 && r->ctx->tile_qh == 4 && ntiles <= 4096u && r->ctx->blend_tpw_log2 <= 0) {

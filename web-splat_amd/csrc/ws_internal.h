@@ -2,6 +2,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 
 #include <string>
@@ -483,6 +485,12 @@ struct ws_context {
                               //   launches (opt-in: on ROCm 7.2 legacy-NULL-stream work between two launches of a used
                               //   executable graph makes the next launch fault)
     uint32_t tile_qw = 4, tile_qh = 4;  // WS_TILE_SHAPE = 2x2 | 4x2 | 4x4 (default: 32x32-px binning tiles)
+    // Is this context drawing on several streams in turn (a hand-rolled pipeline of renderers with frames in flight), or one
+    // frame at a time?  The stream of the latest prepare() and how many consecutive prepare() calls used that same stream;
+    // read by the automatic choice of the blend's workgroup order (ws_api.cpp).  Relaxed atomics: renderers of one context
+    // may be driven from several host threads (the submission threads of a view batch).
+    std::atomic<void*> last_prepare_stream{nullptr};
+    std::atomic<uint32_t> same_stream_run{0};
 };
 
 struct ws_pointcloud {
