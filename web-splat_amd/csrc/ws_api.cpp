@@ -974,7 +974,10 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     if (fat_sort) {
         // fat-tile one-sweep (sort.hip k_dsort_fat): four 8-bit passes A -> B -> A -> B -> A, everything ends where it started
         if ((rc = launch_depth_sort_fat(r->fat, r->keys_a, r->vals_a, r->fpw_a, &r->counters->num_visible, pc->num_points, true,
-                                        r->ctx->depth_sort_mode == DS_COOP, r->epoch, r->ctx->num_cus, stream, km)))
+                                        // (the single-launch form needs all its workgroups resident at once: never beside other
+                                        // frames' kernels -- a slot of a view batch falls back to the one-sweep form)
+                                        r->ctx->depth_sort_mode == DS_COOP && !r->throughput_mode, r->epoch, r->ctx->num_cus, stream,
+                                        km)))
             return rc;
         r->sorted_idx = r->vals_a;
         r->sorted_keys = r->keys_a;
