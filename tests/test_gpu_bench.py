@@ -330,3 +330,16 @@ def test_two_ranks_share_one_gpu_and_draw_identical_views():
     assert sd["views"] == [0, 1] and sd["ranks"] == 2 and sd["identical"] is True and sd["distinct_images"] == 2
     # whole-job value: both ranks' frames over the MAX elapsed
     assert abs(out["value"] - 2 * 30 / (out["ms_per_step"] * 30 / 1e3)) < 1e-6 * out["value"]
+
+
+def test_frames_in_flight_stay_bit_identical_over_a_long_run():
+    """scripts/soak.py in small: the 64 orbit views of c2 drawn 41 times back to back with four frames in flight (2624 frames:
+    the host's run-ahead window, the slots' scratch and mailboxes and the per-frame zero arena cycle hundreds of times), a lone
+    renderer of the same context drawing in between.  The targets of the last pass equal those of the first pass bit for bit, the
+    device's counts are unchanged, no error bit is set.  (The long form -- 96 000 frames of hd1m -- is a script run:
+    profiles/r05/soak_hd1m.json.)"""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import soak
+    res = soak.soak("c2", rounds=40)
+    assert res["pass"], res
+    assert res["frames"] == 40 * 64 and res["distinct_images"] == 64 and res["views_that_differ"] == []
