@@ -43,7 +43,7 @@ struct Geom {
     uint32_t w0, w1, w2;
 };
 __device__ __forceinline__ Geom load_geom(const Source& src, uint32_t store_idx) {
-    const uint32_t* sp = reinterpret_cast<const uint32_t*>(src.splats + (size_t)store_idx * 20);
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(src.splats + (size_t)store_idx * SPLAT_STRIDE);
     Geom g;
     g.w0 = sp[0];
     g.w1 = sp[1];

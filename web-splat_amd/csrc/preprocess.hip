@@ -643,12 +643,17 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
     for (int it = 0; it < K1_ITEMS; ++it) {
         if (vis[it]) {
             const uint32_t slot = base + off[it] + lane_rank[it];
-            uint32_t* sp = reinterpret_cast<uint32_t*>(b.splats + (size_t)slot * 20);
-            sp[0] = so[it].w[0];
-            sp[1] = so[it].w[1];
-            sp[2] = so[it].w[2];
-            sp[3] = so[it].w[3];
-            sp[4] = so[it].w[4];
+            uint32_t* sp = reinterpret_cast<uint32_t*>(b.splats + (size_t)slot * SPLAT_STRIDE);
+            if (SPLAT_STRIDE == 32u) {  // the whole sector in two 16-B stores (no partial-sector write)
+                reinterpret_cast<uint4*>(sp)[0] = make_uint4(so[it].w[0], so[it].w[1], so[it].w[2], so[it].w[3]);
+                reinterpret_cast<uint4*>(sp)[1] = make_uint4(so[it].w[4], 0u, 0u, 0u);
+            } else {
+                sp[0] = so[it].w[0];
+                sp[1] = so[it].w[1];
+                sp[2] = so[it].w[2];
+                sp[3] = so[it].w[3];
+                sp[4] = so[it].w[4];
+            }
             b.keys[slot] = so[it].key;
             b.footprints[slot] = so[it].fp;
             if (b.src_index) b.src_index[slot] = block_base + it * K1_THREADS + tid;
@@ -803,7 +808,7 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess_multi
     };
     auto store = [&](uint32_t v, int it, const SplatOut& so) {
         const uint32_t slot = s_base[v] + s_cnt[v][it][wave] + rank_of(v, it);
-        uint32_t* sp = reinterpret_cast<uint32_t*>(a.b[v].splats + (size_t)slot * 20);
+        uint32_t* sp = reinterpret_cast<uint32_t*>(a.b[v].splats + (size_t)slot * SPLAT_STRIDE);
         sp[0] = so.w[0];
         sp[1] = so.w[1];
         sp[2] = so.w[2];

@@ -470,7 +470,7 @@ __device__ __forceinline__ uint32_t blend_entry_idx(const BlendParams& p, uint2 
 // gather of the next batch never overlapped the walk of the current one); five separate dword loads fix that too but cost
 // 2.5x the address lookups of a random gather (measured: blend +35 % on hd1m, +29 % on c3).
 __device__ __forceinline__ RawSplat blend_gather(const BlendParams& p, uint32_t idx) {
-    const char* sp = reinterpret_cast<const char*>(p.splats) + (size_t)idx * 20;
+    const char* sp = reinterpret_cast<const char*>(p.splats) + (size_t)idx * SPLAT_STRIDE;
     RawSplat r;
     __builtin_memcpy(&r.a, sp, 16);
     __builtin_memcpy(&r.w4, sp + 16, 4);
@@ -491,7 +491,7 @@ __device__ __forceinline__ RawSplat blend_fetch_raw(const BlendParams& p, uint2 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ void blend_gather_lds(const BlendParams& p, uint32_t idx, void* raw4_wave, void* raw1_wave) {
-    const char* sp = reinterpret_cast<const char*>(p.splats) + (size_t)idx * 20;
+    const char* sp = reinterpret_cast<const char*>(p.splats) + (size_t)idx * SPLAT_STRIDE;
     __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)raw4_wave, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(sp + 16), (lptr_t)raw1_wave, 4, 0, 0);
 }
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
     uint32_t idx_next = entry_at(hi1);
     uint32_t w0, w1, w2, w3, w4;
     {
-        const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx_cur * 20);
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx_cur * SPLAT_STRIDE);
         w0 = sp[0];
         w1 = sp[1];
         w2 = sp[2];
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(64) void k_blend_q(const BlendParams p) {
         const uint32_t nb = chunk_len(hi);
         const bool cur_valid = (uint32_t)lane < nb;
         // issue: Splat gather of the next chunk, entry indices of the one after
-        const uint32_t* spn = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx_next * 20);
+        const uint32_t* spn = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx_next * SPLAT_STRIDE);
         const uint32_t n0 = spn[0], n1 = spn[1], n2 = spn[2], n3 = spn[3], n4 = spn[4];
         const uint32_t hi2 = hi1 - chunk_len(hi1);
         const uint32_t idx_nn = entry_at(hi2);
@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(64) void k_blend_strict(const BlendParams p) {
         const uint32_t e = lo + (uint32_t)lane;
         const bool valid = e < range.y;
         const uint32_t idx = p.entry_vals[valid ? e : range.y - 1u];
-        const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx * 20);
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(p.splats + (size_t)idx * SPLAT_STRIDE);
         const StagedSplat s = decode_splat(sp[0], sp[1], sp[2], sp[3], sp[4], W, H, qx_lo, qy_lo, valid);
         unsigned long long rel = __ballot(s.touch);
         while (rel) {

@@ -313,7 +313,7 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     renderer_free_scratch(r);
     int rc;
     const size_t np = (size_t)n + 8;
-    if ((rc = dmalloc(&r->splats, np * 20))) return rc;
+    if ((rc = dmalloc(&r->splats, np * SPLAT_STRIDE))) return rc;
     if ((rc = dmalloc(&r->keys_a, np))) return rc;
     if ((rc = dmalloc(&r->keys_b, np))) return rc;
     if ((rc = dmalloc(&r->vals_a, np))) return rc;
@@ -1634,7 +1634,17 @@ int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, 
             sorted_keys = r->sorted_keys_skipped;
         }
     }
-    if (splats) { int rc_ = copy_d2h(splats, r->splats, (size_t)v * 20, r->last_stream); if (rc_) return rc_; }
+    if (splats) {  // the caller gets the reference's 20-B records whatever stride the device keeps them at
+        if (SPLAT_STRIDE == 20u) {
+            int rc_ = copy_d2h(splats, r->splats, (size_t)v * 20, r->last_stream);
+            if (rc_) return rc_;
+        } else {
+            std::vector<uint8_t> padded((size_t)v * SPLAT_STRIDE);
+            int rc_ = copy_d2h(padded.data(), r->splats, padded.size(), r->last_stream);
+            if (rc_) return rc_;
+            for (size_t i = 0; i < (size_t)v; ++i) std::memcpy(static_cast<uint8_t*>(splats) + i * 20, padded.data() + i * SPLAT_STRIDE, 20);
+        }
+    }
     if (src_index) { int rc_ = copy_d2h(src_index, r->src_index, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
     if (sorted) { int rc_ = copy_d2h(sorted, sorted_idx, (size_t)v * 4, r->last_stream); if (rc_) return rc_; }
     if (keys) {

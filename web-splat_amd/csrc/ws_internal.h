@@ -19,6 +19,14 @@
 #endif
 
 namespace ws {
+// Stride of the per-frame Splat records (pointcloud.rs:352-358: 20 B of f16 values).  32 pads every record to its own 32-B
+// sector: the blend's random gathers then fetch one sector per record instead of 1.5 (A/B: -DWS_SPLAT_STRIDE=32).
+#ifndef WS_SPLAT_STRIDE
+#define WS_SPLAT_STRIDE 20
+#endif
+constexpr uint32_t SPLAT_STRIDE = WS_SPLAT_STRIDE;
+static_assert(SPLAT_STRIDE == 20 || SPLAT_STRIDE == 32, "Splat records are 20 B, optionally padded to 32");
+
 
 // The library's host loops (scene re-layout, PLY row conversion) are OpenMP regions.  LLVM's OpenMP runtime keeps the
 // workers of a finished region SPINNING for KMP_BLOCKTIME -- 200 ms by default -- before they sleep; on a 128-thread host
