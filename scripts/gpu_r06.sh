@@ -35,7 +35,7 @@ PY
 
 if [[ $WHAT == *ubenchq* ]]; then
   for Q in 4 8 16; do
-    GPU_MAX_HW_QUEUES=$Q timeout 300 scripts/ubench/queue_concurrency ${UBENCH_STREAMS:-12} > $OUT/queue_concurrency_q$Q.jsonl 2> $OUT/queue_concurrency_q$Q.err
+    QC_TIMELINE=1 GPU_MAX_HW_QUEUES=$Q timeout 300 scripts/ubench/queue_concurrency ${UBENCH_STREAMS:-12} > $OUT/queue_concurrency_q$Q.jsonl 2> $OUT/queue_concurrency_q$Q.err
     echo "ubenchq q=$Q exit=$?" >> $OUT/summary.txt
   done
 fi

@@ -1,6 +1,6 @@
 // grid_barrier.hip -- what does a device-wide barrier INSIDE a launch cost on MI355X, against the dependent kernel
 // boundary it would replace?  (round-3 verdict item 1: "a negative result counts only with the barrier cost measured in
-// isolation".)  The barrier is the library's own (web-splat_amd/csrc/grid_barrier.h), the phases around it are the same
+// isolation".)  The barrier is the library's own (web-splat_amd/csrc/experimental/grid_barrier.h), the phases around it are the same
 // in both forms:
 //   phase   every workgroup reads the word its LEFT neighbour (blockIdx - 1) wrote in the previous phase, adds one and
 //           writes its own word -- a real cross-workgroup dependency, so a barrier / boundary that does not order memory
@@ -16,7 +16,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "grid_barrier.h"
+#include "experimental/grid_barrier.h"
 
 #define CK(x)                                                                       \
     do {                                                                            \

@@ -103,6 +103,39 @@ int main(int argc, char** argv) {
                 }
                 if (ov < 0.02 * one_chain) ++never_pairs;
             }
+        if (std::getenv("QC_TIMELINE") && (S == 4 || S == 5 || S == 6 || S == 8)) {
+            // per stream: span and busy time; the overlap matrix (share of stream i's busy time with stream j busy too); the
+            // first kernels of every stream as (start, end) in us from the first start: who runs while who waits
+            unsigned long long t00 = ~0ull;
+            for (auto& x : st) t00 = std::min(t00, x.t0);
+            std::printf("{\"timeline_streams\": %d, \"hw_queues\": \"%s\", \"streams\": [", S, q ? q : "default");
+            for (int i = 0; i < S; ++i) {
+                double busy = 0.0;
+                for (int a = 0; a < K; ++a) busy += (double)(st[(size_t)i * K + a].t1 - st[(size_t)i * K + a].t0) / 100.0;
+                std::printf("%s{\"first_start_us\": %.1f, \"last_end_us\": %.1f, \"busy_us\": %.0f, \"overlap_with\": [", i ? ", " : "",
+                            (double)(st[(size_t)i * K].t0 - t00) / 100.0, (double)(st[(size_t)i * K + K - 1].t1 - t00) / 100.0, busy);
+                for (int j = 0; j < S; ++j) {
+                    double ov = 0.0;
+                    if (j != i)
+                        for (int a = 0; a < K; ++a) {
+                            const Stamp& x = st[(size_t)i * K + a];
+                            for (int b = 0; b < K; ++b) {
+                                const Stamp& y = st[(size_t)j * K + b];
+                                if (y.t0 >= x.t1) break;
+                                if (y.t1 <= x.t0) continue;
+                                ov += (double)(std::min(x.t1, y.t1) - std::max(x.t0, y.t0)) / 100.0;
+                            }
+                        }
+                    std::printf("%s%.2f", j ? ", " : "", ov / busy);
+                }
+                std::printf("], \"first_kernels_us\": [");
+                for (int a = 0; a < 12; ++a)
+                    std::printf("%s[%.0f, %.0f]", a ? ", " : "", (double)(st[(size_t)i * K + a + 100].t0 - t00) / 100.0,
+                                (double)(st[(size_t)i * K + a + 100].t1 - t00) / 100.0);
+                std::printf("]}");
+            }
+            std::printf("]}\n");
+        }
         // B: frame-shaped chains
         const int KF = 21 * 30;
         double bestf = 1e30;
