@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 2
+#define WS_ABI_VERSION 3 /* 3: ws_context_config / ws_context_create_with_config; the library reads no environment variable */
 
 typedef enum ws_status {
     WS_OK = 0,
@@ -169,9 +169,47 @@ typedef struct ws_frame_stats {
 
 const char* ws_last_error(void);
 uint32_t ws_abi_version(void);
+/* bit 0: this is the EXPERIMENTAL build (make experimental, lib_exp/): it also carries the measured-and-lost variants the
+ * exp_* fields of ws_context_config select; the product library refuses them with WS_ERR_UNSUPPORTED */
+#define WS_BUILD_EXPERIMENTAL 1u
+uint32_t ws_build_flags(void);
 
 /* ---- context: lib.rs:68-125 WGPUContext::new_instance / new --------------------------------- */
+/* ws_context_create uses the defaults of ws_context_config_init.  THE LIBRARY READS NO ENVIRONMENT VARIABLE: a drop-in
+ * library must not be steered by the environment of whoever loads it.  Tuning / analysis switches travel in this struct;
+ * bench.py, the tests and the tools/ mains translate their WS_* environment into it OUTSIDE the library
+ * (include/websplat_env.h, web-splat_amd/websplat/api.py config_from_env). */
+typedef struct ws_context_config {
+    uint32_t struct_size;      /* sizeof(ws_context_config) of the caller: the struct may grow at its end */
+    int32_t use_graph;         /* 0; 1 = prepare() on a real stream replays a captured frame graph (opt-in: ROCm 7.2 fault) */
+    int32_t depth_skip_top;    /* 1; 0 = the depth sort always runs all of its passes (A/B) */
+    int32_t blend_order;       /* -1 automatic; 0 image order; 1 longest list first; 2 / 3 measured experiments */
+    int32_t blend_split;       /* -1 automatic (tiles < 2 x CUs); 0 / 1 never / always two half-tile workgroups per binning tile */
+    int32_t bin_request;       /* 1 = decided per frame on the device (default); 0 never / 2 always bin at twice the blend's tile */
+    int32_t batch_threads;     /* -1 automatic; 0 / 1 = a view batch never / always enqueues every slot from its own host thread */
+    int32_t batch_queue_depth; /* -1 = default (5): frames a slot's host side may run ahead of the device; 0 = unbounded */
+    int32_t blend_tpw_log2;    /* -1 automatic; tiles per blend workgroup = 2^n (4K-class tile counts) */
+    int32_t blend_lds_pad_kb;  /* 0; unused dynamic LDS per blend workgroup (occupancy experiments) */
+    int32_t tile_qw, tile_qh;  /* 4, 4: 8x8-px quadrants per compositing tile (2x2, 4x2 or 4x4) */
+    int32_t debug_cut;         /* 0; analysis: stop every frame after stage n (1 = K1 ... 4 = tile sort) */
+    int32_t capture;           /* 0; 1 = renderers keep per-splat source indices / per-tile debug words (tests) */
+    int32_t render_views_fast_blend; /* 0; 1 = ws_render_views composites with the throughput blend instead of target precision */
+    int32_t ply_decode_host;   /* 0; 1 = ws_load_ply converts the vertex rows on the host instead of on the device */
+    int32_t depth_digit_bits;  /* 0 = default; 8 = four 8-bit passes (the reference's shape), 9 = three 9-bit passes over key - base */
+    int32_t depth_tile_kpt;    /* 0 = by input size; 4 / 8 = keys per thread of the 9-bit depth sort's tiles (A/B) */
+    /* measured-and-lost variants: honoured by the EXPERIMENTAL build only (lib_exp); the product library refuses non-defaults */
+    int32_t exp_depth_sort;    /* 0 scan (default) | 1 fat-tile one-sweep | 2 one cooperative launch */
+    int32_t exp_dsort_fat_grid;
+    int32_t exp_blend_variant; /* 1 = k_blend_q */
+    int32_t exp_blend_dma;     /* 1 = LDS-DMA staging */
+    int32_t exp_batch_k1;      /* 1 (default) .. 4 views per K1 launch */
+    int32_t exp_footprint_ellipse;
+    int32_t exp_tile_sort_wide;
+    int32_t reserved[7];       /* zero */
+} ws_context_config;
+void ws_context_config_init(ws_context_config* cfg); /* fills in the defaults above */
 int ws_context_create(int hip_device, ws_context** out);
+int ws_context_create_with_config(int hip_device, const ws_context_config* cfg, ws_context** out);
 void ws_context_destroy(ws_context* ctx);
 int ws_sync(ws_context* ctx, void* stream); /* device.poll(Wait) */
 /* How a host thread of this process waits for the context's device in ws_sync / hipStreamSynchronize / the read-backs:
@@ -343,12 +381,16 @@ int ws_renderer_download_frame(ws_renderer* r, uint32_t capacity, void* splats, 
  * function of the frame; WS_BIN_SHIFT=0 / 1 forces it off / on; frames in capture mode always use the context's tile).
  * Four compositing workgroups then share one binned list: half the (tile, splat) entries to emit and sort.  Syncs. */
 int ws_renderer_binning_tile(ws_renderer* r, uint32_t* width, uint32_t* height);
-/* Digit passes the depth sort of the LAST prepared frame executed.  The reference always runs four 8-bit passes
- * (gpu_rs.rs:865-884); here a frame whose keys span less than 2^24 -- a camera outside the scene; most frames of the compressed
- * scenes, whose keys are scaled to about 24 bits (preprocess_compressed.wgsl:325) -- skips the fourth, decided on the device
- * from the key range K1 stored: sorted as (key - base) that pass runs over a constant digit, i.e. is the identity; order and
- * stability are the reference's.  Syncs. */
+/* Digit passes the depth sort of the LAST prepared frame executed, and (digit_bits, may be NULL) their width.  The reference
+ * always runs four 8-bit passes (gpu_rs.rs:865-884).  Here the sort's first histogram kernel -- which reads every key anyway --
+ * leaves the frame's key range on the device; the passes behind it take their digits from (key - base), and the last of the
+ * four enqueued passes leaves at once when it would run over a constant digit (the identity): 3 passes on a frame whose keys
+ * span less than 2^24 (8-bit digits: a camera outside the scene) or 2^27 (9-bit digits).  The compressed shader's keys
+ * (preprocess_compressed.wgsl:325) are NOT confined to 24 bits: clip z is below znear for the nearest splats.  The digit
+ * width is chosen per frame on the host from the key range the renderer's PREVIOUS frame posted (8 bits when it was below
+ * 2^24, else 9; ws_context_config::depth_digit_bits forces it); either width gives the reference's stable order.  Syncs. */
 int ws_renderer_depth_sort_passes(ws_renderer* r, uint32_t* passes);
+int ws_renderer_depth_sort_digit_bits(ws_renderer* r, uint32_t* digit_bits); /* of the last prepared frame; no sync */
 /* The compositing tile in pixels (one workgroup of the blend): 32x32 by default (four 16x16 tiles -- 4x4 wave quadrants
  * of 8x8 pixels -- sharing one binned list), 32x16 or 16x16 with WS_TILE_SHAPE=4x2|2x2 at context creation (tuning; 2x2 is
  * the literal one-workgroup-per-16x16-tile form).  Lists are built per BINNING tile: this tile, or 2 x 2 of them when the

@@ -16,6 +16,7 @@ from websplat import synth  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
 rows = synth.scene_c3(n=n, seed=2)
 ctx = ws.Context(0)
+ctx_host = ws.Context(0, ws.config_from_env(ply_decode_host=1))  # (the switch belongs to the context; the library reads no environment)
 out = {"vertices": n, "file_MB": round(n * 248 / 1e6, 1), "host_threads": os.cpu_count()}
 with tempfile.TemporaryDirectory(dir="/tmp") as td:
     path = os.path.join(td, "scene.ply")
@@ -26,14 +27,11 @@ with tempfile.TemporaryDirectory(dir="/tmp") as td:
     out["read_file_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
     del raw
     for mode in ("gpu", "host", "gpu", "host"):
-        if mode == "host":
-            os.environ["WS_PLY_DECODE"] = "host"
-        else:
-            os.environ.pop("WS_PLY_DECODE", None)
         t0 = time.perf_counter()
-        pc = ws.PointCloud.load(ctx, path)
+        pc = ws.PointCloud.load(ctx_host if mode == "host" else ctx, path)
         ctx.sync()
         out.setdefault(f"load_{mode}_decode_ms", []).append(round((time.perf_counter() - t0) * 1e3, 1))
         pc.close()
+ctx_host.close()
 ctx.close()
 print(json.dumps(out))

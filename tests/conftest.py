@@ -11,20 +11,22 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
+    config.addinivalue_line("markers", "experimental: exercises a measured-and-lost variant that only the experimental build "
+                                       "(make experimental, WEBSPLAT_LIB=.../lib_exp/libwebsplat_hip.so) contains")
 
 
-@pytest.hookimpl(hookwrapper=True)
-def pytest_runtest_makereport(item, call):
-    """The measured-and-lost variants (WS_DEPTH_SORT=onesweep|coop, WS_BLEND_VARIANT, WS_BLEND_DMA, WS_BATCH_K1,
-    WS_FOOTPRINT=ellipse, WS_TILE_SORT=wide) are compiled only into the experimental build (make -C web-splat_amd experimental);
-    the product library refuses their switches at ws_context_create.  Their tests run when WEBSPLAT_LIB points at
-    lib_exp/libwebsplat_hip.so and are reported as SKIPPED, not failed, against the product library."""
-    outcome = yield
-    rep = outcome.get_result()
-    if rep.failed and call.excinfo is not None and "only in the experimental build" in str(call.excinfo.value):
-        rep.outcome = "skipped"
-        rep.longrepr = (str(item.fspath), item.location[1] or 0,
-                        "Skipped: measured-and-lost variant, experimental build only (WEBSPLAT_LIB=.../lib_exp/libwebsplat_hip.so)")
+from variants import lib_is_experimental  # noqa: E402  (tests/variants.py: the explicit marking of the variant tests)
+
+
+def pytest_collection_modifyitems(config, items):
+    marked = [it for it in items if it.get_closest_marker("experimental")]
+    if not marked:
+        return
+    if lib_is_experimental():
+        return
+    skip = pytest.mark.skip(reason="measured-and-lost variant: experimental build only (WEBSPLAT_LIB=.../lib_exp/libwebsplat_hip.so)")
+    for it in marked:
+        it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

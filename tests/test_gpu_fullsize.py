@@ -12,6 +12,8 @@ import sys
 import numpy as np
 import pytest
 
+from variants import env_param, exp_param  # noqa: F401
+
 import scenes
 from websplat import synth
 
@@ -309,6 +311,7 @@ def test_view_batch_submission_threads_draw_identical_frames(ws, oracle, monkeyp
         c.close()
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("group,slots,compressed", [(2, 4, False), (4, 4, False), (4, 8, False), (3, 3, False), (2, 4, True)])
 def test_view_batch_shared_k1_draws_identical_frames(ws, oracle, monkeypatch, tmp_path, group, slots, compressed):
     """WS_BATCH_K1=g: groups of g consecutive frames of a view batch share ONE K1 launch (k_preprocess_multi: the scene is
@@ -541,7 +544,7 @@ def test_c3_full_image_vs_oracle(ws, ctx, oracle):
     _SCENE_CACHE.clear()
 
 
-@pytest.mark.parametrize("depth_sort", ["scan", "onesweep"])
+@pytest.mark.parametrize("depth_sort", ["scan", exp_param("onesweep")])
 def test_frame_graph_replay_equals_launch_by_launch(ws, oracle, monkeypatch, depth_sort):
     """prepare() on a real stream replays a captured frame graph (one graph launch + one kernel-argument update per
     frame, a ring of executable graphs); twelve frames enqueued back to back on ONE stream -- three times the ring --

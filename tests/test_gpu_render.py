@@ -9,6 +9,8 @@ last-ulp difference in `a` next to the discard threshold of gaussian.wgsl:61."""
 import numpy as np
 import pytest
 
+from variants import env_param, exp_param  # noqa: F401
+
 import scenes
 from websplat import synth
 
@@ -263,16 +265,16 @@ def test_ply_file_roundtrip(ws, ctx, oracle, tmp_path):
             pc.close()
 
 
-@pytest.mark.parametrize("env", [{"WS_BLEND_VARIANT": "1"}, {"WS_DEPTH_SORT": "onesweep", "WS_BLEND_VARIANT": "1"},
-                                 {"WS_TILE_SHAPE": "2x2"}, {"WS_TILE_SHAPE": "4x2"}, {"WS_TILE_SHAPE": "4x4"},
-                                 {"WS_TILE_SHAPE": "4x2", "WS_BLEND_VARIANT": "1"},
-                                 {"WS_TILE_SHAPE": "4x4", "WS_BLEND_VARIANT": "1", "WS_DEPTH_SORT": "onesweep"},
-                                 {"WS_TILE_SHAPE": "4x4", "WS_BLEND_TPW_LOG2": "1"},
-                                 {"WS_TILE_SHAPE": "4x2", "WS_BLEND_TPW_LOG2": "2"},
-                                 {"WS_DEPTH_SORT": "onesweep", "WS_TILE_SHAPE": "2x2"},
-                                 {"WS_BLEND_SPLIT": "1"}, {"WS_BLEND_SPLIT": "0"},
-                                 {"WS_BLEND_DMA": "1"}, {"WS_BLEND_DMA": "1", "WS_BLEND_TPW_LOG2": "2"},
-                                 {"WS_DEPTH_SORT": "onesweep"}, {"WS_DEPTH_SORT": "coop"}, {"WS_DEPTH_SORT": "scan"}])
+@pytest.mark.parametrize("env", [env_param({"WS_BLEND_VARIANT": "1"}), env_param({"WS_DEPTH_SORT": "onesweep", "WS_BLEND_VARIANT": "1"}),
+                                 env_param({"WS_TILE_SHAPE": "2x2"}), env_param({"WS_TILE_SHAPE": "4x2"}), env_param({"WS_TILE_SHAPE": "4x4"}),
+                                 env_param({"WS_TILE_SHAPE": "4x2", "WS_BLEND_VARIANT": "1"}),
+                                 env_param({"WS_TILE_SHAPE": "4x4", "WS_BLEND_VARIANT": "1", "WS_DEPTH_SORT": "onesweep"}),
+                                 env_param({"WS_TILE_SHAPE": "4x4", "WS_BLEND_TPW_LOG2": "1"}),
+                                 env_param({"WS_TILE_SHAPE": "4x2", "WS_BLEND_TPW_LOG2": "2"}),
+                                 env_param({"WS_DEPTH_SORT": "onesweep", "WS_TILE_SHAPE": "2x2"}),
+                                 env_param({"WS_BLEND_SPLIT": "1"}), env_param({"WS_BLEND_SPLIT": "0"}),
+                                 env_param({"WS_BLEND_DMA": "1"}), env_param({"WS_BLEND_DMA": "1", "WS_BLEND_TPW_LOG2": "2"}),
+                                 env_param({"WS_DEPTH_SORT": "onesweep"}), env_param({"WS_DEPTH_SORT": "coop"}), env_param({"WS_DEPTH_SORT": "scan"})])
 def test_cross_check_paths(ws, oracle, env, monkeypatch):
     """The alternative implementations kept as cross-checks (fat-tile one-sweep depth sort as per-pass launches and as one
     launch with device-wide barriers, wave-per-quadrant blend, LDS-DMA staging) and
@@ -294,8 +296,8 @@ def test_cross_check_paths(ws, oracle, env, monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize("env", [{"WS_BLEND_DMA": "1"}, {"WS_BLEND_DMA": "1", "WS_BLEND_TPW_LOG2": "2"},
-                                 {"WS_DEPTH_SORT": "onesweep"}, {"WS_DEPTH_SORT": "coop"}, {"WS_DEPTH_SORT": "scan"}])
+@pytest.mark.parametrize("env", [env_param({"WS_BLEND_DMA": "1"}), env_param({"WS_BLEND_DMA": "1", "WS_BLEND_TPW_LOG2": "2"}),
+                                 env_param({"WS_DEPTH_SORT": "onesweep"}), env_param({"WS_DEPTH_SORT": "coop"}), env_param({"WS_DEPTH_SORT": "scan"})])
 @pytest.mark.parametrize("kind", ["c2", "c3"])
 def test_switched_paths_draw_the_default_image_bit_for_bit(ws, ctx, oracle, env, kind, monkeypatch):
     """Switches that change HOW a frame is computed, not WHAT (the LDS-DMA staging of the blend had no test; the
@@ -335,8 +337,8 @@ def test_switched_paths_draw_the_default_image_bit_for_bit(ws, ctx, oracle, env,
         c.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"WS_DEPTH_SORT": "onesweep"}, {"WS_DEPTH_SORT": "coop"}, {"WS_TILE_SORT": "wide"},
-                                 {"WS_BLEND_VARIANT": "1"}])
+@pytest.mark.parametrize("env", [env_param({}), env_param({"WS_DEPTH_SORT": "onesweep"}), env_param({"WS_DEPTH_SORT": "coop"}), env_param({"WS_TILE_SORT": "wide"}),
+                                 env_param({"WS_BLEND_VARIANT": "1"})])
 def test_degenerate_frames(ws, oracle, env, monkeypatch):
     """The ragged ends of the frame: a camera that looks AWAY from the cloud (nothing visible: every kernel behind K1 runs on a
     device-side count of zero), a one-Gaussian cloud, and a cloud whose visible splats all sit in the 1.2x cull margin with
@@ -485,7 +487,7 @@ def _coverage_tiles(splats_f16, viewport, tile=(16, 16)):
     return out
 
 
-@pytest.mark.parametrize("footprint", ["rect", "ellipse", "wide"])
+@pytest.mark.parametrize("footprint", ["rect", exp_param("ellipse"), "wide"])
 @pytest.mark.parametrize("shape", [None, "2x2", "4x2", "4x4"])
 @pytest.mark.parametrize("kind", ["c1", "needles"])
 def test_binning_covers_every_touched_tile(ws, oracle, kind, shape, footprint, monkeypatch):
@@ -618,6 +620,7 @@ def test_wave_stats_capture(ws, ctx, oracle):
         pc.close()
 
 
+@pytest.mark.experimental
 def test_footprint_modes_draw_the_same_image(ws, oracle, monkeypatch):
     """The footprint word only decides which tiles LIST a splat; the blend's per-pixel test decides what is drawn.  The
     ellipse footprint (WS_FOOTPRINT=ellipse) must therefore give the bit-identical image with fewer tile entries."""
@@ -739,6 +742,7 @@ def test_binning_granularity_is_decided_per_frame_on_the_device(ws, oracle, monk
         assert np.array_equal(out[name, "auto"][0], out[name, "1" if name == "big" else "0"][0])
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("viewport,n,bins", [((640, 400), 6000, 512), ((1920, 1080), 150_000, 2048), ((352, 288), 6000, 128),
                                              ((256, 192), 6000, 0)])
 def test_single_pass_tile_sort_equals_the_digit_passes(ws, oracle, monkeypatch, viewport, n, bins):
@@ -852,20 +856,27 @@ def test_compositing_workgroups_run_longest_list_first(ws, oracle, monkeypatch):
     assert not np.array_equal(imgs["1", "auto", 0], imgs["1", "auto", 1])
 
 
-def test_depth_sort_skips_its_last_pass_on_a_narrow_key_range(ws, oracle, monkeypatch):
+@pytest.mark.parametrize("digit_bits", [8, 9])
+def test_depth_sort_skips_its_last_pass_on_a_narrow_key_range(ws, oracle, monkeypatch, digit_bits):
     """Round 5: a camera outside the scene sees depth keys -- bits(zfar - z), preprocess.wgsl:270-273 -- that span less than 2^24;
     sorted as (key - base) the fourth 8-bit pass of the LSD sort is then the identity, and the frame's depth sort executes three
     passes (decided on the device from the key range K1 stored; the readers of the sorted arrays follow).  Draw order, tile
     lists and image must be exactly those of the same frame with the pass forced (WS_DEPTH_SKIP_TOP=0) -- and of the oracle's
     stable sort; the same slab with a trail of splats far behind it (keys over a factor of > 4: more than 2^24 apart) keeps
-    its four passes."""
+    its four passes.  Round 6, digit_bits = 9: three 9-bit passes cover key - base below 2^27 (both frames here), a fourth over
+    bits 27..31 runs only beyond that (a frame with a splat right at the camera and one at the far plane: keys 2^30 apart)."""
+    monkeypatch.setenv("WS_DEPTH_DIGIT_BITS", str(digit_bits))
+    span = 1 << (3 * digit_bits)
+    low = (1 << digit_bits) - 1
     vp = (800, 600)
     rows = synth.scene_c1(n=120_000, seed=71)
     rows[:, 2] *= 0.5        # a slab: seen from outside its keys span a factor of ~2.5 (a factor of 4 is 2^24 in f32 bits)
     outside = synth.look_at_camera(0, [0.2, -0.3, -9.0], [0, 0, 0], vp[0], vp[1], 2100.0, 2100.0)
     trail = synth.scene_c1(n=4000, seed=72)
     trail[:, 0:2] *= 0.3
-    trail[:, 2] = np.random.default_rng(73).uniform(2.0, 60.0, size=4000).astype(np.float32)   # far behind the slab, along the view axis
+    trail[:, 2] = np.random.default_rng(73).uniform(2.0, 60.0 if digit_bits == 8 else 3000.0, size=4000).astype(np.float32)   # far behind the slab, along the view axis
+    if digit_bits == 9:
+        trail[:8, 2] = -8.9   # ... and a few right in front of the camera: bits(zfar - z) of near and far splats are > 2^27 apart
     rows_wide = np.concatenate([rows, trail])
     got = {}
     for skip in ("1", "0"):
@@ -896,12 +907,52 @@ def test_depth_sort_skips_its_last_pass_on_a_narrow_key_range(ws, oracle, monkey
         finally:
             c.close()
     k_out, k_in = got["outside", "1"][1].astype(np.int64), got["inside", "1"][1].astype(np.int64)
-    assert k_out.max() - (k_out.min() & ~0xFF) < (1 << 24) <= k_in.max() - (k_in.min() & ~0xFF)
+    assert k_out.max() - (k_out.min() & ~low) < span <= k_in.max() - (k_in.min() & ~low), (k_out.min(), k_out.max(), k_in.min(), k_in.max())
     assert got["outside", "1"][0] == 3 and got["outside", "0"][0] == 4
     assert got["inside", "1"][0] == 4 and got["inside", "0"][0] == 4
     for name in ("outside", "inside"):
         for k in range(1, 7):
             assert np.array_equal(got[name, "1"][k], got[name, "0"][k]), (name, k)
+
+
+def test_depth_sort_digit_width_follows_the_previous_frames_key_range(ws, oracle, monkeypatch):
+    """Round 6: with no width forced, a renderer sorts a frame with 8-bit digits when its previous frame's keys spanned < 2^24
+    (three passes), with 9-bit digits when they did not (three passes again, instead of four 8-bit ones) -- the answer travels
+    through pinned memory, no sync.  The first frame knows nothing and takes 8 bits; the order -- hence the image -- is the
+    stable sort's whichever width ran."""
+    monkeypatch.delenv("WS_DEPTH_DIGIT_BITS", raising=False)
+    vp = (800, 600)
+    rows = synth.scene_c1(n=60_000, seed=75)
+    rows[:, 2] *= 0.5
+    cam = synth.look_at_camera(0, [0.2, -0.3, -9.0], [0, 0, 0], vp[0], vp[1], 2100.0, 2100.0)
+    trail = synth.scene_c1(n=3000, seed=76)
+    trail[:, 0:2] *= 0.3
+    trail[:, 2] = np.random.default_rng(77).uniform(2.0, 60.0, size=3000).astype(np.float32)
+    c = ws.Context(0)
+    try:
+        for rr, want_bits, want_passes in ((rows, [8, 8, 8], [3, 3, 3]), (np.concatenate([rows, trail]), [8, 9, 9], [4, 3, 3])):
+            sc = scenes.Scene(ws, oracle, rr, 3, cam, vp)
+            pc = ws.PointCloud(c, sc.gpc)
+            r = ws.GaussianRenderer(c, "rgba32float", 3, False)
+            try:
+                imgs, bits, passes = [], [], []
+                for _ in range(3):
+                    r.prepare(pc, sc.args)
+                    r.render(pc)
+                    c.sync()                       # (the mailbox word of this frame is posted: the next prepare() sees it)
+                    bits.append(r.depth_sort_digit_bits())
+                    passes.append(r.depth_sort_passes())
+                    imgs.append(r.download_target())
+                    fr = r.download_frame()
+                    _, order = oracle.sort_pairs(fr["keys"], np.arange(fr["num_visible"], dtype=np.uint32))
+                    assert np.array_equal(fr["sorted"], order)
+                assert bits == want_bits and passes == want_passes, (bits, passes)
+                assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2])
+            finally:
+                r.close()
+                pc.close()
+    finally:
+        c.close()
 
 
 def test_workgroup_order_follows_how_the_context_is_driven(ws, oracle, monkeypatch):

@@ -5,20 +5,27 @@ import os
 import numpy as np
 import pytest
 
+from variants import env_param, exp_param  # noqa: F401
+
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["generic", "depth", "depth:onesweep", "depth:coop"],
-                ids=["reduce_scan", "depth_scan_companion", "depth_fat_onesweep", "depth_fat_coop"])
+@pytest.fixture(scope="module", params=["generic", "depth", "depth9", "depth9k8", exp_param("depth:onesweep", id="depth_fat_onesweep"),
+                                        exp_param("depth:coop", id="depth_fat_coop")],
+                ids=lambda p: {"generic": "reduce_scan", "depth": "depth_scan_companion", "depth9": "depth_9bit_digits",
+                               "depth9k8": "depth_9bit_digits_2048_tiles"}.get(p))
 def sort_ctx(ws, request):
     """Four paths to the same contract: the generic sorter (per-tile histograms -> column scan -> scatter), and the
     renderer's depth sorts behind ws_sorter_sort_depth -- the generic sorter carrying a companion value, and the fat-tile
     one-sweep (round 4) as per-pass launches and as ONE launch with device-wide barriers (WS_DEPTH_SORT selects; inputs
     beyond the fat form's 2 M pairs take the generic sorter)."""
     depth = request.param != "generic"
-    env = {}
+    env = {"WS_DEPTH_DIGIT_BITS": "8", "WS_DEPTH_TILE_KPT": "0"}
     if depth and ":" in request.param:
         env["WS_DEPTH_SORT"] = request.param.split(":")[1]
+    if request.param.startswith("depth9"):   # round 6: 9-bit digits (k_dsort9_*), at both tile sizes
+        env["WS_DEPTH_DIGIT_BITS"] = "9"
+        env["WS_DEPTH_TILE_KPT"] = "8" if request.param.endswith("k8") else "4"
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     c = ws.Context(0)
@@ -124,8 +131,9 @@ def test_sort_large_sortedness(ws, sort_ctx):
     assert np.all(p[1:][ties] > p[:-1][ties])
 
 
+@pytest.mark.parametrize("digit_bits", ["8", "9"])
 @pytest.mark.parametrize("nbits", [0, 1, 5, 12, 13, 20, 26, 27, 28, 30, 31, 32])
-def test_depth_sort_key_ranges(ws, ctx, oracle, nbits):
+def test_depth_sort_key_ranges(ws, oracle, nbits, digit_bits, monkeypatch):
     """Keys confined to a range of nbits bits that starts anywhere (a frame's depth keys are: bits of zfar - z), from a
     single value to the full 32 bits: passes whose digit is the same for every key are the degenerate case of every
     histogram and scan in the sorter."""
@@ -136,10 +144,13 @@ def test_depth_sort_key_ranges(ws, ctx, oracle, nbits):
     keys = (base + rng.integers(0, span + 1, size=n, dtype=np.uint64)).astype(np.uint32)
     if nbits:
         keys[0], keys[1] = np.uint32(base), np.uint32(base + span)   # the range is exactly nbits wide
+    monkeypatch.setenv("WS_DEPTH_DIGIT_BITS", digit_bits)
+    ctx = ws.Context(0)
     sorter = ws.GPURSSorter(ctx, n)
     try:
         k, p = sorter.sort_host(keys, np.arange(n, dtype=np.uint32), depth=True)
     finally:
         sorter.close()
+        ctx.close()
     ok, op = oracle.sort_pairs(keys, np.arange(n, dtype=np.uint32))
     assert np.array_equal(k, ok) and np.array_equal(p, op)

@@ -24,7 +24,27 @@ def test_abi_exports_every_declared_symbol(ws):
     assert not missing, f"declared in websplat.h but not exported: {missing}"
     unbound = sorted(declared - set(_lib.SIGNATURES))
     assert not unbound, f"declared in websplat.h but not bound by the Python stub: {unbound}"
-    assert ws.lib.ws_abi_version() == 2
+    assert ws.lib.ws_abi_version() == 3
+
+
+def test_the_library_reads_no_environment_variable(ws):
+    """Round 6: a drop-in library must not be steered by the environment of whoever loads it.  Every switch travels in
+    ws_context_config; the translation of the WS_* variables lives in the harness (websplat.config_from_env,
+    include/websplat_env.h).  The product library does not even import getenv, and no WS_* name is in its strings."""
+    import subprocess
+    from websplat import _lib
+    und = subprocess.run(["nm", "-D", "-u", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und, "the library imports getenv"
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"WS_GRAPH", b"WS_BLEND_ORDER", b"WS_TILE_SHAPE", b"WS_DEPTH_SORT\0", b"WS_CAPTURE", b"WS_BATCH_QUEUE_DEPTH"):
+        assert name not in blob, name
+    c = ws.config_from_env({"WS_BLEND_ORDER": "1", "WS_TILE_SHAPE": "4x2", "WS_BIN_SHIFT": "0", "WS_DEPTH_DIGIT_BITS": "9",
+                            "WS_DEPTH_SORT": "onesweep", "WS_PLY_DECODE": "host"}, debug_cut=2)
+    assert (c.struct_size, c.blend_order, c.tile_qw, c.tile_qh, c.bin_request, c.depth_digit_bits, c.exp_depth_sort,
+            c.ply_decode_host, c.debug_cut, c.batch_queue_depth, c.exp_batch_k1) == (128, 1, 4, 2, 0, 9, 1, 1, 2, -1, 1)
+    d = ws.config_from_env({})
+    assert (d.use_graph, d.depth_skip_top, d.blend_order, d.blend_split, d.bin_request, d.batch_threads, d.tile_qw, d.tile_qh,
+            d.depth_digit_bits, d.exp_depth_sort) == (0, 1, -1, -1, 1, -1, 4, 4, 0, 0)
 
 
 def test_no_gpu_means_loud_failure(ws):

@@ -116,12 +116,9 @@ int ws_render_views(ws_context* ctx, const ws_pointcloud* pc, const ws_scene* sc
     int rc = ws_renderer_create(ctx, WS_FORMAT_RGBA16_FLOAT, ws_pointcloud_sh_deg(pc), ws_pointcloud_compressed(pc), &r);
     if (rc) return rc;
     // bin/render.rs:154 draws into an Rgba16Float target: the fixed-function blender rounds the destination to f16 after
-    // every splat.  The target-precision blend mode reproduces that (WS_RENDER_VIEWS_BLEND=fast: the throughput blend,
+    // every splat.  The target-precision blend mode reproduces that (ws_context_config::render_views_fast_blend: the throughput blend,
     // one rounding at the store).
-    {
-        const char* bm = std::getenv("WS_RENDER_VIEWS_BLEND");
-        if (!(bm && std::strcmp(bm, "fast") == 0)) (void)ws_renderer_set_blend_mode(r, WS_BLEND_TARGET_PRECISION);
-    }
+    if (!ctx->render_views_fast_blend) (void)ws_renderer_set_blend_mode(r, WS_BLEND_TARGET_PRECISION);
     void* target = nullptr;
     size_t target_bytes = 0;
     std::vector<uint8_t> rgba;
@@ -261,7 +258,7 @@ constexpr uint32_t BATCH_THREADS_MAX_POINTS = 512u * 1024u;
 // frame where the GPU needs 140, so it runs ahead until the runtime's queues are full and then WAITS INSIDE THE HIP RUNTIME
 // for queue space -- spinning: the enqueue thread at 100 % of a core and a runtime helper thread beside it at 93 %
 // (profiles/r05/host_threads.txt; 1.9 cores per rank, 8 ranks on a 16-CPU quota).  Nothing is gained by being a thousand frames
-// ahead.  Every slot therefore keeps its host side at most `queue_depth` frames (default 5, WS_BATCH_QUEUE_DEPTH; 0 =
+// ahead.  Every slot therefore keeps its host side at most `queue_depth` frames (default 5, ws_context_config::batch_queue_depth; 0 =
 // unbounded; measured 2 / 3 / 5: -2 / -1.6 ... -3 / 0 ... -1 % frames/s against unbounded, profiles/r05/host_run_ahead_ab.txt)
 // ahead of the device: the compositing kernel of every frame posts the frame's number to pinned host memory when
 // it STARTS (ws_internal_renderer_progress: one store by one thread, no event, no extra packet), and before a slot's next
@@ -376,8 +373,7 @@ int ws_view_batch_create(ws_context* ctx, ws_color_format format, uint32_t sh_de
         b->streams.push_back(s);
     }
     if (rc == WS_OK) {
-        const char* qd = std::getenv("WS_BATCH_QUEUE_DEPTH");
-        if (qd) b->queue_depth = (uint32_t)std::max(0, std::atoi(qd));
+        if (ctx->batch_queue_depth >= 0) b->queue_depth = (uint32_t)ctx->batch_queue_depth;
         if (b->queue_depth > 64u) b->queue_depth = 64u;
         b->windows.resize(b->renderers.size());
         // several frames in flight: the slots' blends keep the image order of their workgroups (ws_api.cpp)

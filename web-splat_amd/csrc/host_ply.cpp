@@ -241,11 +241,10 @@ extern "C" void ws_ply_free(ws_ply_cloud* pc) {
 }
 
 // PlyReader::read + PointCloud::new.  The vertex rows go to the device as they sit in the file and are converted
-// there (ws_pointcloud_create_from_ply_rows -> k_ply_decode); WS_PLY_DECODE=host selects the host conversion
+// there (ws_pointcloud_create_from_ply_rows -> k_ply_decode); ws_context_config::ply_decode_host selects the host conversion
 // (ws_ply_read + ws_pointcloud_create) for comparison.
 static int load_ply_impl(ws_context* ctx, const char* path, ws_pointcloud** out) {
-    const char* mode = std::getenv("WS_PLY_DECODE");
-    if (mode && std::strcmp(mode, "host") == 0) {
+    if (ctx && ctx->ply_decode_host) {
         ws_ply_cloud* h = nullptr;
         int rc = ws_ply_read(path, &h);
         if (rc) return rc;

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_prefix(const uint32_t* __re
                                                            uint32_t* __restrict__ emit_start,
                                                            uint64_t* __restrict__ status,
                                                            FrameCounters* __restrict__ counters, uint32_t entry_cap) {
+    WS_SETPRIO_SMALL();
     constexpr int BIN_ITEMS = BIN_THREADS * BIN_IPT;
     __shared__ uint32_t s_tmp[BIN_THREADS / 64];
     __shared__ uint32_t s_bid;
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const emit::Source src
                                                          uint32_t* __restrict__ entry_vals,
                                                          uint32_t* __restrict__ tile_hist, uint32_t tile_hist_pitch,
                                                          uint32_t tile_hist_mask, int key16) {
+    WS_SETPRIO_SMALL();
     constexpr int HIST_WORDS = WIDE ? TILE_SORT_WIDE_MAX_BINS : RADIX * EMIT_COPIES;
     __shared__ uint32_t s_off[emit::OFF_WORDS];
     __shared__ uint32_t s_own[emit::OWN_WORDS];
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_blend_order(const uint2* __re
                                                                const FrameCounters* __restrict__ counters, uint32_t tiles_x,
                                                                uint32_t tiles_y, uint32_t bin_tiles_x, uint4* __restrict__ order,
                                                                uint32_t nblocks, int mode) {
+    WS_SETPRIO_SMALL();
     __shared__ uint32_t s_cnt[ORDER_CLASSES];
     __shared__ uint32_t s_wave[ORDER_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -439,7 +442,11 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_blend_order(const uint2* __re
 // itself, whether or not its caller ever polls ws_renderer_errors.
 // (the same thread, when the blend starts: "frame frame_seq of this renderer has reached its compositing pass")
 __device__ __forceinline__ void post_frame_progress(const BlendParams& p) {
-    if (p.progress_mailbox) __hip_atomic_store(p.progress_mailbox, p.frame_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p.progress_mailbox) {
+        __hip_atomic_store(p.progress_mailbox, p.frame_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t cls = p.counters->depth_span_class;  // (0: nothing to say -- the host keeps what it knew)
+        if (cls) __hip_atomic_store(p.progress_mailbox + 1, cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 __device__ __forceinline__ void fold_frame_errors(const BlendParams& p, uint32_t bits) {
     atomicOr(p.sticky, bits);

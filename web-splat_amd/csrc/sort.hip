@@ -86,6 +86,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tile_hist(const uint32_t*
                                                                 uint32_t tiles_cap, FrameCounters* __restrict__ fold,
                                                                 const uint32_t* __restrict__ skip,
                                                                 const uint32_t* __restrict__ key_base) {
+    WS_SETPRIO_SMALL();
     constexpr int TILE_N = SORT_THREADS * KPT;
     __shared__ uint32_t sh[RADIX * HIST_COPIES];
     __shared__ uint32_t s_rng[2][WAVES];
@@ -169,11 +170,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_col_scan(const uint32_t* 
                                                                uint32_t tile_n, uint32_t* __restrict__ tile_sums,
                                                                uint32_t tiles_cap, uint32_t* __restrict__ hist,
                                                                const uint32_t* __restrict__ skip, FrameCounters* __restrict__ fold) {
+    WS_SETPRIO_SMALL();
     __shared__ uint32_t s_tmp[WAVES];
     if (skip && *skip) return;
     // the depth sort's first column scan: the key range the histogram kernel in front of it left -> the base of passes 1..3 and
     // ONE flag for the kernels of the last pass and the sort's readers
-    if (fold && blockIdx.x == 0 && threadIdx.x == 0) depth_range_decide(fold);
+    if (fold && blockIdx.x == 0 && threadIdx.x == 0) depth_range_decide(fold, gridDim.x);  // (one workgroup per digit: the radix)
     const uint32_t count = device_count(d_count, n);
     const uint32_t ntiles = (count + tile_n - 1) / tile_n;
     uint32_t* row = tile_sums + (size_t)blockIdx.x * tiles_cap;
@@ -213,7 +215,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t* __restrict__ hist,     // [256] global digit histogram of this pass
     const uint32_t* __restrict__ tile_off, // [256][tiles_cap] exclusive offsets per digit
     uint32_t tiles_cap, uint2* __restrict__ ranges, uint32_t nranges, const uint32_t* __restrict__ skip,
-    const uint32_t* __restrict__ key_base) {  // key_base: digits come from (key - *key_base) (depth sort, passes 1..3)
+    const uint32_t* __restrict__ key_base) {
+  // key_base: digits come from (key - *key_base) (depth sort, passes 1..3)
+    WS_SETPRIO_SMALL();
     constexpr int TILE_N = SORT_THREADS * KPT;
     constexpr uint32_t DMASK = (1u << BITS) - 1u;
     __shared__ uint32_t s_wave_hist[WAVES][RADIX];
@@ -366,6 +370,239 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     }
 }
 
+// =====================================================================================================================
+// 9-bit digits for the depth sort (round 6; verdict r05 item 4).  key - base spans less than 2^27 on every frame of every
+// BASELINE workload, so THREE 9-bit passes sort it: nine launches and 76 B per key moved instead of twelve
+// and 100 on the frames the 8-bit form cannot shorten (half of hd1m's views, all of c5's).  A fourth pass over bits 27..31 is
+// enqueued for generality and leaves at once when the range says so (depth_range_decide).  512 digit rows against 256
+// threads: every thread owns the digit pair (2 tid, 2 tid + 1) wherever the 8-bit kernels have one digit per thread.  These
+// are separate kernels, not another instantiation of the ones above: the tile-id sort's instantiations stay instruction
+// for instruction what they were.
+// =====================================================================================================================
+constexpr int RADIX9 = 512;
+
+template <int KPT>
+__global__ __launch_bounds__(SORT_THREADS) void k_dsort9_tile_hist(const uint32_t* __restrict__ keys,
+                                                                  const uint32_t* __restrict__ d_count, uint32_t n, int shift,
+                                                                  uint32_t* __restrict__ tile_sums, uint32_t tiles_cap,
+                                                                  FrameCounters* __restrict__ fold,
+                                                                  const uint32_t* __restrict__ skip,
+                                                                  const uint32_t* __restrict__ key_base) {
+    WS_SETPRIO_SMALL();
+    constexpr int TILE_N = SORT_THREADS * KPT;
+    constexpr int COPIES = 4;  // (512 digits x 4 copies = 8 KB, as the 8-bit kernel's 256 x 8)
+    __shared__ uint32_t sh[RADIX9 * COPIES];
+    __shared__ uint32_t s_rng[2][WAVES];
+    if (skip && *skip) return;
+    const uint32_t kbase = key_base ? *key_base : 0u;
+    const uint32_t count = device_count(d_count, n);
+    const uint32_t copy = threadIdx.x & (COPIES - 1);
+    const uint32_t ntiles = (count + TILE_N - 1) / TILE_N;
+    for (uint32_t L = blockIdx.x; (L >> 3) < ((ntiles + 7u) >> 3); L += gridDim.x) {
+        uint32_t t;
+        if (!xcd_tile(L, ntiles, &t)) continue;  // block-uniform
+        for (int i = threadIdx.x; i < RADIX9 * COPIES; i += SORT_THREADS) sh[i] = 0u;
+        __syncthreads();
+        const uint32_t base = t * TILE_N;
+        uint32_t k[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
+            k[j] = keys[pos < count ? pos : count - 1u];
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
+            if (pos < count) atomicAdd(&sh[(((k[j] - kbase) >> shift) & (RADIX9 - 1)) * COPIES + copy], 1u);
+        }
+        if (fold) {  // the frame's key range, as k_sort_tile_hist leaves it (first pass only)
+            uint32_t knmin = 0u, kmax = 0u;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t pos = base + j * SORT_THREADS + threadIdx.x;
+                if (pos < count) {
+                    knmin = max(knmin, ~k[j]);
+                    kmax = max(kmax, k[j]);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                knmin = max(knmin, (uint32_t)__shfl_xor((int)knmin, o, 64));
+                kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+            }
+            if ((threadIdx.x & 63) == 0) {
+                s_rng[0][threadIdx.x >> 6] = knmin;
+                s_rng[1][threadIdx.x >> 6] = kmax;
+            }
+        }
+        __syncthreads();
+        if (fold && threadIdx.x == 0) {
+            uint32_t knmin = 0u, kmax = 0u;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                knmin = max(knmin, s_rng[0][w]);
+                kmax = max(kmax, s_rng[1][w]);
+            }
+            if (knmin) {
+                uint32_t* ts = fold->tile_sums + (t & (TILE_SUM_SLOTS - 1)) * TILE_SUM_STRIDE;
+                atomicMax(ts + 2, knmin);
+                atomicMax(ts + 3, kmax);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t d = threadIdx.x + h * SORT_THREADS;
+            uint32_t c = 0;
+#pragma unroll
+            for (int r = 0; r < COPIES; ++r) c += sh[d * COPIES + r];
+            tile_sums[(size_t)d * tiles_cap + t] = c;
+        }
+        __syncthreads();
+    }
+}
+
+// One 9-bit pass of the depth sort: (key, value, companion) triples, digits from key - *key_base (nullptr: from the key).
+template <int KPT>
+__global__ __launch_bounds__(SORT_THREADS) void k_dsort9_scatter(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out,
+    const uint32_t* __restrict__ d_count, uint32_t n, int shift, int iota, const uint32_t* __restrict__ hist,
+    const uint32_t* __restrict__ tile_off, uint32_t tiles_cap, const uint32_t* __restrict__ skip,
+    const uint32_t* __restrict__ key_base) {
+    WS_SETPRIO_SMALL();
+    constexpr int TILE_N = SORT_THREADS * KPT;
+    constexpr int BITS = 9;
+    constexpr uint32_t DMASK = RADIX9 - 1;
+    __shared__ __attribute__((aligned(8))) uint32_t s_wave_hist[WAVES][RADIX9];
+    __shared__ __attribute__((aligned(8))) uint32_t s_local_excl[RADIX9];
+    __shared__ __attribute__((aligned(8))) uint32_t s_global_base[RADIX9];
+    __shared__ uint32_t s_keys[TILE_N];
+    __shared__ uint32_t s_vals[TILE_N];
+    __shared__ uint32_t s_aux[TILE_N];
+    __shared__ uint32_t s_tmp[WAVES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    if (skip && *skip) return;  // (block-uniform) a pass over a constant digit moves nothing
+    const uint32_t kbase = key_base ? *key_base : 0u;
+    const uint32_t count = device_count(d_count, n);
+    // first output position of the digit pair (2 tid, 2 tid + 1): the same for all tiles of this pass
+    const uint2 hh = reinterpret_cast<const uint2*>(hist)[tid];
+    const uint32_t digit_base0 = block_exclusive_scan(hh.x + hh.y, s_tmp, nullptr);
+    const uint32_t digit_base1 = digit_base0 + hh.x;
+    const bool has_aux = aux_in != nullptr;  // (kernel-uniform; the standalone sorter may carry no companion)
+    const uint32_t ntiles = (count + TILE_N - 1) / TILE_N;
+    for (uint32_t L = blockIdx.x; (L >> 3) < ((ntiles + 7u) >> 3); L += gridDim.x) {
+    uint32_t t;
+    if (!xcd_tile(L, ntiles, &t)) continue;  // block-uniform
+    const uint32_t tile_base = t * TILE_N;
+    const uint32_t valid = (count - tile_base) < (uint32_t)TILE_N ? (count - tile_base) : (uint32_t)TILE_N;
+
+    uint32_t key[KPT];
+    uint32_t val[KPT];
+    const uint32_t wave_base = tile_base + wave * (64 * KPT) + lane;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const uint32_t pos = wave_base + j * 64;
+        key[j] = pos < count ? keys_in[pos] : 0xFFFFFFFFu;
+    }
+    auto digit_of = [&](uint32_t k) -> uint32_t { return ((k == 0xFFFFFFFFu ? k : k - kbase) >> shift) & DMASK; };
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const uint32_t pos = wave_base + j * 64;
+        val[j] = iota ? pos : (pos < count ? vals_in[pos] : 0u);
+    }
+    uint32_t aux[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const uint32_t pos = wave_base + j * 64;
+        aux[j] = (has_aux && pos < count) ? aux_in[pos] : 0u;
+    }
+    // issued early: needed only after the ranking
+    const uint32_t my_tile_off0 = tile_off[(size_t)(2 * tid) * tiles_cap + t];
+    const uint32_t my_tile_off1 = tile_off[(size_t)(2 * tid + 1) * tiles_cap + t];
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) reinterpret_cast<uint2*>(s_wave_hist[w])[tid] = make_uint2(0u, 0u);
+    __syncthreads();
+
+    // ---- rank inside the wave: nine ballots per key (see k_sort_scatter) ---------------------------------------------------
+    uint32_t info[KPT];
+    const uint32_t lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xFFFFFFFFu;
+    const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const uint32_t d = digit_of(key[j]);
+        uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
+#pragma unroll
+        for (int bit = 0; bit < BITS; ++bit) {
+            const uint32_t B = (uint32_t)(-(int32_t)((d >> bit) & 1u));
+            const unsigned long long bal = __ballot(B != 0u);
+            mlo &= ~((uint32_t)bal ^ B);
+            mhi &= ~((uint32_t)(bal >> 32) ^ B);
+        }
+        const uint32_t below = (uint32_t)__popc(mlo & lt_lo) + (uint32_t)__popc(mhi & lt_hi);
+        const uint32_t leader = mlo ? (uint32_t)(__ffs((int)mlo) - 1) : 32u + (uint32_t)(__ffs((int)mhi) - 1);
+        const uint32_t cnt = (below == 0u) ? (uint32_t)(__popc(mlo) + __popc(mhi)) : 0u;
+        info[j] = below | (leader << 8) | (cnt << 16);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    uint32_t prev[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const uint32_t d = digit_of(key[j]);
+        prev[j] = 0u;
+        if (info[j] >> 16) prev[j] = atomicAdd(&s_wave_hist[wave][d], info[j] >> 16);
+    }
+    uint32_t rank[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) rank[j] = __shfl(prev[j], (int)((info[j] >> 8) & 63u), 64) + (info[j] & 63u);
+    __syncthreads();
+
+    // ---- per digit pair: prefix over waves, tile counts --------------------------------------------------------------------
+    uint32_t cnt0 = 0u, cnt1 = 0u;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        uint2* wp = reinterpret_cast<uint2*>(s_wave_hist[w]) + tid;
+        const uint2 c = *wp;
+        *wp = make_uint2(cnt0, cnt1);
+        cnt0 += c.x;
+        cnt1 += c.y;
+    }
+    {
+        const uint32_t local_excl = block_exclusive_scan(cnt0 + cnt1, s_tmp, nullptr);
+        reinterpret_cast<uint2*>(s_local_excl)[tid] = make_uint2(local_excl, local_excl + cnt0);
+        reinterpret_cast<uint2*>(s_global_base)[tid] =
+            make_uint2(digit_base0 + my_tile_off0 - local_excl, digit_base1 + my_tile_off1 - (local_excl + cnt0));
+    }
+    __syncthreads();
+
+    // ---- reorder through LDS, write contiguous digit runs ------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const uint32_t d = digit_of(key[j]);
+        const uint32_t lpos = s_local_excl[d] + s_wave_hist[wave][d] + rank[j];
+        s_keys[lpos] = key[j];
+        s_vals[lpos] = val[j];
+        s_aux[lpos] = aux[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const uint32_t lp = k * SORT_THREADS + tid;
+        const uint32_t kk = s_keys[lp];
+        const uint32_t vv = s_vals[lp];
+        const uint32_t gpos = s_global_base[digit_of(kk)] + lp;
+        if (lp < valid) {
+            vals_out[gpos] = vv;
+            if (has_aux) aux_out[gpos] = s_aux[lp];
+            keys_out[gpos] = kk;
+        }
+    }
+    __syncthreads();  // LDS is reused by the next tile
+    }
+}
+
 template <int KPT, int BITS, bool KEY16>
 int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t* ain,
                     uint32_t* aout,
@@ -387,27 +624,40 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
             if (fk_skipped) *fk_skipped = kin;
             if (fv_skipped) *fv_skipped = vin;
         }
+        uint32_t* const hist_p = sc.hist + (size_t)p * sc.hist_pitch;
+        if constexpr (BITS == 9) {  // the depth sort's 9-bit form: its own kernels (above)
+            hipLaunchKernelGGL((k_dsort9_tile_hist<KPT>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift, sc.tile_sums,
+                               sc.tiles_cap, fold, skip, kbase);
+            km_mark(km, names[0]);
+            hipLaunchKernelGGL(k_sort_col_scan, dim3(RADIX9), dim3(SORT_THREADS), 0, stream, d_count, n, TILE_N, sc.tile_sums, sc.tiles_cap,
+                               hist_p, skip, fold);
+            km_mark(km, names[1]);
+            hipLaunchKernelGGL((k_dsort9_scatter<KPT>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout, ain, aout, d_count,
+                               n, shift, iota, hist_p, sc.tile_sums, sc.tiles_cap, skip, kbase);
+            km_mark(km, names[2]);
+        } else {
         if (!(p == 0 && first_tile_hist_ready)) {
             hipLaunchKernelGGL((k_sort_tile_hist<KPT, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, d_count, n, shift,
                                (1u << BITS) - 1u, sc.tile_sums, sc.tiles_cap, fold, skip, kbase);
             km_mark(km, names[0]);
         }
         hipLaunchKernelGGL(k_sort_col_scan, dim3(1u << BITS), dim3(SORT_THREADS), 0, stream, d_count, n, TILE_N,
-                           sc.tile_sums, sc.tiles_cap, sc.hist + p * RADIX, skip, fold);
+                           sc.tile_sums, sc.tiles_cap, hist_p, skip, fold);
         km_mark(km, names[1]);
         if (ranges && p == npass - 1)
             hipLaunchKernelGGL((k_sort_scatter<KPT, true, BITS, false, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota,
-                               sc.hist + p * RADIX, sc.tile_sums, sc.tiles_cap, ranges, nranges, skip, kbase);
+                               hist_p, sc.tile_sums, sc.tiles_cap, ranges, nranges, skip, kbase);
         else if (ain)
             hipLaunchKernelGGL((k_sort_scatter<KPT, false, BITS, true>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin,
-                               vin, kout, vout, ain, aout, d_count, n, shift, iota, sc.hist + p * RADIX, sc.tile_sums,
+                               vin, kout, vout, ain, aout, d_count, n, shift, iota, hist_p, sc.tile_sums,
                                sc.tiles_cap, (uint2*)nullptr, 0u, skip, kbase);
         else
             hipLaunchKernelGGL((k_sort_scatter<KPT, false, BITS, false, KEY16>), dim3(tiles), dim3(SORT_THREADS), 0, stream, kin, vin,
                                kout, vout, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, n, shift, iota,
-                               sc.hist + p * RADIX, sc.tile_sums, sc.tiles_cap, (uint2*)nullptr, 0u, skip, kbase);
+                               hist_p, sc.tile_sums, sc.tiles_cap, (uint2*)nullptr, 0u, skip, kbase);
         km_mark(km, names[2]);
+        }
         WS_HIP(hipGetLastError());
         uint32_t* tk = kin;
         kin = kout;
@@ -459,7 +709,7 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, hipStream_t stream,
                       uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km, const char* tag, uint2* ranges,
                       uint32_t nranges, int digit_bits, bool key16, uint32_t* aux, uint32_t* aux_alt, FrameCounters* skip_top,
-                      uint32_t** out_keys_skipped, uint32_t** out_vals_skipped) {
+                      uint32_t** out_keys_skipped, uint32_t** out_vals_skipped, int kpt9) {
     // labels of the per-kernel timers: "<tag>k_sort_..." with tag = "depth:" / "tiles:"
     const bool depth = tag && tag[0] == 'd';
     static const char* const N_DEPTH[3] = {"depth:k_sort_tile_hist", "depth:k_sort_col_scan", "depth:k_sort_scatter"};
@@ -472,13 +722,15 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
     if (aux && (ranges || !aux_alt)) return fail(WS_ERR_INVALID, "sort: companion values need a scratch partner and no range recording");
     if (key16 && end_bit > 16) return fail(WS_ERR_INVALID, "sort: 16-bit keys with more than 16 key bits");
     if (key16 && aux) return fail(WS_ERR_INVALID, "sort: companion values travel with 32-bit keys only");
-    if (digit_bits < 6 || digit_bits > RADIX_BITS) return fail(WS_ERR_INVALID, "sort: digit width must be 6, 7 or 8 bits");
+    if (digit_bits < 6 || digit_bits > 9) return fail(WS_ERR_INVALID, "sort: digit width must be 6, 7, 8 or (depth sort) 9 bits");
+    if (digit_bits == 9 && (key16 || ranges || first_tile_hist_ready || sc.rows < 512u || sc.hist_pitch < 512u))
+        return fail(WS_ERR_INVALID, "sort: 9-bit digits belong to the depth sort (32-bit keys, a scratch with 512 count rows)");
     if (begin_bit < 0 || end_bit > 32 || begin_bit >= end_bit)
         return fail(WS_ERR_INVALID, "sort: bit range must be non-empty and within [0,32]");
     if ((reinterpret_cast<uintptr_t>(keys) & 15u) != 0) return fail(WS_ERR_INVALID, "sort: keys must be 16-byte aligned");
     const int npass = (end_bit - begin_bit + digit_bits - 1) / digit_bits;
     if (npass > 4) return fail(WS_ERR_INVALID, "sort: more than four digit passes");
-    if (skip_top && (npass != 4 || begin_bit != 0 || digit_bits != RADIX_BITS || first_tile_hist_ready || ranges))
+    if (skip_top && (npass != 4 || begin_bit != 0 || (digit_bits != RADIX_BITS && digit_bits != 9) || first_tile_hist_ready || ranges))
         return fail(WS_ERR_INVALID, "sort: the top-byte skip belongs to the four-pass depth sort");
 
     uint32_t* kin = keys;
@@ -494,7 +746,15 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                : run_passes_scan<KPT_, BITS_, false>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass,  \
                                                      implicit_iota, first_tile_hist_ready, stream, &kin, &vin, km, names,  \
                                                      ranges, nranges, skip_top, out_keys_skipped, out_vals_skipped)
-    if (digit_bits == 8) {
+    if (digit_bits == 9) {  // (never key16: checked above)
+        const bool big9 = kpt9 ? kpt9 >= SORT_KPT : big;
+        if (big9) rc = run_passes_scan<SORT_KPT, 9, false>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass, implicit_iota,
+                                                          false, stream, &kin, &vin, km, names, nullptr, 0u, skip_top, out_keys_skipped,
+                                                          out_vals_skipped);
+        else rc = run_passes_scan<SORT_KPT_SMALL, 9, false>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass,
+                                                            implicit_iota, false, stream, &kin, &vin, km, names, nullptr, 0u, skip_top,
+                                                            out_keys_skipped, out_vals_skipped);
+    } else if (digit_bits == 8) {
         if (big) WS_RUN_SCAN(SORT_KPT, 8); else WS_RUN_SCAN(SORT_KPT_SMALL, 8);
     } else if (digit_bits == 7) {
         if (big) WS_RUN_SCAN(SORT_KPT, 7); else WS_RUN_SCAN(SORT_KPT_SMALL, 7);

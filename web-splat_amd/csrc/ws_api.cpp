@@ -27,10 +27,6 @@ int hip_fail(hipError_t e, const char* what) {
     return e == hipErrorOutOfMemory ? WS_ERR_OOM : WS_ERR_HIP;
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* v = std::getenv(name);
-    return (v && *v) ? std::atoi(v) : dflt;
-}
 
 template <typename T>
 static int dmalloc(T** p, size_t count) {
@@ -95,7 +91,7 @@ struct SorterZero {
     uint32_t tickets[4];
     uint32_t error;
     uint32_t _pad[3];
-    uint32_t hist[4 * RADIX];
+    uint32_t hist[4 * 512];                                  // (rows of 512: 9-bit digits; 8-bit digits use the first 256)
     uint32_t fat_barrier[9 * 16];                            // single-launch depth sort: barrier state
 };
 
@@ -142,7 +138,8 @@ struct ws_renderer {
                                      // of all frames since the last reset, [1] the largest entries_needed of an overflowed frame
     uint32_t needed_seen = 0;        // host copy of [1]: the automatic entry capacity grows to it at the next prepare()
     uint32_t* demand_mailbox = nullptr;      // TWO pinned host words the blend posts to (device-visible address: demand_mailbox_dev):
-    uint32_t* demand_mailbox_dev = nullptr;  //   [0] the demand [1] above -- prepare() reads it without a sync, so the capacity grows
+    uint32_t* demand_mailbox_dev = nullptr;  //   ([2]: depth_span_class of the last frame whose blend has started -> the next frame's digit width)
+                                             //   [0] the demand [1] above -- prepare() reads it without a sync, so the capacity grows
                                              //   without anyone polling; [1] the number of the last frame whose blend has started
     uint32_t frames_enqueued = 0;            // render() calls so far (the sequence number the blend posts)
     bool throughput_mode = false;            // this renderer runs beside others (a slot of a view batch with frames in flight):
@@ -166,6 +163,8 @@ struct ws_renderer {
         bool valid = false;
         uint32_t *sorted_idx = nullptr, *sorted_keys = nullptr, *fp_sorted = nullptr, *entries_sorted = nullptr;
         uint32_t *sorted_idx_skipped = nullptr, *sorted_keys_skipped = nullptr;
+        int order_mode = 0;              // decide_blend_order() of the captured frame: a change re-captures
+        bool blend_order_valid = false;  // the captured frame contains k_blend_order
     } fg;
     uint64_t scratch_generation = 0;
 
@@ -187,6 +186,9 @@ struct ws_renderer {
     uint32_t* debug_walked = nullptr;    // [tiles][17], capture mode only
     uint4* blend_order = nullptr;        // [blend_order_blocks]: the blend's tiles, longest list first (k_blend_order)
     bool blend_order_valid = false;      // the last prepared frame wrote it
+    int order_mode_this_frame = 0;       // decide_blend_order() of the prepare() in progress
+    int depth_bits_this_frame = 8;       // digit width the last enqueued depth sort used (8 | 9)
+    int graph_depth_bits = 0;            // != 0 while a frame graph is captured / valid: its depth sort's digit width
     bool blend_timing = false;           // ws_renderer_enable_blend_timing: render() launches the time-stamped blend
     uint32_t* debug_timing = nullptr;    // [tiles][16][BLEND_TIMING_WORDS], allocated on first use
     uint32_t debug_timing_tiles = 0;
@@ -208,8 +210,12 @@ static void free_sort_scratch(SortScratch& sc, bool own_alt) {
 }
 
 // wide_bins != 0: also room for the [tiles][wide_bins] count rows of the single-pass tile-id sort (launch_tile_sort_wide)
-static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, uint32_t wide_bins = 0) {
+// digit width of the depth sort: ws_context_config::depth_digit_bits, 0 = the default
+static int depth_digit_bits(const ws_context* c) { return c->depth_digit_bits == 9 ? 9 : (c->depth_digit_bits == 8 ? 8 : WS_DEPTH_DIGIT_BITS_DEFAULT); }
+
+static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, uint32_t wide_bins = 0, uint32_t rows = RADIX) {
     sc.cap = cap;
+    sc.rows = rows;
     sc.tiles = (cap + SORT_TILE - 1) / SORT_TILE;
     if (sc.tiles == 0) sc.tiles = 1;
     int rc;
@@ -220,7 +226,7 @@ static int alloc_sort_scratch(SortScratch& sc, uint32_t cap, bool own_alt, uint3
     const uint32_t small_n = std::min<uint32_t>(cap, SORT_SMALL_MAX);
     const uint32_t small_tiles = (small_n + SORT_THREADS * SORT_KPT_SMALL - 1) / (SORT_THREADS * SORT_KPT_SMALL);
     sc.tiles_cap = std::max<uint32_t>(std::max<uint32_t>(small_tiles, sc.tiles), 1u);
-    size_t sum_words = (size_t)sc.tiles_cap * RADIX;
+    size_t sum_words = (size_t)sc.tiles_cap * rows;
     // (4 B x tiles x bins: 8 KiB per 2048 entries of capacity at 2048 bins, 1.3 x the entry lists themselves; beyond 1 GiB
     // -- 250 M entries -- the tile sort stays with its digit passes)
     if (wide_bins && (size_t)sc.tiles * wide_bins * sizeof(uint32_t) <= ((size_t)1 << 30)) {
@@ -240,6 +246,7 @@ static void renderer_free_graph(ws_renderer* r) {
     }
     if (g.graph) (void)hipGraphDestroy(g.graph);
     g = ws_renderer::FrameGraph();
+    r->graph_depth_bits = 0;
 }
 
 static void renderer_free_scratch(ws_renderer* r) {
@@ -346,10 +353,11 @@ static int renderer_ensure_scratch(ws_renderer* r, uint32_t n, uint32_t vw, uint
     WS_HIP(hipMemset(r->zero, 0, r->zero_bytes));
     r->counters = &r->zero->counters;
     r->tile_ranges = reinterpret_cast<uint2*>(reinterpret_cast<char*>(r->zero) + sizeof(FrameZero));
-    if ((rc = alloc_sort_scratch(r->sort_depth, n ? n : 1, false))) return rc;
+    if ((rc = alloc_sort_scratch(r->sort_depth, n ? n : 1, false, 0, 512))) return rc;  // (512 count rows: 9-bit digits)
     r->sort_depth.keys_alt = r->keys_b;
     r->sort_depth.vals_alt = r->vals_b;
     r->sort_depth.hist = r->zero->depth_hist;
+    r->sort_depth.hist_pitch = 512;
     // WS_TILE_SORT=wide: the tile-id sort is ONE counting pass when the viewport has at most 2048 binning tiles
     uint32_t wide_bins = 0;
     {
@@ -393,11 +401,49 @@ extern "C" {
 
 const char* ws_last_error(void) { return g_last_error.c_str(); }
 uint32_t ws_abi_version(void) { return WS_ABI_VERSION; }
+uint32_t ws_build_flags(void) {
+#ifdef WS_EXPERIMENTAL
+    return WS_BUILD_EXPERIMENTAL;
+#else
+    return 0u;
+#endif
+}
 
 // ---- context ---------------------------------------------------------------------------------------
+void ws_context_config_init(ws_context_config* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof *c);
+    c->struct_size = (uint32_t)sizeof *c;
+    c->depth_skip_top = 1;
+    c->blend_order = -1;
+    c->blend_split = -1;
+    c->bin_request = BIN_AUTO;
+    c->batch_threads = -1;
+    c->batch_queue_depth = -1;
+    c->blend_tpw_log2 = -1;
+    c->tile_qw = c->tile_qh = 4;
+    c->exp_batch_k1 = 1;
+}
+
 int ws_context_create(int hip_device, ws_context** out) {
+    ws_context_config c;
+    ws_context_config_init(&c);
+    return ws_context_create_with_config(hip_device, &c, out);
+}
+
+// The library reads NO environment variable (round 6; verdict r05 "a drop-in library steered by the environment of whoever loads
+// it"): every switch arrives in the config.  bench.py / the tests / the tools translate their WS_* environment outside.
+int ws_context_create_with_config(int hip_device, const ws_context_config* cfg_in, ws_context** out) {
     if (!out) return fail(WS_ERR_INVALID, "ws_context_create: out is null");
     *out = nullptr;
+    ws_context_config cfg;
+    ws_context_config_init(&cfg);
+    if (cfg_in) {  // a caller built against an older (shorter) struct: its fields, our defaults for the rest
+        if (cfg_in->struct_size < 8u || cfg_in->struct_size > 4096u)
+            return fail(WS_ERR_INVALID, "ws_context_create_with_config: struct_size is not set (ws_context_config_init)");
+        std::memcpy(&cfg, cfg_in, cfg_in->struct_size < sizeof cfg ? cfg_in->struct_size : sizeof cfg);
+        cfg.struct_size = (uint32_t)sizeof cfg;
+    }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) {
@@ -405,6 +451,12 @@ int ws_context_create(int hip_device, ws_context** out) {
         return fail(WS_ERR_HIP, "ws_context_create: no HIP device available (this library has no CPU fallback)");
     }
     if (hip_device < 0 || hip_device >= count) return fail(WS_ERR_INVALID, "ws_context_create: bad device index");
+    if (!((cfg.tile_qw == 2 && cfg.tile_qh == 2) || (cfg.tile_qw == 4 && cfg.tile_qh == 2) || (cfg.tile_qw == 4 && cfg.tile_qh == 4)))
+        return fail(WS_ERR_INVALID, "ws_context_config: tile_qw x tile_qh must be 2x2, 4x2 or 4x4");
+    if (cfg.bin_request < (int)BIN_NEVER || cfg.bin_request > (int)BIN_ALWAYS)
+        return fail(WS_ERR_INVALID, "ws_context_config: bin_request must be 0 (never), 1 (per frame on the device) or 2 (always)");
+    if (cfg.depth_digit_bits != 0 && cfg.depth_digit_bits != 8 && cfg.depth_digit_bits != 9)
+        return fail(WS_ERR_INVALID, "ws_context_config: depth_digit_bits must be 0 (default), 8 or 9");
     WS_HIP(hipSetDevice(hip_device));
     ws_context* ctx = new (std::nothrow) ws_context();
     if (!ctx) return fail(WS_ERR_OOM, "ws_context_create: host allocation failed");
@@ -415,70 +467,45 @@ int ws_context_create(int hip_device, ws_context** out) {
     // lib_exp/libwebsplat_hip.so, -DWS_EXPERIMENTAL), which the variant tests load; the product library refuses their switches
     // loudly instead of carrying their kernels ------------------------------------------------------------------------
 #ifdef WS_EXPERIMENTAL
-    {   // WS_TILE_SORT=wide: ONE counting pass over the whole tile id up to 2048 binning tiles instead of two digit passes.
-        // Measured (profiles/r03/tile_sort_wide_ab_v20_summary.txt): one frame at a time +1..+5 % (three launches fewer), with
-        // frames in flight -0.5..-5 %: at 2048 bins the [sort tile][bin] count rows are as many bytes as the entries themselves.
-        const char* ts = std::getenv("WS_TILE_SORT");
-        ctx->tile_sort_wide = ts && std::strcmp(ts, "wide") == 0;
-    }
-    if (const char* ds = std::getenv("WS_DEPTH_SORT")) {
-        if (std::strcmp(ds, "onesweep") == 0) ctx->depth_sort_mode = DS_ONESWEEP;
-        else if (std::strcmp(ds, "coop") == 0) ctx->depth_sort_mode = DS_COOP;
-        else if (std::strcmp(ds, "scan") == 0 || std::strcmp(ds, "classic") == 0) ctx->depth_sort_mode = DS_SCAN;
-    }
-    ctx->dsort_fat_grid = env_int("WS_DSORT_FAT_GRID", 0);
-    ctx->blend_variant = env_int("WS_BLEND_VARIANT", 0);
-    ctx->blend_dma = env_int("WS_BLEND_DMA", 0) ? 1 : 0;
-    ctx->batch_k1 = env_int("WS_BATCH_K1", 1);
+    ctx->tile_sort_wide = cfg.exp_tile_sort_wide != 0;
+    if (cfg.exp_depth_sort == 1) ctx->depth_sort_mode = DS_ONESWEEP;
+    else if (cfg.exp_depth_sort == 2) ctx->depth_sort_mode = DS_COOP;
+    ctx->dsort_fat_grid = cfg.exp_dsort_fat_grid;
+    ctx->blend_variant = cfg.exp_blend_variant;
+    ctx->blend_dma = cfg.exp_blend_dma ? 1 : 0;
+    ctx->batch_k1 = cfg.exp_batch_k1;
     if (ctx->batch_k1 < 1 || ctx->batch_k1 > K1_MAX_VIEWS) ctx->batch_k1 = 1;
-    {
-        const char* fm = std::getenv("WS_FOOTPRINT");  // ellipse | rect (default)
-        ctx->footprint = (fm && std::strcmp(fm, "ellipse") == 0) ? FP_ELLIPSE : FP_RECT_PACKED;
-    }
+    ctx->footprint = cfg.exp_footprint_ellipse ? FP_ELLIPSE : FP_RECT_PACKED;
 #else
-    {
-        auto asked = [](const char* name, const char* off) {
-            const char* v = std::getenv(name);
-            return v && *v && std::strcmp(v, off) != 0;
-        };
-        const char* ds = std::getenv("WS_DEPTH_SORT");
-        const bool sort_variant = ds && *ds && std::strcmp(ds, "scan") != 0 && std::strcmp(ds, "classic") != 0;
-        const char* fm = std::getenv("WS_FOOTPRINT");
-        const char* ts = std::getenv("WS_TILE_SORT");
-        if (sort_variant || asked("WS_BLEND_VARIANT", "0") || asked("WS_BLEND_DMA", "0") || asked("WS_BATCH_K1", "1") ||
-            (fm && std::strcmp(fm, "ellipse") == 0) || (ts && std::strcmp(ts, "wide") == 0)) {
-            delete ctx;
-            return fail(WS_ERR_UNSUPPORTED, "ws_context_create: WS_DEPTH_SORT=onesweep|coop, WS_BLEND_VARIANT, WS_BLEND_DMA, WS_BATCH_K1, "
-                                            "WS_FOOTPRINT=ellipse and WS_TILE_SORT=wide select measured-and-lost variants that are only in "
-                                            "the experimental build (make -C web-splat_amd experimental; WEBSPLAT_LIB=.../lib_exp/libwebsplat_hip.so)");
-        }
+    if (cfg.exp_depth_sort || cfg.exp_blend_variant || cfg.exp_blend_dma || cfg.exp_batch_k1 != 1 || cfg.exp_footprint_ellipse ||
+        cfg.exp_tile_sort_wide) {
+        delete ctx;
+        return fail(WS_ERR_UNSUPPORTED, "ws_context_create: exp_depth_sort, exp_blend_variant, exp_blend_dma, "
+                                        "exp_batch_k1, exp_footprint_ellipse and exp_tile_sort_wide select measured-and-lost variants that are only in "
+                                        "the experimental build (make -C web-splat_amd experimental; WEBSPLAT_LIB=.../lib_exp/libwebsplat_hip.so)");
     }
 #endif
-    ctx->debug_cut = env_int("WS_DEBUG_CUT", 0);  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
-    ctx->blend_tpw_log2 = env_int("WS_BLEND_TPW_LOG2", -1);
-    if (ctx->blend_tpw_log2 > 4) ctx->blend_tpw_log2 = 4;
-    ctx->use_graph = env_int("WS_GRAPH", 0);
-    ctx->depth_skip_top = env_int("WS_DEPTH_SKIP_TOP", 1);  // 0: the depth sort always runs its four passes (A/B)
+    ctx->debug_cut = cfg.debug_cut;  // analysis only: stop the frame after stage n (1 = K1 ... 4 = tile sort)
+    ctx->blend_tpw_log2 = cfg.blend_tpw_log2 > 4 ? 4 : cfg.blend_tpw_log2;
+    ctx->use_graph = cfg.use_graph;
+    ctx->depth_skip_top = cfg.depth_skip_top;  // 0: the depth sort always runs all of its passes (A/B)
     // the blend's workgroups: -1 (default) longest list first for a renderer that draws one frame at a time, image order for
     // the slots of a view batch with frames in flight (ws_renderer_render); 0 / 1 force image order / longest first;
     // 2 (shortest first) and 3 (alternating) are the measured experiments of DESIGN 3.3
-    ctx->blend_order = env_int("WS_BLEND_ORDER", -1);
-    ctx->blend_split = env_int("WS_BLEND_SPLIT", -1);  // -1 = automatic (ws_renderer_render)
-    {
-        const char* bs = std::getenv("WS_BIN_SHIFT");  // 0 | 1 | auto (default): binning at twice the blend's tile size
-        ctx->bin_request = !bs ? BIN_AUTO : (std::strcmp(bs, "1") == 0 ? BIN_ALWAYS : (std::strcmp(bs, "0") == 0 ? BIN_NEVER : BIN_AUTO));
-    }
-    ctx->batch_threads = env_int("WS_BATCH_THREADS", -1);
+    ctx->blend_order = cfg.blend_order;
+    ctx->blend_split = cfg.blend_split;  // -1 = automatic (ws_renderer_render)
+    ctx->bin_request = cfg.bin_request;  // binning at twice the blend's tile size: never | per frame on the device | always
+    ctx->batch_threads = cfg.batch_threads;
+    ctx->batch_queue_depth = cfg.batch_queue_depth;
     ctx->num_cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
-    ctx->blend_lds_pad_kb = env_int("WS_BLEND_LDS_PAD_KB", 0);
-    if (ctx->blend_lds_pad_kb < 0 || ctx->blend_lds_pad_kb > 96) ctx->blend_lds_pad_kb = 0;
-    if (const char* shape = std::getenv("WS_TILE_SHAPE")) {  // tuning / A-B: quadrants per tile
-        const std::string v(shape);
-        if (v == "2x2") { ctx->tile_qw = 2; ctx->tile_qh = 2; }
-        else if (v == "4x2") { ctx->tile_qw = 4; ctx->tile_qh = 2; }
-        else if (v == "4x4") { ctx->tile_qw = 4; ctx->tile_qh = 4; }
-        else { delete ctx; return fail(WS_ERR_INVALID, "WS_TILE_SHAPE must be 2x2, 4x2 or 4x4"); }
-    }
+    ctx->blend_lds_pad_kb = (cfg.blend_lds_pad_kb < 0 || cfg.blend_lds_pad_kb > 96) ? 0 : cfg.blend_lds_pad_kb;
+    ctx->tile_qw = (uint32_t)cfg.tile_qw;
+    ctx->tile_qh = (uint32_t)cfg.tile_qh;
+    ctx->capture = cfg.capture != 0;
+    ctx->render_views_fast_blend = cfg.render_views_fast_blend != 0;
+    ctx->ply_decode_host = cfg.ply_decode_host != 0;
+    ctx->depth_digit_bits = cfg.depth_digit_bits;
+    ctx->depth_tile_kpt = (cfg.depth_tile_kpt == 4 || cfg.depth_tile_kpt == 8) ? cfg.depth_tile_kpt : 0;
     *out = ctx;
     return WS_OK;
 }
@@ -824,7 +851,7 @@ int ws_renderer_create(ws_context* ctx, ws_color_format format, uint32_t sh_deg,
     r->format = format;
     r->sh_deg = sh_deg;
     r->compressed = compressed != 0;
-    r->capture = env_int("WS_CAPTURE", 0) != 0;
+    r->capture = ctx->capture;
     for (auto& e : r->ev) {
         if (hipEventCreate(&e) != hipSuccess) {
             ws_renderer_destroy(r);
@@ -837,8 +864,8 @@ int ws_renderer_create(ws_context* ctx, ws_color_format format, uint32_t sh_deg,
         return fail(WS_ERR_HIP, "ws_renderer_create: error word allocation failed");
     }
     // the demand mailbox (optional: without pinned memory the capacity still grows through ws_renderer_errors)
-    if (hipHostMalloc(reinterpret_cast<void**>(&r->demand_mailbox), 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
-        r->demand_mailbox[0] = r->demand_mailbox[1] = 0u;
+    if (hipHostMalloc(reinterpret_cast<void**>(&r->demand_mailbox), 4 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+        r->demand_mailbox[0] = r->demand_mailbox[1] = r->demand_mailbox[2] = r->demand_mailbox[3] = 0u;
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&r->demand_mailbox_dev), r->demand_mailbox, 0) != hipSuccess) {
             (void)hipHostFree(r->demand_mailbox);
             r->demand_mailbox = r->demand_mailbox_dev = nullptr;
@@ -939,6 +966,23 @@ int ws_renderer_set_tile_entry_capacity(ws_renderer* r, uint64_t entries) {
 // phase: FRAME_ALL = the whole sequence; FRAME_CLEAR = the arena memset only, FRAME_REST = everything behind K1 (a view
 // batch runs K1 for several renderers in ONE launch between the two: ws_internal_prepare_group).
 enum FramePhase { FRAME_ALL = 0, FRAME_CLEAR = 1, FRAME_REST = 2 };
+// The order of the blend's workgroups for the frame about to be enqueued: 0 = image order, 1 = longest list first (k_blend_order),
+// 2 / 3 the measured experiments.  Decided ONCE per prepare() and outside any stream capture (a frame graph captured
+// under one decision and replayed under another composited with a stale order table): the graph path re-captures when the
+// decision changes.
+static int decide_blend_order(ws_renderer* r, hipStream_t stream) {
+    bool in_flight = r->throughput_mode;
+    if (!in_flight) {
+        ws_context* c = r->ctx;
+        void* const prev = c->last_prepare_stream.exchange(static_cast<void*>(stream), std::memory_order_relaxed);
+        uint32_t run = 0;
+        if (prev == static_cast<void*>(stream)) run = c->same_stream_run.fetch_add(1u, std::memory_order_relaxed) + 1u;
+        else c->same_stream_run.store(0u, std::memory_order_relaxed);
+        in_flight = run < 4u;
+    }
+    return r->ctx->blend_order < 0 ? (in_flight ? 0 : 1) : r->ctx->blend_order;
+}
+
 static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params& kp, const K1Buffers& kb, hipStream_t stream,
                          int phase = FRAME_ALL) {
     int rc;
@@ -991,9 +1035,21 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
         uint32_t *sk = nullptr, *sv = nullptr, *sk2 = nullptr, *sv2 = nullptr;
         const int key_bits = 32;
         FrameCounters* skip_top = r->ctx->depth_skip_top ? r->counters : nullptr;
+        // Digit width (round 6): three 8-bit passes when the renderer's previous frame says its keys span < 2^24 (the cheapest
+        // form), three 9-bit passes when it says they do not (c5: every frame; hd1m: the views that see the cloud end on) --
+        // the answer of the last frame whose blend has started, read from pinned memory without a sync.  Either width yields
+        // the same stable order, so the image does not depend on which frame's answer was the latest.
+        int dbits = r->ctx->depth_digit_bits;
+        if (dbits != 8 && dbits != 9) {
+            dbits = WS_DEPTH_DIGIT_BITS_DEFAULT;
+            if (WS_DEPTH_DIGIT_BITS_ADAPTIVE && skip_top && r->demand_mailbox && r->graph_depth_bits == 0)
+                dbits = *reinterpret_cast<volatile const uint32_t*>(r->demand_mailbox + 2) == 2u ? 9 : 8;
+        }
+        if (r->graph_depth_bits) dbits = r->graph_depth_bits;  // (a captured frame graph keeps the width it was captured with)
+        r->depth_bits_this_frame = dbits;
         if ((rc = launch_sort_pairs(r->sort_depth, r->keys_a, r->vals_a, &r->counters->num_visible, pc->num_points, 0, key_bits,
-                                    true, false, stream, &sk, &sv, km, "depth:", nullptr, 0, RADIX_BITS, false, r->fpw_a,
-                                    r->fpw_b, skip_top, &sk2, &sv2)))
+                                    true, false, stream, &sk, &sv, km, "depth:", nullptr, 0, dbits, false, r->fpw_a,
+                                    r->fpw_b, skip_top, &sk2, &sv2, r->ctx->depth_tile_kpt ? r->ctx->depth_tile_kpt : 8)))
             return rc;
         r->sorted_idx = sv;
         r->sorted_keys = sk;
@@ -1092,17 +1148,9 @@ static int enqueue_frame(ws_renderer* r, const ws_pointcloud* pc, const K1Params
     // "In flight" = a slot of a view batch with several slots, or -- for renderers driven by the caller's own loop -- a context
     // whose prepare() calls change stream from call to call (frames in flight on a ring of streams do; a renderer that draws
     // one frame at a time stays on its stream: after four consecutive calls on one stream it orders its tiles).
+    // (the decision itself is taken once per prepare(), OUTSIDE any captured region: ws_renderer_prepare -> decide_blend_order)
     r->blend_order_valid = false;
-    bool in_flight = r->throughput_mode;
-    if (!in_flight) {
-        ws_context* c = r->ctx;
-        void* const prev = c->last_prepare_stream.exchange(static_cast<void*>(stream), std::memory_order_relaxed);
-        uint32_t run = 0;
-        if (prev == static_cast<void*>(stream)) run = c->same_stream_run.fetch_add(1u, std::memory_order_relaxed) + 1u;
-        else c->same_stream_run.store(0u, std::memory_order_relaxed);
-        in_flight = run < 4u;
-    }
-    const int order_mode = r->ctx->blend_order < 0 ? (in_flight ? 0 : 1) : r->ctx->blend_order;
+    const int order_mode = r->order_mode_this_frame;
     // (up to 4096 tiles = eight rounds of workgroups on this chip: beyond that the tail is a small share of the kernel and the
     // one-workgroup ordering kernel, 3 us at 2040 tiles and 7.6 us at 8160, costs what it saves -- c5, 4K: measured)
     if (order_mode && r->ctx->tile_qw == 4 && r->ctx->tile_qh == 4 && ntiles <= 4096u && r->ctx->blend_tpw_log2 <= 0) {
@@ -1217,12 +1265,15 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     // when the caller gave a real stream and no per-launch instrumentation is on.  The legacy NULL stream cannot be captured.
     const bool use_graph = r->ctx->use_graph && stream != nullptr && !r->marks.active && !r->timers && !r->capture &&
                            cut_mode == 0;
+    r->order_mode_this_frame = decide_blend_order(r, stream);
     if (!use_graph) return enqueue_frame(r, pc, kp, kb, stream);
     ws_renderer::FrameGraph& g = r->fg;
-    if (!(g.valid && g.pc == pc && g.generation == r->scratch_generation)) {
+    if (!(g.valid && g.pc == pc && g.generation == r->scratch_generation && g.order_mode == r->order_mode_this_frame)) {
         renderer_free_graph(r);
+        r->graph_depth_bits = 0;
         WS_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         rc = enqueue_frame(r, pc, kp, kb, stream);
+        r->graph_depth_bits = r->depth_bits_this_frame;
         hipGraph_t graph = nullptr;
         const hipError_t ce = hipStreamEndCapture(stream, &graph);
         if (rc) {
@@ -1264,6 +1315,8 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
         g.entries_sorted = r->entries_sorted;
         g.sorted_idx_skipped = r->sorted_idx_skipped;
         g.sorted_keys_skipped = r->sorted_keys_skipped;
+        g.order_mode = r->order_mode_this_frame;
+        g.blend_order_valid = r->blend_order_valid;  // did the captured frame run k_blend_order?
         g.valid = true;
     }
     const int slot = (int)(g.next++ % ws_renderer::GRAPH_RING);
@@ -1282,6 +1335,7 @@ int ws_renderer_prepare(ws_renderer* r, const ws_pointcloud* pc, const ws_splatt
     r->entries_sorted = g.entries_sorted;
     r->sorted_idx_skipped = g.sorted_idx_skipped;
     r->sorted_keys_skipped = g.sorted_keys_skipped;
+    r->blend_order_valid = g.blend_order_valid;  // what THIS graph's frames write, whatever a launch-by-launch frame left behind
     r->prepared = true;
     r->prepared_pc = pc;
     r->last_stream = stream;
@@ -1331,6 +1385,7 @@ int ws_internal_prepare_group(ws_renderer* const* rs, uint32_t n, const ws_point
     int rc;
     for (uint32_t i = 0; i < n; ++i) {
         if ((rc = prepare_setup(rs[i], pc, &views[i], streams[i], &kp[i], &kb[i]))) return rc;
+        rs[i]->order_mode_this_frame = decide_blend_order(rs[i], streams[i]);
         for (int e = 0; e < 2; ++e)
             if (!rs[i]->ev_group[e]) WS_HIP(hipEventCreateWithFlags(&rs[i]->ev_group[e], hipEventDisableTiming));
     }
@@ -1489,6 +1544,13 @@ int ws_renderer_depth_sort_passes(ws_renderer* r, uint32_t* passes) {
         { int rc_ = copy_d2h(&skipped, &r->counters->depth_skip_top, sizeof skipped, r->last_stream); if (rc_) return rc_; }
         if (skipped) *passes = 3u;
     }
+    return WS_OK;
+}
+
+int ws_renderer_depth_sort_digit_bits(ws_renderer* r, uint32_t* digit_bits) {
+    if (!r || !digit_bits) return fail(WS_ERR_INVALID, "ws_renderer_depth_sort_digit_bits: null argument");
+    if (!r->prepared) return fail(WS_ERR_STATE, "ws_renderer_depth_sort_digit_bits: no prepared frame");
+    *digit_bits = (uint32_t)r->depth_bits_this_frame;
     return WS_OK;
 }
 
@@ -1667,7 +1729,8 @@ int ws_sorter_create(ws_context* ctx, uint32_t max_n, ws_sorter** out) {
     ws_sorter* s = new (std::nothrow) ws_sorter();
     if (!s) return fail(WS_ERR_OOM, "ws_sorter_create: host allocation failed");
     s->ctx = ctx;
-    int rc = alloc_sort_scratch(s->sc, max_n, true);
+    int rc = alloc_sort_scratch(s->sc, max_n, true, 0, 512);
+    s->sc.hist_pitch = 512;
     if (rc == WS_OK) rc = dmalloc(&s->zero, 1);
     if (rc == WS_OK) rc = dmalloc(&s->aux_alt, (size_t)max_n + 4);
     if (rc == WS_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(WS_ERR_HIP, "ws_sorter_create: device sync failed");
@@ -1744,7 +1807,8 @@ int ws_sorter_sort_depth(ws_sorter* s, uint32_t* d_keys, uint32_t* d_payload, ui
                                      s->epoch, s->ctx->num_cus, stream, nullptr);
     uint32_t *ok = nullptr, *ov = nullptr;
     int rc = launch_sort_pairs(s->sc, d_keys, d_payload, d_count, n, 0, 32, false, false, stream, &ok, &ov, nullptr, "depth:",
-                               nullptr, 0, RADIX_BITS, false, d_aux, d_aux ? s->aux_alt : nullptr);
+                               nullptr, 0, depth_digit_bits(s->ctx), false, d_aux, d_aux ? s->aux_alt : nullptr, nullptr, nullptr, nullptr,
+                               s->ctx->depth_tile_kpt);
     if (rc) return rc;
     if (ok != d_keys) return fail(WS_ERR_STATE, "ws_sorter_sort_depth: internal ping-pong parity error");
     return WS_OK;

@@ -70,6 +70,22 @@ constexpr float CUT_A = 2.0f * CUTOFF;        // gaussian.wgsl:61 discard if a >
 constexpr float T_MIN = 1.0f / 16384.0f;      // front-to-back early-out (6.1e-5; DESIGN.md section Blend)
 
 // ---- device-side frame state, zeroed by ONE memset at the start of every frame ------------------
+// Wave priority (s_setprio 0..3) of K1 and of the frame's small dependent kernels against the blend's default 0: which wave a
+// SIMD issues from when several are ready.  A/B switches (round 6, verdict r05 item 1); 0 = no instruction emitted.
+#ifndef WS_PRIO_K1
+#define WS_PRIO_K1 0
+#endif
+#ifndef WS_PRIO_SMALL
+#define WS_PRIO_SMALL 0
+#endif
+#define WS_SETPRIO_K1() do { if (WS_PRIO_K1) __builtin_amdgcn_s_setprio(WS_PRIO_K1); } while (0)
+#define WS_SETPRIO_SMALL() do { if (WS_PRIO_SMALL) __builtin_amdgcn_s_setprio(WS_PRIO_SMALL); } while (0)
+#ifndef WS_DEPTH_DIGIT_BITS_DEFAULT
+#define WS_DEPTH_DIGIT_BITS_DEFAULT 8
+#endif
+#ifndef WS_DEPTH_DIGIT_BITS_ADAPTIVE   // 1: a renderer picks 8 or 9 bits per frame from its previous frame's key range (ws_api.cpp)
+#define WS_DEPTH_DIGIT_BITS_ADAPTIVE 1
+#endif
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 
@@ -89,7 +105,10 @@ struct FrameCounters {
     uint32_t depth_skip_top; // written by the depth sort's first kernel: 1 = the frame's keys span less than 2^24 above
                              // depth_key_base: the sort's fourth digit pass has nothing to do, the result is where pass 2 left it
     uint32_t depth_key_base; // written with it: passes 1..3 take their digits from (key - depth_key_base) (depth_range_decide)
-    uint32_t _pad[13];
+    uint32_t depth_span_class; // written with them: 0 = no key reported, 1 = the frame's keys span < 2^24 above their 256-aligned minimum (three
+                               // 8-bit passes sort them), 2 = they do not (three 9-bit passes do, below 2^27).  The blend posts it to the host:
+                               // the NEXT frame of the renderer picks its digit width by it (ws_api.cpp; either width gives the same order)
+    uint32_t _pad[12];
     // --- the frame's footprint totals, summed by K1: TILE_SUM_SLOTS x {sum at the blend's tile size, sum at twice that
     // size}, one 64-B line per slot.  Workgroup b adds its partial sums to slot b % 16 with two returnless atomics; all
     // K1 workgroups retire within a few microseconds of each other, and ~1000 atomics on ONE address drain one after
@@ -106,7 +125,7 @@ static_assert(sizeof(FrameCounters) == 128 + TILE_SUM_SLOTS * TILE_SUM_STRIDE * 
 // sorts, and the tile ranges (appended after this struct).
 struct FrameZero {
     FrameCounters counters;
-    uint32_t depth_hist[4 * RADIX];
+    uint32_t depth_hist[4 * 512];   // digit totals of the depth sort's passes (8-bit digits use the first 256 of every row of 512)
     uint32_t tile_hist[4 * RADIX];
     uint32_t fat_barrier[9 * 16];  // single-launch depth sort (WS_DEPTH_SORT=coop): state of its device-wide barriers (grid_barrier.h)
     // uint2 tile_ranges[tiles] follows
@@ -171,7 +190,12 @@ __host__ __device__ inline uint32_t rect_coarse(uint32_t r) {
 // a constant digit -- the identity: its three kernels leave at once, and the readers of the sorted arrays (k_bin_prefix,
 // k_bin_emit, the host's read-back) take them from where pass 2 left them.  Three launches and 24 of 112 B per key less on
 // such frames; order and stability are the reference's.  -> (base, skip) in the counters
-__host__ __device__ inline void depth_range_decide(FrameCounters* c) {
+// `digits` = 2^b, the radix of the sort: b = 8 is the reference's shape (four passes, the fourth skipped below 2^24); b = 9
+// (round 6) is three passes over key - base whenever the frame's keys span less than 2^27 -- every frame of every BASELINE
+// workload -- with a fourth pass over bits 27..31 enqueued for the frames that do not, which leaves at once on all others.
+// A frame that holds a key of 0xFFFFFFFF (the compressed path's saturating u32(f32), bits(NaN)) keeps base = 0: the scatter
+// kernels exempt that value from the subtraction (it is also their padding key), the histogram kernels do not.
+__host__ __device__ inline void depth_range_decide(FrameCounters* c, uint32_t digits = 256u) {
     uint32_t not_min = 0u, mx = 0u;
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) {
@@ -180,9 +204,12 @@ __host__ __device__ inline void depth_range_decide(FrameCounters* c) {
         mx = b > mx ? b : mx;
     }
     const bool known = not_min != 0u;          // (no key reported: nothing visible, or a K1 form that does not report)
-    const uint32_t base = known ? (~not_min & 0xFFFFFF00u) : 0u;
+    const uint32_t base = (known && mx != 0xFFFFFFFFu) ? (~not_min & ~(digits - 1u)) : 0u;
+    const uint32_t span = digits * digits * digits;  // 2^24 / 2^27: what three passes cover
     c->depth_key_base = base;
-    c->depth_skip_top = (known && mx >= base && (mx - base) < (1u << 24)) ? 1u : 0u;
+    c->depth_skip_top = (known && mx >= base && (mx - base) < span) ? 1u : 0u;
+    const uint32_t base8 = (known && mx != 0xFFFFFFFFu) ? (~not_min & ~255u) : 0u;
+    c->depth_span_class = !known ? 0u : ((mx - base8) < (1u << 24) ? 1u : 2u);
 }
 
 __host__ __device__ inline uint32_t bin_shift_decide(const FrameCounters* c) {
@@ -260,8 +287,10 @@ constexpr int TILE_SORT_WIDE_MAX_BINS = 1 << TILE_SORT_WIDE_MAX_BITS;
 struct SortScratch {
     uint32_t* keys_alt = nullptr;     // ping-pong partner of the caller's key buffer   [cap]
     uint32_t* vals_alt = nullptr;     // ping-pong partner of the caller's value buffer [cap]
-    uint32_t* hist = nullptr;         // [4][256] digit totals of the passes (written by the column scans)
-    uint32_t* tile_sums = nullptr;    // [256][tiles_cap] per-tile digit counts / offsets
+    uint32_t* hist = nullptr;         // [4][hist_pitch] digit totals of the passes (written by the column scans)
+    uint32_t hist_pitch = 256;        // words per pass in hist (512 for a scratch that may run 9-bit digits)
+    uint32_t* tile_sums = nullptr;    // [rows][tiles_cap] per-tile digit counts / offsets, rows = 256 (512: 9-bit digits)
+    uint32_t rows = 256;
     uint32_t cap = 0;
     uint32_t tiles = 0;               // ceil(cap / SORT_TILE)
     uint32_t tiles_cap = 0;           // row pitch of tile_sums: the largest tile count any n <= cap can need
@@ -283,7 +312,8 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                       int begin_bit, int end_bit, bool implicit_iota, bool first_tile_hist_ready, hipStream_t stream,
                       uint32_t** out_keys, uint32_t** out_vals, KernelMarks* km = nullptr, const char* tag = "", uint2* ranges = nullptr, uint32_t nranges = 0,
                       int digit_bits = RADIX_BITS, bool key16 = false, uint32_t* aux = nullptr, uint32_t* aux_alt = nullptr,
-                      FrameCounters* skip_top = nullptr, uint32_t** out_keys_skipped = nullptr, uint32_t** out_vals_skipped = nullptr);
+                      FrameCounters* skip_top = nullptr, uint32_t** out_keys_skipped = nullptr, uint32_t** out_vals_skipped = nullptr,
+                      int kpt9 = 0);  // kpt9 (9-bit digits only): 0 = the tile size the input size selects, 4 / 8 = keys per thread (A/B)
 //   skip_top (four 8-bit passes from bit 0 only: the depth sort of a frame): the first kernel folds K1's key-bit words into
 //     skip_top->depth_skip_top (depth_top_decide); when it is set the three kernels of the LAST pass return at once and the
 //     result is what pass 2 wrote: *out_keys_skipped / *out_vals_skipped (the companion values next to the payload).
@@ -409,6 +439,7 @@ struct BlendParams {
     uint32_t* sticky;           // per-renderer error word that is NOT zeroed per frame (ws_renderer_errors)
     uint32_t* demand_mailbox;   // nullptr, or a host-visible (pinned, mapped) word: the entry demand of overflowed frames
     uint32_t* progress_mailbox; // nullptr, or a host-visible word: the blend's first workgroup posts frame_seq here when it starts
+                                // (progress_mailbox[1]: the frame's depth_span_class, posted with it)
     uint32_t frame_seq;         //   (the frame's kernels in front of the blend are done: what a view batch bounds the host's run-ahead by)
     const uint4* order;         // nullptr, or [blockIdx] -> (tx | ty << 16, begin, end, -) longest list first (k_blend_order;
                                 //   4x4 tiles, one tile per workgroup, not split)
@@ -493,6 +524,12 @@ struct ws_context {
                               //   launches (opt-in: on ROCm 7.2 legacy-NULL-stream work between two launches of a used
                               //   executable graph makes the next launch fault)
     uint32_t tile_qw = 4, tile_qh = 4;  // WS_TILE_SHAPE = 2x2 | 4x2 | 4x4 (default: 32x32-px binning tiles)
+    int batch_queue_depth = -1;    // ws_context_config::batch_queue_depth: -1 = the view batch's default
+    bool capture = false;          // ws_context_config::capture: renderers keep source indices / debug words (tests)
+    bool render_views_fast_blend = false;
+    bool ply_decode_host = false;
+    int depth_digit_bits = 0;      // ws_context_config::depth_digit_bits: 0 = default, 8 / 9 force the depth sort's digit width
+    int depth_tile_kpt = 0;        // ws_context_config::depth_tile_kpt (9-bit digits, A/B): 0 = by input size, 4 / 8 keys per thread
     // Is this context drawing on several streams in turn (a hand-rolled pipeline of renderers with frames in flight), or one
     // frame at a time?  The stream of the latest prepare() and how many consecutive prepare() calls used that same stream;
     // read by the automatic choice of the blend's workgroup order (ws_api.cpp).  Relaxed atomics: renderers of one context

@@ -4,6 +4,7 @@
 #include <cstdio>
 
 #include "websplat.h"
+#include "websplat_env.h"  // the harness-side translation of WS_* switches (the library reads no environment)
 
 int main(int argc, char** argv) {
     if (argc != 4) {
@@ -13,7 +14,9 @@ int main(int argc, char** argv) {
     ws_context* ctx = nullptr;
     ws_pointcloud* pc = nullptr;
     ws_scene* scene = nullptr;
-    int rc = ws_context_create(0, &ctx);
+    ws_context_config cfg;
+    ws_context_config_from_env(&cfg);
+    int rc = ws_context_create_with_config(0, &cfg, &ctx);
     std::printf("reading scene file '%s'\n", argv[2]);
     if (rc == WS_OK) rc = ws_scene_load_json(argv[2], &scene);
     std::printf("reading point cloud file '%s'\n", argv[1]);

@@ -5,5 +5,5 @@ Importing this package loads the HIP library; there is no CPU fallback (ImportEr
 from ._lib import (LIB_PATH, WebSplatError, lib, check, ws_gaussian_quantization, ws_quantization)  # noqa: F401
 from .api import (Aabb, Context, GaussianRenderer, GenericGaussianPointCloud, GPURSSorter, PerspectiveCamera,  # noqa: F401
                   PointCloud, SplattingArgs, pointcloud_stats, FORMATS, Scene, SceneCamera, read_npz, read_ply, write_png,
-                  render_views, measure, ViewBatch, stage_splat, footprint_tiles, packed_rect, binning_decision)
+                  render_views, measure, ViewBatch, config_from_env, stage_splat, footprint_tiles, packed_rect, binning_decision)
 from . import synth  # noqa: F401

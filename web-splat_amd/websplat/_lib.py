@@ -44,6 +44,16 @@ class ws_gaussian_quantization(C.Structure):
                 ("opacity", ws_quantization), ("scaling_factor", ws_quantization)]
 
 
+class ws_context_config(C.Structure):
+    """include/websplat.h ws_context_config: every tuning / analysis switch of a context.  The library reads no environment
+    variable; config_from_env() below is the harness-side translation of the historical WS_* variables."""
+    _fields_ = [(n, C.c_uint32 if n == "struct_size" else C.c_int32) for n in (
+        "struct_size", "use_graph", "depth_skip_top", "blend_order", "blend_split", "bin_request", "batch_threads",
+        "batch_queue_depth", "blend_tpw_log2", "blend_lds_pad_kb", "tile_qw", "tile_qh", "debug_cut", "capture",
+        "render_views_fast_blend", "ply_decode_host", "depth_digit_bits", "depth_tile_kpt", "exp_depth_sort", "exp_dsort_fat_grid",
+        "exp_blend_variant", "exp_blend_dma", "exp_batch_k1", "exp_footprint_ellipse", "exp_tile_sort_wide")] + [("reserved", C.c_int32 * 7)]
+
+
 class ws_pointcloud_desc(C.Structure):
     _fields_ = [
         ("num_points", C.c_uint32), ("sh_deg", C.c_uint32), ("compressed", C.c_int32),
@@ -149,12 +159,16 @@ _f32p = C.POINTER(C.c_float)
 SIGNATURES = {
     "ws_last_error": (C.c_char_p, []),
     "ws_abi_version": (C.c_uint32, []),
+    "ws_build_flags": (C.c_uint32, []),
     "ws_context_create": (C.c_int, [C.c_int, _PP]),
+    "ws_context_config_init": (None, [C.POINTER(ws_context_config)]),
+    "ws_context_create_with_config": (C.c_int, [C.c_int, C.POINTER(ws_context_config), _PP]),
     "ws_context_destroy": (None, [_P]),
     "ws_context_tile_size": (C.c_int, [_P, _u32p, _u32p]),
     "ws_renderer_download_wave_stats": (C.c_int, [_P, C.c_uint32, _u32p]),
     "ws_renderer_download_blend_order": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "ws_renderer_depth_sort_passes": (C.c_int, [_P, _P]),
+    "ws_renderer_depth_sort_digit_bits": (C.c_int, [_P, _P]),
     "ws_renderer_enable_blend_timing": (C.c_int, [_P, C.c_int]),
     "ws_renderer_download_blend_timing": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "ws_debug_stage_splat": (C.c_int, [_u32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,

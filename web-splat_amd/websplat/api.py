@@ -11,6 +11,7 @@ Names follow the reference so that tests read like web-splat code:
 No compute happens here; every method is one call into libwebsplat_hip.so.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
 
@@ -176,12 +177,55 @@ def binning_decision(request, sums, sums_coarse):
     return sh.value
 
 
+def config_from_env(env=None, **overrides):
+    """The harness-side translation of the WS_* environment switches into a ws_context_config (bench.py, tests, scripts).
+    The LIBRARY reads no environment variable (include/websplat.h); include/websplat_env.h is the same table for C callers.
+    Keyword overrides name struct fields directly (config_from_env(blend_order=1))."""
+    env = os.environ if env is None else env
+    c = L.ws_context_config()
+    lib.ws_context_config_init(C.byref(c))
+
+    def num(name, field):
+        v = env.get(name)
+        if v not in (None, ""):
+            setattr(c, field, int(v))
+
+    for name, field in (("WS_GRAPH", "use_graph"), ("WS_DEPTH_SKIP_TOP", "depth_skip_top"), ("WS_BLEND_ORDER", "blend_order"),
+                        ("WS_BLEND_SPLIT", "blend_split"), ("WS_BATCH_THREADS", "batch_threads"),
+                        ("WS_BATCH_QUEUE_DEPTH", "batch_queue_depth"), ("WS_BLEND_TPW_LOG2", "blend_tpw_log2"),
+                        ("WS_BLEND_LDS_PAD_KB", "blend_lds_pad_kb"), ("WS_DEBUG_CUT", "debug_cut"), ("WS_CAPTURE", "capture"),
+                        ("WS_DEPTH_DIGIT_BITS", "depth_digit_bits"), ("WS_DEPTH_TILE_KPT", "depth_tile_kpt"), ("WS_DSORT_FAT_GRID", "exp_dsort_fat_grid"),
+                        ("WS_BLEND_VARIANT", "exp_blend_variant"), ("WS_BATCH_K1", "exp_batch_k1")):
+        num(name, field)
+    if env.get("WS_BLEND_DMA") not in (None, ""):
+        c.exp_blend_dma = 1 if int(env["WS_BLEND_DMA"]) else 0
+    bs = env.get("WS_BIN_SHIFT")
+    if bs is not None:
+        c.bin_request = 2 if bs == "1" else (0 if bs == "0" else 1)
+    shape = env.get("WS_TILE_SHAPE")
+    if shape:
+        qw, _, qh = shape.partition("x")
+        c.tile_qw, c.tile_qh = (int(qw), int(qh)) if qw.isdigit() and qh.isdigit() else (-1, -1)  # (the library refuses what it does not have)
+    c.render_views_fast_blend = 1 if env.get("WS_RENDER_VIEWS_BLEND") == "fast" else 0
+    c.ply_decode_host = 1 if env.get("WS_PLY_DECODE") == "host" else 0
+    c.exp_depth_sort = {"onesweep": 1, "coop": 2}.get(env.get("WS_DEPTH_SORT", ""), 0)
+    c.exp_footprint_ellipse = 1 if env.get("WS_FOOTPRINT") == "ellipse" else 0
+    c.exp_tile_sort_wide = 1 if env.get("WS_TILE_SORT") == "wide" else 0
+    for k, v in overrides.items():
+        setattr(c, k, int(v))
+    return c
+
+
 class Context:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, config=None):
+        """config: a ws_context_config (config_from_env(...)); None = this process's WS_* environment, translated HERE -- the
+        harness side -- because the library itself reads no environment variable."""
         h = C.c_void_p()
-        check(lib.ws_context_create(int(device), C.byref(h)))
+        cfg = config_from_env() if config is None else config
+        check(lib.ws_context_create_with_config(int(device), C.byref(cfg), C.byref(h)))
         self.handle = h
         self.device = device
+        self.config = cfg
 
     def close(self):
         if self.handle:
@@ -613,6 +657,12 @@ class GaussianRenderer:
         """digit passes the last prepared frame's depth sort executed (websplat.h)."""
         v = C.c_uint32()
         check(lib.ws_renderer_depth_sort_passes(self.handle, C.byref(v)))
+        return v.value
+
+    def depth_sort_digit_bits(self) -> int:
+        """digit width (8 | 9) of the last prepared frame's depth sort (websplat.h)."""
+        v = C.c_uint32()
+        check(lib.ws_renderer_depth_sort_digit_bits(self.handle, C.byref(v)))
         return v.value
 
     def blend_order(self):
