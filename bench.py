@@ -50,6 +50,9 @@ sys.path[:0] = [os.path.join(ROOT, "web-splat_amd"), os.path.join(ROOT, "tests")
 
 import numpy as np  # noqa: E402
 
+NUM_SIMDS = 1024                      # 256 CUs x 4 SIMDs
+VALU_CYCLES_PER_INST = 2.0            # a wave64 VALU instruction on a SIMD (MI355X_MICROARCH.md); the roofline's `peak`
+VALU_CYCLES_PER_INST_MEASURED = 2.4   # scripts/ubench/valu_rate.hip on this part (DESIGN_LOG.md): reported beside it
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 WORKLOADS = ("hd1m", "c2", "bonsai", "c3", "c4", "c5", "c1", "realistic1m")
@@ -401,6 +404,16 @@ def init_distributed(a, torch):
     backend = "gloo" if (a.dry_run or a.dist_backend == "gloo") else "nccl"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
+    if backend == "nccl" and world > 1:
+        # RCCL wants one device per rank: two ranks of a communicator on one device end in ncclInvalidUsage ("Duplicate GPU
+        # detected") at best and in a hang inside the bootstrap at worst.  Say so BEFORE the rendezvous, by name, on every rank.
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        have = torch.cuda.device_count()
+        if a.single_device or local_world > have:
+            raise SystemExit(f"[bench] RCCL needs one device per rank: {local_world} local rank(s), {have} visible device(s)"
+                             + (", --single-device" if a.single_device else "") + ".  To stand several ranks on one device "
+                             "(shard determinism, host budget) use --single-device --dist-backend gloo; the collective of the "
+                             "real run needs --gpus <= devices")
     if world == 1:
         if a.no_dist:
             return None, rank, local_rank, world, "disabled (--no-dist)"
@@ -662,7 +675,8 @@ def main():
                        "host_cpus": len(host_cpus) if host_cpus else None, "host_affinity": host_note,
                        # cores one rank keeps busy while it renders (MAX over ranks) and what the container grants in total:
                        # world x busy above the quota means the ranks throttle each other, whatever the core count says
-                       "host_cores_busy_per_rank": cpu_busy, "host_cpu_quota": cpu_quota(),
+                       # (CPU time comes in 10-ms clock ticks: below 0.1 s of timed region the ratio is noise -- null, like host_threads)
+                       "host_cores_busy_per_rank": cpu_busy if elapsed >= 0.1 else None, "host_cpu_quota": cpu_quota(),
                        "host_threads": host_threads if elapsed >= 0.1 else None, "host_wait": a.host_wait,
                        "frame_submission": os.environ.get("WS_GRAPH", "0") not in ("", "0") and "graph replay (WS_GRAPH)" or "launch by launch",
                        "timing_barrier": ("none (one process, --no-dist): device synchronize on both sides" if dist is None else
@@ -705,8 +719,31 @@ def main():
     if dist is not None and a.dry_run:
         got = [None] * world
         dist.all_gather_object(got, view_ids)   # verification only (tests): every rank's shard
+        # ... and every rank's share of the host as pin_host_share() really set it on THIS machine's sysfs (verdict r05 item 8a):
+        # the ranks of a node must not overlap, and their OpenMP teams together must fit the cgroup's CPU quota
+        try:
+            mine = sorted(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            mine = None
+        shares = [None] * world
+        dist.all_gather_object(shares, {"rank": rank, "cpus": mine, "omp_num_threads": int(os.environ.get("OMP_NUM_THREADS", "0") or 0),
+                                        "pinned": bool(host_cpus) and "not pinned" not in host_note, "note": host_note})
         if out is not None:
             out["config"]["rank_views"] = got
+            pinned = [sh for sh in shares if sh["pinned"] and sh["cpus"]]
+            overlap = [(x["rank"], y["rank"]) for i, x in enumerate(pinned) for y in pinned[i + 1:] if set(x["cpus"]) & set(y["cpus"])]
+            quota = cpu_quota()
+            omp_sum = sum(sh["omp_num_threads"] for sh in shares)
+            # (a team is never smaller than one thread: with more ranks than quota'd CPUs the floor is one thread per rank)
+            budget = max(quota, float(world)) if quota else None
+            out["config"]["host_partition"] = {
+                "ranks": [{"rank": sh["rank"], "logical_cpus": len(sh["cpus"]) if sh["cpus"] else None, "first_cpu": sh["cpus"][0] if sh["cpus"] else None,
+                           "omp_num_threads": sh["omp_num_threads"], "pinned": sh["pinned"], "note": sh["note"]} for sh in shares],
+                "pinned_ranks": len(pinned), "disjoint": not overlap, "overlapping_pairs": overlap,
+                "omp_threads_sum": omp_sum, "cpu_quota": quota, "fits_quota": (omp_sum <= budget) if budget else None}
+            if overlap or (budget and omp_sum > budget):
+                raise SystemExit(f"[bench] host partition INVALID: overlapping rank shares {overlap}, sum of OMP teams {omp_sum} "
+                                 f"against a quota of {quota}")
     if not a.dry_run:
         r.close()
         batch.close()
@@ -777,8 +814,14 @@ def secondary(a, ws, ctx, torch, workload, nstreams, frames=200):
             "value": frames / elapsed, "unit": "frames/s", "ms_per_step": elapsed / frames * 1e3,
             "single_stream_fps": sub["config"]["single_stream_fps"], "host_enqueue_ms_per_frame": t_enq / frames * 1e3,
             "binning_tile": sub["config"]["binning_tile"], "avg_visible": V, "avg_tile_entries": sub["config"]["avg_tile_entries"],
-            "roofline": {"kernel": rf["kernel"], "frac": rf["frac"], "achieved": rf["achieved"], "peak": rf["peak"],
-                         "alg_bytes": rf["alg_bytes_per_launch"], "avg_launch_ms": rf["avg_launch_ms"], "traffic": rf["traffic"]},
+            "roofline": {"kernel": rf["kernel"], "bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "peak": rf["peak"],
+                         "unit": rf["unit"], "hbm_frac": rf["hbm_frac"], "hbm_achieved": rf["hbm_achieved"],
+                         "frac_at_measured_issue_rate": rf.get("frac_at_measured_issue_rate"),
+                         "alg_bytes": rf["alg_bytes_per_launch"], "avg_launch_ms": rf["avg_launch_ms"], "traffic": rf["traffic"],
+                         # the whole frame against the HBM roofline, at THIS block's frame period (frames in flight)
+                         "frame": {"alg_bytes_per_frame": rf["frame"]["alg_bytes_per_frame"], "ms_per_step": elapsed / frames * 1e3,
+                                   "achieved": rf["frame"]["alg_bytes_per_frame"] / (elapsed / frames) / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": rf["frame"]["alg_bytes_per_frame"] / (elapsed / frames) / 1e9 / HBM_PEAK_GBS}},
             "kernels": {
                 # 68 V: four passes x (8 B in + 8 B out) + one more key read (the reference's sorter shape)
                 "depth sort": {"launches_per_frame": sum(v["launches_per_frame"] for lbl, v in k.items() if lbl.startswith("depth:")),
@@ -906,25 +949,44 @@ def analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world
     vpath = os.path.join(ROOT, "profiles", f"valu_{a.workload}.json")
     if os.path.exists(vpath):  # PMC pass of the same command (scripts/pmc_valu.py): VALU issue accounting per launch
         valu = json.load(open(vpath)).get(dom)
+    hbm_frac = (dk["GBps"] / HBM_PEAK_GBS) if dk["GBps"] else None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (dk["GBps"] / HBM_PEAK_GBS) if dk["GBps"] else None, "traffic": traffic,
-                "traffic_detail": traffic_detail,
+                "frac": hbm_frac, "traffic": traffic, "traffic_detail": traffic_detail,
+                "hbm_achieved": dk["GBps"], "hbm_frac": hbm_frac,
                 "alg_bytes_per_launch": dk["alg_bytes_per_launch"], "avg_launch_ms": dk["avg_launch_ms"],
                 "launches_per_frame": dk["launches_per_frame"],
                 "event_interval_ms": dk["event_interval_ms"], "empty_launch_interval_ms": empty_ms,
-                "limited_by": ("latency" if (valu and valu.get("issue_util", 1.0) < 0.5) else "valu") if dom == "k_blend" else "hbm",
-                "valu": valu,
-                "note": "dominant = most GPU time per frame summed over its launches; HIP events around every "
-                        "launch on the launch stream, one frame in flight; avg_launch_ms = event interval minus "
-                        "the interval of an empty launch recorded the same way in every frame (dispatch latency "
-                        "of a dependent launch, which rocprofv3 kernel durations do not contain).  No stage is a dense contraction, so "
-                        "MFMA is unused and every kernel is priced against HBM; k_blend moves few bytes per "
-                        "(pixel, splat) pair: what limits it is VALU issue and, on scenes whose tiles saturate after "
-                        "one or two staged batches, the per-tile start-up latency (valu.issue_util, DESIGN.md 3.3); "
-                        "early-out makes its real traffic a fraction of the algorithmic bytes.  D counts the entries of "
-                        "the frame's binned lists: a frame that bins at 64x64 (config.binning_tile) has half the entries "
-                        "of the same frame binned at the 32x32 compositing tile, so the same blend time prices at about "
-                        "half the fraction -- the frame got faster (fewer entries emitted and sorted), not the blend slower"}
+                "valu": valu}
+    # The BINDING resource (verdict r05 item 2).  k_blend moves few bytes per (pixel, splat) pair: what it runs out of is the
+    # chip's wave64 VALU issue slots.  Then `bound` = "valu", `achieved` = wave64 VALU instructions per second (SQ_INSTS_VALU of
+    # the PMC pass of the same command, profiles/valu_<workload>.json, / the launch duration measured HERE), `peak` = what 1024
+    # SIMDs issue at VALU_CYCLES_PER_INST cycles per instruction -- 2 by the microarchitecture guide (a wave64 op over a
+    # 32-lane-wide SIMD datapath), 2.4 by scripts/ubench/valu_rate.hip on this part: both fractions are on the record, `frac`
+    # is the guide's -- and the HBM figure stays beside it as hbm_frac.  Every other kernel is priced against HBM.
+    if dom == "k_blend" and valu and valu.get("valu_insts_per_launch") and valu.get("kernel_cycles") and dk["avg_launch_ms"]:
+        insts, cyc = float(valu["valu_insts_per_launch"]), float(valu["kernel_cycles"])
+        frac_guide = insts * VALU_CYCLES_PER_INST / (NUM_SIMDS * cyc)
+        ach = insts / (dk["avg_launch_ms"] * 1e-3) / 1e9
+        roofline.update({"bound": "valu", "achieved": ach, "peak": ach / frac_guide, "unit": "G wave64-inst/s", "frac": frac_guide,
+                         "valu_cycles_per_inst": VALU_CYCLES_PER_INST,
+                         "frac_at_measured_issue_rate": insts * VALU_CYCLES_PER_INST_MEASURED / (NUM_SIMDS * cyc),
+                         "valu_cycles_per_inst_measured": VALU_CYCLES_PER_INST_MEASURED})
+    # the driver-timed number's own roofline: algorithmic bytes of ALL launches of a frame / the frame period of the timed region
+    frame_bytes = sum((k["alg_bytes_per_launch"] or 0.0) * k["launches_per_frame"] for k in kernels.values())
+    frame_gbps = frame_bytes / (out["ms_per_step"] * 1e-3) / 1e9 if out.get("ms_per_step") else None
+    roofline["frame"] = {"bound": "hbm", "alg_bytes_per_frame": frame_bytes, "ms_per_step": out.get("ms_per_step"),
+                         "achieved": frame_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (frame_gbps / HBM_PEAK_GBS) if frame_gbps else None,
+                         "note": "sum over the frame's launches of their algorithmic bytes (the kernel table) / ms_per_step of the "
+                                 "timed region (frames in flight): how much of the HBM roofline the whole job uses"}
+    roofline["note"] = ("dominant = most GPU time per frame summed over its launches; HIP events around every launch on the launch "
+                        "stream, one frame in flight; avg_launch_ms = event interval minus the interval of an empty launch recorded the "
+                        "same way in every frame (dispatch latency of a dependent launch, which rocprofv3 kernel durations do not "
+                        "contain).  No stage is a dense contraction, so MFMA is unused.  `bound` names the resource the dominant kernel "
+                        "runs out of: \"valu\" for k_blend (wave64 VALU issue: frac = SQ_INSTS_VALU x cycles per instruction / (1024 SIMDs "
+                        "x kernel cycles)), \"hbm\" otherwise; hbm_frac is always the algorithmic bytes against 8 TB/s.  D counts the "
+                        "entries of the frame's binned lists: a frame that bins at 64x64 (config.binning_tile) has half the entries of "
+                        "the same frame binned at the 32x32 compositing tile")
     # the device picks the binning tile per frame (the compositing tile or 2 x 2 of them): D counts entries of THOSE lists
     bin_w, bin_h = r.binning_tile()
     out["config"].update({"binning_tile": f"{bin_w}x{bin_h}", "compositing_tile": f"{tile_w}x{tile_h}",

@@ -516,6 +516,10 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
 int ws_view_batch_sync(ws_view_batch* b);
 int ws_view_batch_errors(ws_view_batch* b, uint32_t* bits, int reset); /* OR of ws_renderer_errors over the slots (syncs) */
 ws_renderer* ws_view_batch_renderer(ws_view_batch* b, uint32_t slot); /* the renderer of a slot (stats, timers) */
+/* times ws_view_batch_render had to sleep because a slot's host side was queue_depth frames ahead of the device (statistics).
+ * A slot whose progress word does not move for 10 s (lost launch, device fault) makes ws_view_batch_render return
+ * WS_ERR_STATE once; its later frames are enqueued without the bound. */
+uint32_t ws_view_batch_host_waits(const ws_view_batch* b);
 
 /* Display::render (renderer.rs:548-582) + display.wgsl:37-55: the splat image (premultiplied RGBA, renderer
  * format) composited with PREMULTIPLIED_ALPHA_BLENDING over a surface cleared to `background`, written as 8-bit

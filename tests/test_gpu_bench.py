@@ -41,13 +41,25 @@ def test_bench_one_rank_rccl_and_contract():
     assert out["config"]["timing_barrier"].startswith(("host barrier (gloo group)", "nccl barrier"))
     assert out["config"]["compositing_tile"] == "32x32" and out["config"]["binning_tile"] in ("32x32", "64x64")
     rf = out["roofline"]
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    # `bound` names the resource the dominant kernel runs out of (round 6): "valu" for k_blend when the PMC pass of the workload
+    # is on file (frac = wave64 VALU issue slots used), "hbm" otherwise; the HBM figure is always there as hbm_frac; the whole
+    # frame is priced against HBM at the driver-timed frame period
+    assert rf["bound"] in ("hbm", "valu") and rf["hbm_frac"] is not None and 0 < rf["hbm_frac"] < 1
+    if rf["bound"] == "hbm":
+        assert rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and rf["frac"] == rf["hbm_frac"]
+    else:
+        assert rf["kernel"] == "k_blend" and rf["unit"] == "G wave64-inst/s" and rf["valu_cycles_per_inst"] == 2.0
+        assert 0 < rf["frac"] < rf["frac_at_measured_issue_rate"] < 1.2 and abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-9
+    fr = rf["frame"]
+    assert fr["bound"] == "hbm" and fr["peak"] == 8000.0 and fr["unit"] == "GB/s" and fr["ms_per_step"] == out["ms_per_step"]
+    assert abs(fr["frac"] - fr["alg_bytes_per_frame"] / (out["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9 and 0 < fr["frac"] < 1
     assert abs(out["value"] - 40 / (out["ms_per_step"] * 40 / 1e3)) < 1e-6 * out["value"]
     # the host side of the timed region is always on the record (round-3 verdict: an 8-GPU run that comes back sub-linear
     # must say whether the enqueue threads kept up)
     cfg = out["config"]
     assert cfg["host_enqueue_ms_per_frame"] > 0 and isinstance(cfg["host_bound"], bool) and cfg["host_cpus"] >= 1
-    assert 0 < cfg["host_cores_busy_per_rank"] < 64 and "host_cpu_quota" in cfg
+    # (40 frames of c1 last a few milliseconds: CPU time comes in 10-ms ticks, so the busy-cores ratio is null below 0.1 s)
+    assert (cfg["host_cores_busy_per_rank"] is None or 0 < cfg["host_cores_busy_per_rank"] < 64) and "host_cpu_quota" in cfg
     assert "secondary" not in out      # (only the default workload carries the c3 block)
 
 
@@ -65,7 +77,8 @@ def test_bench_secondary_c3_block():
     c3 = out["secondary"]["c3"]
     assert c3["workload"].startswith("c3: 5000000 Gaussians, 1920x1080") and c3["frames"] == 200
     assert c3["value"] > 100 and c3["single_stream_fps"] > 100 and c3["avg_visible"] > 4_000_000
-    assert c3["roofline"]["kernel"] and 0 < c3["roofline"]["frac"] < 1
+    assert c3["roofline"]["kernel"] and 0 < c3["roofline"]["frac"] < 1 and c3["roofline"]["bound"] in ("hbm", "valu")
+    assert 0 < c3["roofline"]["hbm_frac"] < 1 and 0 < c3["roofline"]["frame"]["frac"] < 1
     for name in ("depth sort", "K1"):
         assert 0 < c3["kernels"][name]["frac"] < 1, (name, c3["kernels"][name])
     assert out["config"]["workload"].startswith("hd1m:") and out["value"] > 1000
@@ -343,3 +356,25 @@ def test_frames_in_flight_stay_bit_identical_over_a_long_run():
     res = soak.soak("c2", rounds=40)
     assert res["pass"], res
     assert res["frames"] == 40 * 64 and res["distinct_images"] == 64 and res["views_that_differ"] == []
+
+
+def test_two_rccl_ranks_on_one_device_end_with_a_named_error_not_a_hang():
+    """Round 6 (verdict r05 item 8b): until now only gloo had seen N > 1 ranks.  `python bench.py --gpus 2` on a box with ONE
+    device must not reach RCCL's rendezvous with two ranks on one GPU (ncclInvalidUsage at best, a hang in the bootstrap at
+    worst): every rank stops before it, by name, and the launcher returns non-zero within the timeout."""
+    import time
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one device")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c1", "--steps", "8", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode != 0
+    assert "RCCL needs one device per rank: 2 local rank(s), 1 visible device(s)" in p.stderr, p.stderr[-2000:]
+    assert time.time() - t0 < 240
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]      # no result line from a run that did not happen
+    # --single-device with the nccl backend is the same mistake, said the same way
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--workload", "c1", "--steps", "8",
+                        "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode != 0 and "RCCL needs one device per rank" in p.stderr and "--single-device" in p.stderr

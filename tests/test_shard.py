@@ -239,3 +239,56 @@ def test_gpu_numa_nodes_from_a_kfd_topology(tmp_path):
     s, note = bench.numa_share(6, 8, allowed, gpu_nodes=[0, 0, 0, 0, 1, 1, -1, 1], cpus_of_node={0: set(range(16)), 1: set(range(16, 32))}.get,
                                physical=lambda cp: [[c] for c in sorted(cp)])
     assert s == [24, 25, 26, 27] and "unknown" in note
+
+
+def _eight_rank_dry_run():
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR",
+                                                            "MASTER_PORT", "OMP_NUM_THREADS", "WS_BENCH_PIN")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--workload", "c1", "--steps", "16",
+           "--warmup", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def _check_host_partition(out):
+    hp = out["config"]["host_partition"]
+    assert len(hp["ranks"]) == 8 and [r["rank"] for r in hp["ranks"]] == list(range(8))
+    # rank 0 has SEEN every rank's affinity mask (all_gather) and found no CPU in two pinned ranks' shares ...
+    assert hp["disjoint"] is True and hp["overlapping_pairs"] == []
+    # ... and the OpenMP teams of the eight ranks fit the cgroup's CPU quota together (one thread per rank is the floor)
+    if hp["cpu_quota"]:
+        assert hp["fits_quota"] is True and hp["omp_threads_sum"] <= max(hp["cpu_quota"], 8.0), hp
+    for r in hp["ranks"]:
+        assert r["omp_num_threads"] >= 1
+        if r["pinned"]:
+            assert r["logical_cpus"] >= 1 and r["omp_num_threads"] <= r["logical_cpus"], r
+    return hp
+
+
+def test_eight_rank_dry_run_partitions_the_host():
+    """`python bench.py --gpus 8 --dry-run` (round 6, verdict r05 item 8a): the self-launched eight ranks pin themselves
+    (bench.pin_host_share on THIS machine's sysfs), report their affinity masks to rank 0, and rank 0 asserts that the shares
+    are pairwise disjoint and that the sum of the OpenMP teams fits the cgroup quota -- the run fails otherwise."""
+    if len(os.sched_getaffinity(0)) < 8:
+        pytest.skip("needs at least eight CPUs for eight pinned ranks")
+    out = _eight_rank_dry_run()
+    assert out["n_gpus"] == 8 and out["dry_run"] is True
+    hp = _check_host_partition(out)
+    assert hp["pinned_ranks"] == 8
+
+
+@pytest.mark.gpu
+def test_eight_rank_dry_run_partitions_the_gpu_boxes_real_host():
+    """The same on the GPU box: its real KFD topology / NUMA nodes / 256 logical CPUs / 16-CPU quota instead of a fake sysfs
+    tree (the 8-GPU node of the scaling run has the same host)."""
+    out = _eight_rank_dry_run()
+    hp = _check_host_partition(out)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    import json
+    with open(os.path.join(ROOT, "gpurun_out", "eight_rank_host_partition.json"), "w") as f:
+        json.dump(hp, f, indent=1)
+    assert hp["pinned_ranks"] == 8

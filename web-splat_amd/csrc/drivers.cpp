@@ -266,7 +266,8 @@ constexpr uint32_t BATCH_THREADS_MAX_POINTS = 512u * 1024u;
 // blocking flavour included, spins for ~200 us before it sleeps, i.e. always at these frame times: measured, 0.99 of a core).
 // With 4 slots x 5 frames the GPU always has > 2 ms of work queued; the image stream is unchanged.
 struct SlotWindow {
-    uint32_t waits = 0;   // (statistics: times the host had to wait for this slot)
+    uint32_t waits = 0;      // times the host had to wait for this slot (ws_view_batch_host_waits)
+    bool stalled = false;    // the slot's progress word did not move for 10 s: windowing is off for it, the batch reports WS_ERR_STATE
 };
 struct ws_view_batch {
     ws_context* ctx = nullptr;
@@ -308,18 +309,25 @@ int slot_window_admit(ws_view_batch* b, size_t slot) {
     const uint32_t enq = ws_internal_renderer_frames_enqueued(r);
     uint32_t started = 0;
     if (!ws_internal_renderer_progress(r, &started)) return WS_OK;  // (no mailbox: unbounded, as before)
+    SlotWindow& win = b->windows[slot];
+    if (win.stalled) return WS_OK;  // (reported once, below; later frames are enqueued unbounded, as without a mailbox)
     bool waited = false;
+    int spins = 0;
     // (sequence numbers wrap: compare differences) -- and never wait forever: a frame that failed to launch posts nothing
-    for (int spins = 0; (int32_t)(enq - started) >= (int32_t)b->queue_depth && spins < 500000; ++spins) {
+    for (; (int32_t)(enq - started) >= (int32_t)b->queue_depth && spins < 500000; ++spins) {
         struct timespec ts = {0, 20000};
         nanosleep(&ts, nullptr);
         waited = true;
         if (!ws_internal_renderer_progress(r, &started)) break;
     }
-    if (waited) ++b->windows[slot].waits;
+    if (waited) ++win.waits;
+    if (spins >= 500000) {  // 10 s without progress (a lost launch, a device fault): say so instead of proceeding silently
+        win.stalled = true;
+        return fail(WS_ERR_STATE, "ws_view_batch_render: a slot's frames made no progress for 10 s (device fault or lost launch); "
+                                  "the frames enqueued so far are NOT known to have been drawn");
+    }
     return WS_OK;
 }
-int slot_window_record(ws_view_batch*, size_t) { return WS_OK; }
 
 void batch_worker(ws_view_batch* b, size_t slot) {
     (void)hipSetDevice(b->ctx->device);
@@ -339,7 +347,6 @@ void batch_worker(ws_view_batch* b, size_t slot) {
             rc = slot_window_admit(b, slot);
             if (rc == WS_OK) rc = ws_renderer_prepare(b->renderers[slot], j.pc, &j.views[i], b->streams[slot]);
             if (rc == WS_OK) rc = ws_renderer_render(b->renderers[slot], j.pc, j.background, j.targets[i], j.pitch, b->streams[slot]);
-            if (rc == WS_OK) rc = slot_window_record(b, slot);
         }
         b->workers[slot].rc = rc;
         if (rc) b->workers[slot].err = ws_last_error();  // (the error text is thread-local: hand it to the caller)
@@ -482,7 +489,6 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
             if (rc) return rc;
             for (size_t j = 0; j < group; ++j) {
                 rc = ws_renderer_render(rs[j], pc, background, d_targets[i + j], row_pitch_bytes, ss[j]);
-                if (rc == WS_OK) rc = slot_window_record(b, k + j);
                 if (rc) return rc;
             }
             i += (uint32_t)group;
@@ -494,7 +500,6 @@ int ws_view_batch_render(ws_view_batch* b, const ws_pointcloud* pc, const ws_spl
         int rc = slot_window_admit(b, k);
         if (rc == WS_OK) rc = ws_renderer_prepare(b->renderers[k], pc, &views[i], b->streams[k]);
         if (rc == WS_OK) rc = ws_renderer_render(b->renderers[k], pc, background, d_targets[i], row_pitch_bytes, b->streams[k]);
-        if (rc == WS_OK) rc = slot_window_record(b, k);
         if (rc) return rc;
         ++b->next;
         ++i;
@@ -518,6 +523,13 @@ int ws_view_batch_errors(ws_view_batch* b, uint32_t* bits, int reset) {
         *bits |= one;
     }
     return WS_OK;
+}
+
+uint32_t ws_view_batch_host_waits(const ws_view_batch* b) {
+    uint32_t n = 0;
+    if (b)
+        for (const SlotWindow& w : b->windows) n += w.waits;
+    return n;
 }
 
 ws_renderer* ws_view_batch_renderer(ws_view_batch* b, uint32_t slot) {

@@ -616,7 +616,7 @@ int run_passes_scan(const SortScratch& sc, uint32_t* kin, uint32_t* vin, uint32_
         const int shift = begin_bit + p * BITS;
         const int iota = (implicit_iota && p == 0) ? 1 : 0;
         // the depth sort of a frame: its first kernel decides whether the last pass has anything to do, the kernels of the last
-        // pass ask (ws_internal.h depth_top_decide)
+        // pass ask (ws_internal.h depth_range_decide)
         FrameCounters* fold = (skip_top && p == 0) ? skip_top : nullptr;
         const uint32_t* skip = (skip_top && p == npass - 1) ? &skip_top->depth_skip_top : nullptr;
         const uint32_t* kbase = (skip_top && p > 0) ? &skip_top->depth_key_base : nullptr;

@@ -314,8 +314,8 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                       int digit_bits = RADIX_BITS, bool key16 = false, uint32_t* aux = nullptr, uint32_t* aux_alt = nullptr,
                       FrameCounters* skip_top = nullptr, uint32_t** out_keys_skipped = nullptr, uint32_t** out_vals_skipped = nullptr,
                       int kpt9 = 0);  // kpt9 (9-bit digits only): 0 = the tile size the input size selects, 4 / 8 = keys per thread (A/B)
-//   skip_top (four 8-bit passes from bit 0 only: the depth sort of a frame): the first kernel folds K1's key-bit words into
-//     skip_top->depth_skip_top (depth_top_decide); when it is set the three kernels of the LAST pass return at once and the
+//   skip_top (four passes of 8- or 9-bit digits from bit 0 only: the depth sort of a frame): the first histogram kernel leaves the key range, the column scan behind it folds it into
+//     skip_top->depth_skip_top (depth_range_decide); when it is set the three kernels of the LAST pass return at once and the
 //     result is what pass 2 wrote: *out_keys_skipped / *out_vals_skipped (the companion values next to the payload).
 //   aux / aux_alt: a 4-byte companion value per pair travels with the payload; the result lands where
 //     the payload lands (aux for an even pass count, aux_alt for an odd one).

@@ -219,6 +219,7 @@ SIGNATURES = {
     "ws_view_batch_errors": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int]),
     "ws_renderer_errors": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]),
     "ws_view_batch_renderer": (C.c_void_p, [_P, C.c_uint32]),
+    "ws_view_batch_host_waits": (C.c_uint32, [_P]),
     "ws_display_composite": (C.c_int, [_P, _P, C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, _f32p, C.c_int, _P,
                                        C.c_size_t, _P]),
     "ws_pointcloud_create": (C.c_int, [_P, C.POINTER(ws_pointcloud_desc), _PP]),

@@ -842,6 +842,10 @@ class ViewBatch:
         check(lib.ws_view_batch_errors(self.handle, C.byref(bits), int(bool(reset))))
         return bits.value
 
+    def host_waits(self) -> int:
+        """times render() slept because a slot's host side was queue_depth frames ahead of the device (websplat.h)."""
+        return int(lib.ws_view_batch_host_waits(self.handle))
+
     def renderer(self, slot: int) -> "GaussianRenderer":
         """A non-owning view of slot's renderer (frame_stats, timers)."""
         r = GaussianRenderer.__new__(GaussianRenderer)
