@@ -197,6 +197,8 @@ typedef struct ws_context_config {
     int32_t ply_decode_host;   /* 0; 1 = ws_load_ply converts the vertex rows on the host instead of on the device */
     int32_t depth_digit_bits;  /* 0 = default; 8 = four 8-bit passes (the reference's shape), 9 = three 9-bit passes over key - base */
     int32_t depth_tile_kpt;    /* 0 = by input size; 4 / 8 = keys per thread of the 9-bit depth sort's tiles (A/B) */
+    int32_t blend_async;       /* -1 / 0 = k_blend (two workgroup barriers per staged batch); 1 = k_blend2 (double-buffered staging, LDS
+                                * arrival counters, no per-batch barrier: bit-identical images, measured slower -- experimental build only) */
     /* measured-and-lost variants: honoured by the EXPERIMENTAL build only (lib_exp); the product library refuses non-defaults */
     int32_t exp_depth_sort;    /* 0 scan (default) | 1 fat-tile one-sweep | 2 one cooperative launch */
     int32_t exp_dsort_fat_grid;
@@ -205,7 +207,7 @@ typedef struct ws_context_config {
     int32_t exp_batch_k1;      /* 1 (default) .. 4 views per K1 launch */
     int32_t exp_footprint_ellipse;
     int32_t exp_tile_sort_wide;
-    int32_t reserved[7];       /* zero */
+    int32_t reserved[6];       /* zero */
 } ws_context_config;
 void ws_context_config_init(ws_context_config* cfg); /* fills in the defaults above */
 int ws_context_create(int hip_device, ws_context** out);
@@ -340,7 +342,8 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
 /* GaussianRenderer::num_visible_points (syncs) */
 int ws_renderer_num_visible(ws_renderer* r, uint32_t* out);
 int ws_renderer_frame_stats(ws_renderer* r, ws_frame_stats* out); /* syncs */
-/* Error bits of EVERY frame this renderer drew since creation / the last reset (syncs): bit 0 = the (tile, splat)
+/* Error bits of EVERY frame this renderer drew since creation / the last reset (syncs; bit 4 = a compositing workgroup waited
+ * ~1 s for a staged batch that never came -- k_blend2's bounded spin): bit 0 = the (tile, splat)
  * entry list overflowed its capacity (entries_needed = what the last frame would have needed), bits 1..3 = a
  * look-back spin timed out.  The reference has no counterpart: wgpu validates sizes up front and the ROPs cannot
  * overflow; here the binned entry list can, and a caller that enqueues frames back to back (bin/measure.rs:98-153)

@@ -37,6 +37,7 @@ static inline void ws_context_config_from_env(ws_context_config* c) {
     c->ply_decode_host = ws_env_is_("WS_PLY_DECODE", "host");
     c->depth_digit_bits = ws_env_int_("WS_DEPTH_DIGIT_BITS", c->depth_digit_bits);
     c->depth_tile_kpt = ws_env_int_("WS_DEPTH_TILE_KPT", c->depth_tile_kpt);
+    c->blend_async = ws_env_int_("WS_BLEND_ASYNC", c->blend_async);
     if (ws_env_is_("WS_DEPTH_SORT", "onesweep")) c->exp_depth_sort = 1;
     else if (ws_env_is_("WS_DEPTH_SORT", "coop")) c->exp_depth_sort = 2;
     c->exp_dsort_fat_grid = ws_env_int_("WS_DSORT_FAT_GRID", c->exp_dsort_fat_grid);

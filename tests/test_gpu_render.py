@@ -856,6 +856,12 @@ def test_compositing_workgroups_run_longest_list_first(ws, oracle, monkeypatch):
     assert not np.array_equal(imgs["1", "auto", 0], imgs["1", "auto", 1])
 
 
+def _row_at(row, xyz):
+    r = np.array(row, copy=True)[None, :]
+    r[0, 0:3] = np.asarray(xyz, dtype=np.float32)
+    return r
+
+
 @pytest.mark.parametrize("digit_bits", [8, 9])
 def test_depth_sort_skips_its_last_pass_on_a_narrow_key_range(ws, oracle, monkeypatch, digit_bits):
     """Round 5: a camera outside the scene sees depth keys -- bits(zfar - z), preprocess.wgsl:270-273 -- that span less than 2^24;
@@ -886,11 +892,15 @@ def test_depth_sort_skips_its_last_pass_on_a_narrow_key_range(ws, oracle, monkey
             for name, cj, rr in (("outside", outside, rows), ("inside", outside, rows_wide)):
                 sc = scenes.Scene(ws, oracle, rr, 3, cj, vp)
                 if digit_bits == 9 and name == "inside":
-                    # 2^27 in f32 bits is a factor of 65 536 in (zfar - z): only a splat that all but touches the far plane gets
-                    # there -- put the far plane right behind the deepest splat of the trail
+                    # 2^27 in f32 bits is a factor of 65 536 in (zfar - z), and K1 culls z_ndc >= 1 (preprocess.wgsl:190): a splat can
+                    # come that close to the far plane only when znear / zfar is large (1 - z_ndc ~ (znear / zfar) * eps must stay
+                    # above an f32 ulp) -- no camera fitted to a scene gets there, which is why three 9-bit passes are the rule.
+                    # Forced here: row 0 ON the view axis 3000 units out, the far plane 1.4e-5 (relative) behind it, the near plane at 30.
                     fwd = np.asarray(cj.rotation, dtype=np.float64)[:, 2]
-                    depth = (rr[:, 0:3].astype(np.float64) - np.asarray(cj.position, dtype=np.float64)) @ fwd
-                    sc.args.camera.zfar = float(np.float32(depth.max() * (1.0 + 3e-6)))
+                    far = np.asarray(cj.position, dtype=np.float64) + 3000.0 * fwd
+                    sc = scenes.Scene(ws, oracle, np.concatenate([_row_at(rr[0], far), rr[1:]]), 3, cj, vp)
+                    sc.args.camera.znear = 30.0
+                    sc.args.camera.zfar = float(np.float32(3000.0 * (1.0 + 1.4e-5)))
                 pc = ws.PointCloud(c, sc.gpc)
                 r = ws.GaussianRenderer(c, "rgba32float", 3, False)
                 try:
@@ -1078,3 +1088,45 @@ def test_two_contexts_in_one_process_draw_the_same_frames(ws, oracle):
         a.close()
         for s in streams:
             hip.hipStreamDestroy(s)
+
+
+@pytest.mark.experimental
+@pytest.mark.parametrize("fmt", ["rgba32float", "rgba16float", "rgba8unorm"])
+@pytest.mark.parametrize("order", ["0", "1"])
+def test_async_blend_is_bit_identical(ws, oracle, monkeypatch, fmt, order):
+    """Round 6: k_blend2 (double-buffered staging, LDS arrival counters, no per-batch workgroup barrier) composites every pixel
+    with the statements of k_blend in the same order -- only WHEN a wave does its share differs.  Its image must therefore be
+    the bit-identical image: tiles with one staged batch, tiles with dozens (400 k splats on 320x240: lists of > 10 k entries,
+    early saturation in the dense centre), empty tiles, tiles cut by the image edge (330x250), both workgroup orders."""
+    monkeypatch.setenv("WS_BLEND_ORDER", order)
+    cases = [("sparse", synth.scene_c1(n=20_000, seed=91), synth.camera_c1(330, 250), (330, 250)),
+             ("dense", synth.scene_c2(n=400_000, seed=92), synth.orbit_cameras(8, 320, 240, 320.0, 320.0)[2], (320, 240)),
+             ("hd", synth.scene_c2(n=300_000, seed=93), synth.orbit_cameras(8, 1280, 720, 1280.0, 1280.0)[5], (1280, 720))]
+    imgs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("WS_BLEND_ASYNC", mode)
+        c = ws.Context(0)
+        try:
+            for name, rows, cj, vp in cases:
+                sc = scenes.Scene(ws, oracle, rows, 3, cj, vp)
+                pc = ws.PointCloud(c, sc.gpc)
+                r = ws.GaussianRenderer(c, fmt, 3, False)
+                try:
+                    for rep in range(2):
+                        r.prepare(pc, sc.args)
+                        r.render(pc, background=(0.1, 0.2, 0.3, 0.4))
+                        imgs[mode, name, rep] = r.download_target()
+                    st = r.frame_stats()
+                    assert st["overflow"] == 0 and r.errors()[0] == 0, (mode, name, st)
+                    if name == "dense":
+                        b, e, _ = r.tile_lists()
+                        assert (e - b).max() > 4 * 512        # lists of many staged batches
+                finally:
+                    r.close()
+                    pc.close()
+        finally:
+            c.close()
+    for name, *_ in cases:
+        for rep in range(2):
+            assert np.array_equal(imgs["0", name, rep], imgs["1", name, rep]), (name, rep)
+        assert np.array_equal(imgs["1", name, 0], imgs["1", name, 1]), name

@@ -15,7 +15,7 @@ def lib_is_experimental():
 # parameter sets through exp_param / env_param below) and are skipped BY THAT MARKER against the product library.  Nothing
 # is skipped because of the text of an exception: a product path that raises WS_ERR_UNSUPPORTED is a failure.
 VARIANT_ENV = {"WS_DEPTH_SORT": ("onesweep", "coop"), "WS_BLEND_VARIANT": None, "WS_BLEND_DMA": None, "WS_BATCH_K1": None,
-               "WS_FOOTPRINT": ("ellipse",), "WS_TILE_SORT": ("wide",)}
+               "WS_FOOTPRINT": ("ellipse",), "WS_TILE_SORT": ("wide",), "WS_BLEND_ASYNC": None}
 
 
 def env_is_variant(env):

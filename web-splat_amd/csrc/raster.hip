@@ -945,6 +945,9 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     if (DMA) wait_vector_loads();  // a prefetch the tile did not consume must have landed before the workgroup's LDS is released
 }
 
+#ifdef WS_EXPERIMENTAL  // measured-and-lost variants: compiled by `make experimental` only
+#include "experimental/blend_async.hip"
+#endif
 // ---- k_blend_q: one WAVE per 8x8 quadrant, no LDS, no barriers -------------------------------------------
 // Measured on MI355X (profiles/): the 256-thread kernel above is bound by the serial latency of one tile (two
 // barriers per 256-splat batch, three dependent LDS reads per splat), not by VALU (26 % busy) or LDS bandwidth.
@@ -1218,6 +1221,21 @@ static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
         WS_HIP(hipGetLastError());
         return WS_OK;
     }
+#ifdef WS_EXPERIMENTAL
+    // the barrier-free form (k_blend2): one 32x32 tile per workgroup, production launch only
+    if (p.async_staging && QW == 4 && QH == 4 && !capture && tpw_log2 == 0u && !p.dma && p.range_row_shift == 0u) {
+        switch (p.format) {
+            case WS_FORMAT_RGBA32_FLOAT: hipLaunchKernelGGL(k_blend2<WS_FORMAT_RGBA32_FLOAT>, dim3(grid), dim3(1024), pad, stream, p); break;
+            case WS_FORMAT_RGBA16_FLOAT: hipLaunchKernelGGL(k_blend2<WS_FORMAT_RGBA16_FLOAT>, dim3(grid), dim3(1024), pad, stream, p); break;
+            case WS_FORMAT_RGBA8_UNORM: hipLaunchKernelGGL(k_blend2<WS_FORMAT_RGBA8_UNORM>, dim3(grid), dim3(1024), pad, stream, p); break;
+            default: return fail(WS_ERR_INVALID, "blend: unknown colour format");
+        }
+        WS_HIP(hipGetLastError());
+        return WS_OK;
+    }
+#else
+    if (p.async_staging) return fail(WS_ERR_UNSUPPORTED, "barrier-free staging (k_blend2) is only in the experimental build");
+#endif
 #ifdef WS_EXPERIMENTAL  // (LDS-DMA staging, WS_BLEND_DMA=1: measured neutral; instantiated in the experimental build only)
 #define WS_LAUNCH_BLEND_DMA(FMT)                                                                                          \
     if (!capture && tpw_log2 > 0u && p.dma)                                                                               \

@@ -423,6 +423,7 @@ void ws_context_config_init(ws_context_config* c) {
     c->blend_tpw_log2 = -1;
     c->tile_qw = c->tile_qh = 4;
     c->exp_batch_k1 = 1;
+    c->blend_async = -1;
 }
 
 int ws_context_create(int hip_device, ws_context** out) {
@@ -478,10 +479,10 @@ int ws_context_create_with_config(int hip_device, const ws_context_config* cfg_i
     ctx->footprint = cfg.exp_footprint_ellipse ? FP_ELLIPSE : FP_RECT_PACKED;
 #else
     if (cfg.exp_depth_sort || cfg.exp_blend_variant || cfg.exp_blend_dma || cfg.exp_batch_k1 != 1 || cfg.exp_footprint_ellipse ||
-        cfg.exp_tile_sort_wide) {
+        cfg.exp_tile_sort_wide || cfg.blend_async > 0) {
         delete ctx;
         return fail(WS_ERR_UNSUPPORTED, "ws_context_create: exp_depth_sort, exp_blend_variant, exp_blend_dma, "
-                                        "exp_batch_k1, exp_footprint_ellipse and exp_tile_sort_wide select measured-and-lost variants that are only in "
+                                        "exp_batch_k1, exp_footprint_ellipse, exp_tile_sort_wide and blend_async = 1 select measured-and-lost variants that are only in "
                                         "the experimental build (make -C web-splat_amd experimental; WEBSPLAT_LIB=.../lib_exp/libwebsplat_hip.so)");
     }
 #endif
@@ -505,6 +506,7 @@ int ws_context_create_with_config(int hip_device, const ws_context_config* cfg_i
     ctx->render_views_fast_blend = cfg.render_views_fast_blend != 0;
     ctx->ply_decode_host = cfg.ply_decode_host != 0;
     ctx->depth_digit_bits = cfg.depth_digit_bits;
+    ctx->blend_async = cfg.blend_async;
     ctx->depth_tile_kpt = (cfg.depth_tile_kpt == 4 || cfg.depth_tile_kpt == 8) ? cfg.depth_tile_kpt : 0;
     *out = ctx;
     return WS_OK;
@@ -1443,6 +1445,7 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
     bp.lds_pad_kb = r->ctx->blend_lds_pad_kb;
     bp.dma = r->ctx->blend_dma;
+    bp.async_staging = r->ctx->blend_async < 0 ? WS_BLEND_ASYNC_DEFAULT : (r->ctx->blend_async ? 1 : 0);
     bp.num_cus = r->ctx->num_cus;
     bp.range_row_shift = 0;
     bp.bin_tiles_x = r->tiles_x;

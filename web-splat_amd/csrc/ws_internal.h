@@ -80,6 +80,9 @@ constexpr float T_MIN = 1.0f / 16384.0f;      // front-to-back early-out (6.1e-5
 #endif
 #define WS_SETPRIO_K1() do { if (WS_PRIO_K1) __builtin_amdgcn_s_setprio(WS_PRIO_K1); } while (0)
 #define WS_SETPRIO_SMALL() do { if (WS_PRIO_SMALL) __builtin_amdgcn_s_setprio(WS_PRIO_SMALL); } while (0)
+#ifndef WS_BLEND_ASYNC_DEFAULT
+#define WS_BLEND_ASYNC_DEFAULT 0
+#endif
 #ifndef WS_DEPTH_DIGIT_BITS_DEFAULT
 #define WS_DEPTH_DIGIT_BITS_DEFAULT 8
 #endif
@@ -431,6 +434,7 @@ struct BlendParams {
     int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
     int lds_pad_kb;             // tuning: extra (unused) dynamic LDS per workgroup, limits workgroups per CU
     int dma;                    // stage the Splat records with gfx950's LDS-DMA (global_load_lds) instead of through VGPRs
+    int async_staging;          // k_blend2: double-buffered staging, LDS arrival counters instead of the two barriers per batch
     int num_cus;
     uint32_t bin_tiles_x;       // binning tiles per row at the blend's tile size (the frame may bin at twice that: FrameCounters::bin_shift)
     uint32_t range_row_shift;   // 0, or 1 = "split" mode: tiles_y counts HALF binning tiles (32x16 px, 8 waves) and the list of
@@ -529,6 +533,7 @@ struct ws_context {
     bool render_views_fast_blend = false;
     bool ply_decode_host = false;
     int depth_digit_bits = 0;      // ws_context_config::depth_digit_bits: 0 = default, 8 / 9 force the depth sort's digit width
+    int blend_async = -1;          // ws_context_config::blend_async: -1 = default, 0 / 1 = k_blend / k_blend2 (barrier-free staging)
     int depth_tile_kpt = 0;        // ws_context_config::depth_tile_kpt (9-bit digits, A/B): 0 = by input size, 4 / 8 keys per thread
     // Is this context drawing on several streams in turn (a hand-rolled pipeline of renderers with frames in flight), or one
     // frame at a time?  The stream of the latest prepare() and how many consecutive prepare() calls used that same stream;

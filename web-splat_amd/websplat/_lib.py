@@ -50,8 +50,8 @@ class ws_context_config(C.Structure):
     _fields_ = [(n, C.c_uint32 if n == "struct_size" else C.c_int32) for n in (
         "struct_size", "use_graph", "depth_skip_top", "blend_order", "blend_split", "bin_request", "batch_threads",
         "batch_queue_depth", "blend_tpw_log2", "blend_lds_pad_kb", "tile_qw", "tile_qh", "debug_cut", "capture",
-        "render_views_fast_blend", "ply_decode_host", "depth_digit_bits", "depth_tile_kpt", "exp_depth_sort", "exp_dsort_fat_grid",
-        "exp_blend_variant", "exp_blend_dma", "exp_batch_k1", "exp_footprint_ellipse", "exp_tile_sort_wide")] + [("reserved", C.c_int32 * 7)]
+        "render_views_fast_blend", "ply_decode_host", "depth_digit_bits", "depth_tile_kpt", "blend_async", "exp_depth_sort", "exp_dsort_fat_grid",
+        "exp_blend_variant", "exp_blend_dma", "exp_batch_k1", "exp_footprint_ellipse", "exp_tile_sort_wide")] + [("reserved", C.c_int32 * 6)]
 
 
 class ws_pointcloud_desc(C.Structure):

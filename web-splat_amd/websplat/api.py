@@ -194,7 +194,7 @@ def config_from_env(env=None, **overrides):
                         ("WS_BLEND_SPLIT", "blend_split"), ("WS_BATCH_THREADS", "batch_threads"),
                         ("WS_BATCH_QUEUE_DEPTH", "batch_queue_depth"), ("WS_BLEND_TPW_LOG2", "blend_tpw_log2"),
                         ("WS_BLEND_LDS_PAD_KB", "blend_lds_pad_kb"), ("WS_DEBUG_CUT", "debug_cut"), ("WS_CAPTURE", "capture"),
-                        ("WS_DEPTH_DIGIT_BITS", "depth_digit_bits"), ("WS_DEPTH_TILE_KPT", "depth_tile_kpt"), ("WS_DSORT_FAT_GRID", "exp_dsort_fat_grid"),
+                        ("WS_DEPTH_DIGIT_BITS", "depth_digit_bits"), ("WS_DEPTH_TILE_KPT", "depth_tile_kpt"), ("WS_BLEND_ASYNC", "blend_async"), ("WS_DSORT_FAT_GRID", "exp_dsort_fat_grid"),
                         ("WS_BLEND_VARIANT", "exp_blend_variant"), ("WS_BATCH_K1", "exp_batch_k1")):
         num(name, field)
     if env.get("WS_BLEND_DMA") not in (None, ""):
