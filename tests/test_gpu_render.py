@@ -895,12 +895,12 @@ def test_depth_sort_skips_its_last_pass_on_a_narrow_key_range(ws, oracle, monkey
                     # 2^27 in f32 bits is a factor of 65 536 in (zfar - z), and K1 culls z_ndc >= 1 (preprocess.wgsl:190): a splat can
                     # come that close to the far plane only when znear / zfar is large (1 - z_ndc ~ (znear / zfar) * eps must stay
                     # above an f32 ulp) -- no camera fitted to a scene gets there, which is why three 9-bit passes are the rule.
-                    # Forced here: row 0 ON the view axis 3000 units out, the far plane 1.4e-5 (relative) behind it, the near plane at 30.
+                    # Forced here: row 0 ON the view axis 3000 units out, the far plane 1e-5 (relative) behind it, the near plane at 300.
                     fwd = np.asarray(cj.rotation, dtype=np.float64)[:, 2]
                     far = np.asarray(cj.position, dtype=np.float64) + 3000.0 * fwd
                     sc = scenes.Scene(ws, oracle, np.concatenate([_row_at(rr[0], far), rr[1:]]), 3, cj, vp)
-                    sc.args.camera.znear = 30.0
-                    sc.args.camera.zfar = float(np.float32(3000.0 * (1.0 + 1.4e-5)))
+                    sc.args.camera.znear = 300.0
+                    sc.args.camera.zfar = float(np.float32(3000.0 * (1.0 + 1.0e-5)))
                 pc = ws.PointCloud(c, sc.gpc)
                 r = ws.GaussianRenderer(c, "rgba32float", 3, False)
                 try:
