@@ -394,6 +394,12 @@ int ws_renderer_binning_tile(ws_renderer* r, uint32_t* width, uint32_t* height);
  * 2^24, else 9; ws_context_config::depth_digit_bits forces it); either width gives the reference's stable order.  Syncs. */
 int ws_renderer_depth_sort_passes(ws_renderer* r, uint32_t* passes);
 int ws_renderer_depth_sort_digit_bits(ws_renderer* r, uint32_t* digit_bits); /* of the last prepared frame; no sync */
+/* Analysis of FRAMES IN FLIGHT (no counterpart in the reference; rocprofv3's kernel trace serialises the hardware queues, so what
+ * runs beside what has to be measured on the device): K1 and the compositing kernel of the next `frames` frames of this renderer
+ * leave {first workgroup start, last workgroup end} on the device's 100-MHz clock -- stamps[frame][4] = K1 start, K1 end, blend
+ * start, blend end; one clock shared by all renderers of the device.  frames = 0 switches it off.  download syncs. */
+int ws_renderer_enable_frame_trace(ws_renderer* r, uint32_t frames);
+int ws_renderer_download_frame_trace(ws_renderer* r, uint32_t capacity, uint64_t* stamps, uint32_t* count);
 /* The compositing tile in pixels (one workgroup of the blend): 32x32 by default (four 16x16 tiles -- 4x4 wave quadrants
  * of 8x8 pixels -- sharing one binned list), 32x16 or 16x16 with WS_TILE_SHAPE=4x2|2x2 at context creation (tuning; 2x2 is
  * the literal one-workgroup-per-16x16-tile form).  Lists are built per BINNING tile: this tile, or 2 x 2 of them when the

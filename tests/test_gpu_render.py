@@ -1130,3 +1130,36 @@ def test_async_blend_is_bit_identical(ws, oracle, monkeypatch, fmt, order):
         for rep in range(2):
             assert np.array_equal(imgs["0", name, rep], imgs["1", name, rep]), (name, rep)
         assert np.array_equal(imgs["1", name, 0], imgs["1", name, 1]), name
+
+
+def test_frame_trace_stamps_k1_and_the_blend_on_the_device_clock(ws, ctx, oracle):
+    """Round 6: ws_renderer_enable_frame_trace -- K1 and the compositing kernel of the next n frames leave {first workgroup start,
+    last workgroup end} on the 100-MHz device clock (the instrument of scripts/inflight_device_trace.py: rocprofv3 serialises
+    frames in flight).  Per frame K1 starts before it ends, ends before the blend starts (the sorts and the binning lie between),
+    frames of one renderer follow one another; the image is the untraced image; frames beyond n are not traced."""
+    sc = scenes.c1(ws, oracle, n=30_000, viewport=(640, 480), seed=95)
+    pc = ws.PointCloud(ctx, sc.gpc)
+    r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    try:
+        r.prepare(pc, sc.args)
+        r.render(pc)
+        ref = r.download_target()
+        assert r.frame_trace().shape == (0, 4)
+        r.enable_frame_trace(3)
+        for _ in range(5):
+            r.prepare(pc, sc.args)
+            r.render(pc)
+        tr = r.frame_trace().astype(np.int64)
+        assert tr.shape == (3, 4)
+        assert np.array_equal(r.download_target(), ref)
+        for k1s, k1e, bs, be in tr:
+            assert 0 < k1s < k1e <= bs < be, (k1s, k1e, bs, be)
+            assert (k1e - k1s) < 100 * 1000 and (be - bs) < 100 * 1000      # (100-MHz ticks: well under a millisecond each)
+        assert np.all(tr[1:, 0] >= tr[:-1, 3])                                # one renderer, one stream: frame after frame
+        r.enable_frame_trace(0)
+        r.prepare(pc, sc.args)
+        r.render(pc)
+        assert r.frame_trace().shape == (0, 4) and np.array_equal(r.download_target(), ref)
+    finally:
+        r.close()
+        pc.close()

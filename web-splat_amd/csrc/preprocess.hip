@@ -535,6 +535,7 @@ __device__ __forceinline__ void k1_back_compressed(const K1Params& p, const K1Bu
 template <bool COMPRESSED, int FPMODE>
 __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const K1Params p, const K1Buffers b) {
     WS_SETPRIO_K1();
+    ws_trace_begin(b.trace);
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_cnt[K1_ITEMS][K1_THREADS / 64];
     __shared__ uint32_t s_base;
@@ -695,6 +696,7 @@ __global__ __launch_bounds__(K1_THREADS, WS_K1_MINWAVES) void k_preprocess(const
             }
         }
     }
+    ws_trace_end(b.trace);
 }
 
 }  // namespace

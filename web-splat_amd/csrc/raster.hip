@@ -618,6 +618,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
         if (bits) fold_frame_errors(p, bits);
         post_frame_progress(p);
     }
+    ws_trace_begin(p.trace);
     const BlendShape shape = blend_shape(QW, QH);
     const BlendBlock blk = blend_block_of(blockIdx.x, p.tiles_x, p.tiles_y, shape, tpw_log2);
     // Ordered launch (k_blend_order): workgroup b composites the tile the table names for b -- every b below the tile count has
@@ -943,6 +944,7 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
     }
     }  // tiles of this workgroup
     if (DMA) wait_vector_loads();  // a prefetch the tile did not consume must have landed before the workgroup's LDS is released
+    ws_trace_end(p.trace);
 }
 
 #ifdef WS_EXPERIMENTAL  // measured-and-lost variants: compiled by `make experimental` only

@@ -189,6 +189,9 @@ struct ws_renderer {
     int order_mode_this_frame = 0;       // decide_blend_order() of the prepare() in progress
     int depth_bits_this_frame = 8;       // digit width the last enqueued depth sort used (8 | 9)
     int graph_depth_bits = 0;            // != 0 while a frame graph is captured / valid: its depth sort's digit width
+    unsigned long long* frame_trace = nullptr;  // [trace_cap][4]: {K1 start, K1 end, blend start, blend end} per frame (ws_renderer_enable_frame_trace)
+    uint32_t trace_cap = 0, trace_count = 0;
+    unsigned long long* trace_slot = nullptr;   // the slot of the frame being prepared / rendered (nullptr: not traced)
     bool blend_timing = false;           // ws_renderer_enable_blend_timing: render() launches the time-stamped blend
     uint32_t* debug_timing = nullptr;    // [tiles][16][BLEND_TIMING_WORDS], allocated on first use
     uint32_t debug_timing_tiles = 0;
@@ -885,6 +888,7 @@ void ws_renderer_destroy(ws_renderer* r) {
     (void)hipDeviceSynchronize();
     renderer_free_scratch(r);
     dfree(r->sticky);
+    if (r->frame_trace) (void)hipFree(r->frame_trace);
     if (r->demand_mailbox) (void)hipHostFree(r->demand_mailbox);
     for (auto& e : r->ev)
         if (e) (void)hipEventDestroy(e);
@@ -937,6 +941,41 @@ int ws_renderer_download_blend_order(ws_renderer* r, uint32_t capacity_blocks, u
     if (capacity_blocks < nb) return fail(WS_ERR_INVALID, "ws_renderer_download_blend_order: capacity smaller than the block count");
     WS_HIP(hipStreamSynchronize(r->last_stream));
     return copy_d2h(order4, r->blend_order, (size_t)nb * sizeof(uint4), r->last_stream);
+}
+
+// Analysis of frames in flight (round 6): rocprofv3's kernel trace serialises the queues, so what really runs beside what is
+// measured on the device -- K1 and the blend of the next `frames` frames of this renderer leave {min start, max end} of their
+// workgroups on the 100-MHz device clock (one 64-bit atomic per workgroup at each end; off: a null pointer, one scalar branch).
+int ws_renderer_enable_frame_trace(ws_renderer* r, uint32_t frames) {
+    if (!r) return fail(WS_ERR_INVALID, "ws_renderer_enable_frame_trace: null renderer");
+    if (r->last_stream || r->prepared) WS_HIP(hipStreamSynchronize(r->last_stream));
+    if (r->frame_trace) {
+        (void)hipFree(r->frame_trace);
+        r->frame_trace = nullptr;
+    }
+    r->trace_cap = r->trace_count = 0;
+    r->trace_slot = nullptr;
+    if (frames == 0) return WS_OK;
+    std::vector<unsigned long long> init((size_t)frames * 4);
+    for (uint32_t i = 0; i < frames; ++i) {
+        init[4 * i + 0] = init[4 * i + 2] = ~0ull;
+        init[4 * i + 1] = init[4 * i + 3] = 0ull;
+    }
+    WS_HIP(hipMalloc(reinterpret_cast<void**>(&r->frame_trace), init.size() * sizeof(unsigned long long)));
+    WS_HIP(hipMemcpy(r->frame_trace, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    r->trace_cap = frames;
+    return WS_OK;
+}
+
+int ws_renderer_download_frame_trace(ws_renderer* r, uint32_t capacity, uint64_t* stamps, uint32_t* count) {
+    if (!r || !count) return fail(WS_ERR_INVALID, "ws_renderer_download_frame_trace: null argument");
+    *count = r->trace_count < r->trace_cap ? r->trace_count : r->trace_cap;
+    if (!stamps) return WS_OK;
+    if (capacity < *count) return fail(WS_ERR_INVALID, "ws_renderer_download_frame_trace: capacity smaller than the traced frames");
+    if (*count == 0) return WS_OK;
+    WS_HIP(hipStreamSynchronize(r->last_stream));
+    WS_HIP(hipMemcpy(stamps, r->frame_trace, (size_t)*count * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return WS_OK;
 }
 
 int ws_renderer_enable_blend_timing(ws_renderer* r, int enable) {
@@ -1242,6 +1281,10 @@ static int prepare_setup(ws_renderer* r, const ws_pointcloud* pc, const ws_splat
     kb.src_index = r->capture ? r->src_index : nullptr;
     kb.block_status = r->k1_status;
     kb.counters = r->counters;
+    // (the next `trace_cap` frames of a traced renderer: one slot of four stamps per frame, each used once)
+    r->trace_slot = (r->frame_trace && r->trace_count < r->trace_cap) ? r->frame_trace + (size_t)r->trace_count * 4 : nullptr;
+    if (r->trace_slot) ++r->trace_count;
+    kb.trace = r->trace_slot;
 
     // look-back epoch of this frame (lookback.h); on wrap-around the status arrays are re-zeroed
     if (++r->epoch == 0) {
@@ -1469,6 +1512,7 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.debug_consumed = r->capture ? r->debug_consumed : nullptr;
     bp.debug_walked = r->capture ? r->debug_walked : nullptr;
     bp.debug_timing = nullptr;
+    bp.trace = r->trace_slot ? r->trace_slot + 2 : nullptr;
     if (r->blend_timing && !r->capture) {
         const uint32_t nt = r->tiles_x * r->tiles_y;
         if (r->debug_timing_tiles != nt) {

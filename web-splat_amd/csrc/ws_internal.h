@@ -80,6 +80,20 @@ constexpr float T_MIN = 1.0f / 16384.0f;      // front-to-back early-out (6.1e-5
 #endif
 #define WS_SETPRIO_K1() do { if (WS_PRIO_K1) __builtin_amdgcn_s_setprio(WS_PRIO_K1); } while (0)
 #define WS_SETPRIO_SMALL() do { if (WS_PRIO_SMALL) __builtin_amdgcn_s_setprio(WS_PRIO_SMALL); } while (0)
+// ---- device-side launch trace (ws_renderer_enable_frame_trace): min of the workgroups' start stamps, max of their end stamps ----
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned long long ws_realtime() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ void ws_trace_begin(unsigned long long* t) {
+    if (t && threadIdx.x == 0) atomicMin(t, ws_realtime());
+}
+__device__ __forceinline__ void ws_trace_end(unsigned long long* t) {
+    if (t && threadIdx.x == 0) atomicMax(t + 1, ws_realtime());
+}
+#endif
 #ifndef WS_BLEND_ASYNC_DEFAULT
 #define WS_BLEND_ASYNC_DEFAULT 0
 #endif
@@ -375,6 +389,8 @@ struct K1Buffers {
     uint32_t* src_index;         // [N] or nullptr (capture mode)
     uint64_t* block_status;      // [blocks] epoch-tagged look-back words
     FrameCounters* counters;
+    unsigned long long* trace;   // nullptr, or {first workgroup start, last workgroup end} of this launch on the 100-MHz device clock
+                                 //   (ws_renderer_enable_frame_trace: analysis of frames in flight; rocprofv3 serialises them)
 };
 int launch_preprocess(const K1Params& p, const K1Buffers& b, bool compressed, int footprint_mode, hipStream_t stream);
 // K1 of up to K1_MAX_VIEWS views of ONE scene in one launch (preprocess.hip k_preprocess_multi): the scene is read once
@@ -450,6 +466,7 @@ struct BlendParams {
     uint32_t* debug_consumed;   // nullptr, or [tiles]: entries of each tile's list the blend walked (capture mode)
     uint32_t* debug_walked;     // nullptr, or [tiles][17]: records walked per wave, [16] = sum over batches of the per-batch maximum
     uint32_t* debug_timing;     // nullptr, or [tiles][16 waves][BLEND_TIMING_WORDS]: per-wave phase times (ws_renderer_enable_blend_timing)
+    unsigned long long* trace;  // nullptr, or {first workgroup start, last workgroup end} of this launch (ws_renderer_enable_frame_trace)
 };
 constexpr int BLEND_TIMING_WORDS = 16;
 int launch_blend(const BlendParams& p, int variant, hipStream_t stream);

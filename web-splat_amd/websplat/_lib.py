@@ -169,6 +169,8 @@ SIGNATURES = {
     "ws_renderer_download_blend_order": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "ws_renderer_depth_sort_passes": (C.c_int, [_P, _P]),
     "ws_renderer_depth_sort_digit_bits": (C.c_int, [_P, _P]),
+    "ws_renderer_enable_frame_trace": (C.c_int, [_P, C.c_uint32]),
+    "ws_renderer_download_frame_trace": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "ws_renderer_enable_blend_timing": (C.c_int, [_P, C.c_int]),
     "ws_renderer_download_blend_timing": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "ws_debug_stage_splat": (C.c_int, [_u32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,

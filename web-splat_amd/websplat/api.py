@@ -659,6 +659,19 @@ class GaussianRenderer:
         check(lib.ws_renderer_depth_sort_passes(self.handle, C.byref(v)))
         return v.value
 
+    def enable_frame_trace(self, frames: int):
+        """K1 and the blend of the next `frames` frames leave (start, end) on the device clock (websplat.h)."""
+        check(lib.ws_renderer_enable_frame_trace(self.handle, int(frames)))
+
+    def frame_trace(self):
+        """[frames, 4] uint64 ticks of the 100-MHz device clock: K1 start, K1 end, blend start, blend end (syncs)."""
+        n = C.c_uint32()
+        check(lib.ws_renderer_download_frame_trace(self.handle, 0, None, C.byref(n)))
+        out = np.zeros((n.value, 4), dtype=np.uint64)
+        if n.value:
+            check(lib.ws_renderer_download_frame_trace(self.handle, n.value, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return out
+
     def depth_sort_digit_bits(self) -> int:
         """digit width (8 | 9) of the last prepared frame's depth sort (websplat.h)."""
         v = C.c_uint32()
