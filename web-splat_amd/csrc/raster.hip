@@ -551,6 +551,9 @@ __device__ __forceinline__ void blend_composite(const BlendRec& r, float lx, flo
     }
 }
 
+#ifndef WS_BLEND_COMPACT_SKIP
+#define WS_BLEND_COMPACT_SKIP 0
+#endif
 #ifndef WS_BLEND_MINWAVES
 #define WS_BLEND_MINWAVES 1
 #endif
@@ -806,6 +809,11 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
                                               // unrolled rounds would hold eight registers for the whole kernel)
 #pragma unroll
             for (int h = 0; h < LCAP / 256; ++h) {
+#if WS_BLEND_COMPACT_SKIP
+                // (a batch of at most 256 entries -- the median hd1m tile stages 197 -- has nothing in its upper slots: a scalar branch
+                //  saves their mask load and four ballots)
+                if (h > 0 && nb - sub <= (uint32_t)(h * 256)) break;
+#endif
                 const uint2 mm = mp[h];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
