@@ -552,7 +552,7 @@ __device__ __forceinline__ void blend_composite(const BlendRec& r, float lx, flo
 }
 
 #ifndef WS_BLEND_COMPACT_SKIP
-#define WS_BLEND_COMPACT_SKIP 0
+#define WS_BLEND_COMPACT_SKIP 1
 #endif
 #ifndef WS_BLEND_MINWAVES
 #define WS_BLEND_MINWAVES 1

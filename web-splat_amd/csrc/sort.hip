@@ -747,7 +747,8 @@ int launch_sort_pairs(const SortScratch& sc, uint32_t* keys, uint32_t* vals, con
                                                      implicit_iota, first_tile_hist_ready, stream, &kin, &vin, km, names,  \
                                                      ranges, nranges, skip_top, out_keys_skipped, out_vals_skipped)
     if (digit_bits == 9) {  // (never key16: checked above)
-        const bool big9 = kpt9 ? kpt9 >= SORT_KPT : big;
+        // (1024-pair tiles only up to SORT_SMALL_MAX keys: the count rows' pitch is sized for that, alloc_sort_scratch)
+        const bool big9 = (kpt9 == SORT_KPT_SMALL && n <= SORT_SMALL_MAX) ? false : (kpt9 ? true : big);
         if (big9) rc = run_passes_scan<SORT_KPT, 9, false>(sc, kin, vin, kout, vout, aux, aux_alt, d_count, n, begin_bit, npass, implicit_iota,
                                                           false, stream, &kin, &vin, km, names, nullptr, 0u, skip_top, out_keys_skipped,
                                                           out_vals_skipped);
