@@ -551,6 +551,9 @@ __device__ __forceinline__ void blend_composite(const BlendRec& r, float lx, flo
     }
 }
 
+#ifndef WS_BLEND_LAST_BATCH_NO_VOTE
+#define WS_BLEND_LAST_BATCH_NO_VOTE 0
+#endif
 #ifndef WS_BLEND_COMPACT_SKIP
 #define WS_BLEND_COMPACT_SKIP 1
 #endif
@@ -874,6 +877,12 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
             tm[6] += t - tm_last;  // walk
             tm_last = t;
         }
+#if WS_BLEND_LAST_BATCH_NO_VOTE
+        // The LAST batch of the list needs no vote: nobody stages behind it, so a wave stores its pixels -- and gives its wave slot
+        // back -- when ITS walk ends instead of waiting for the slowest of sixteen (the median hd1m tile has one batch: all of its
+        // vote wait).  (MULTI: the barrier between two tiles of a workgroup stays, below.  Capture / LDS-DMA builds keep the vote.)
+        if (!DMA && !(CAPTURE && p.debug_walked) && hi == range.x) break;
+#endif
         bool all_done;
         if (DMA) {  // __syncthreads_and() without the release fence that would drain the staging DMA
             const bool wave_alive = __ballot(T >= T_MIN) != 0ull;  // (evaluated by ALL lanes, not behind `lane == 0 &&`)
