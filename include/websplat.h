@@ -363,8 +363,14 @@ int ws_renderer_kernel_times(ws_renderer* r, uint32_t capacity, ws_kernel_time* 
  *                                the destination rounded to the target's precision (f16 RNE / unorm8 RNE / f32) after
  *                                EVERY splat, no early termination -- what bin/render.rs:154 (Rgba16Float) and
  *                                bin/measure.rs:184 (Rgba8Unorm) write.  Several times slower; ws_render_views uses it.
+ *   WS_BLEND_FAST_EXACT_CUT      WS_BLEND_FAST, but a fragment within a few ulp of the cut-off (gaussian.wgsl:61, a > 2 CUTOFF
+ *                                discards: a step of 0.009 * alpha in its weight) is kept or discarded by the reference's own
+ *                                expression, dot(screen_pos, screen_pos) from the un-prescaled inverse, re-derived from the Splat
+ *                                record (rare: ~1e-5 of the fragments).  No cut-off boundary pixel is left between this mode and
+ *                                the f32 reference image (max-abs 6.1e-5, the early-out bound, on the uncompressed workloads);
+ *                                the band test costs the blend +5 ... +7 % (frames/s -3 %), so it is a mode, not the default.
  * Takes effect at the next render(). */
-typedef enum ws_blend_mode { WS_BLEND_FAST = 0, WS_BLEND_TARGET_PRECISION = 1 } ws_blend_mode;
+typedef enum ws_blend_mode { WS_BLEND_FAST = 0, WS_BLEND_TARGET_PRECISION = 1, WS_BLEND_FAST_EXACT_CUT = 2 } ws_blend_mode;
 int ws_renderer_set_blend_mode(ws_renderer* r, int mode);
 /* parity tooling: also record the original Gaussian index of every store slot (costs 4 B per visible splat) */
 int ws_renderer_enable_capture(ws_renderer* r, int enable);

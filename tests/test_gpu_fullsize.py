@@ -126,8 +126,17 @@ def test_c5_compressed_4k_vs_oracle(ws, ctx, oracle, tmp_path):
         _REPORT["c5/view1"] = {"gaussians": int(gpc.num_points), "viewport": list(viewport), "visible": int(len(keys)),
                                "tile_entries": int(st["num_tile_entries"]),
                                "f32_target_vs_oracle_f32": {"max_abs": mx, "mean_abs": mean, "boundary_pixels_proven": nb}}
+        # the exact-cut mode (round 6): the twelve boundary pixels of the fast mode shrink to the few whose fragment sits at the cut-off
+        # of a splat that K1c itself stores one f16 ulp off the oracle's (the compressed path's documented 1-ulp axes) -- still proven
+        r.set_blend_mode("fast_exact_cut")
+        r.render(pc)
+        img_x = r.download_target()
+        r.set_blend_mode("fast")
+        ok_x, msg_x, mx_x, mean_x, nb_x = scenes.image_close(img_x, ref, proof=lambda: scenes.BoundaryProof(splats, order, viewport[0], viewport[1]))
+        _REPORT["c5/view1"]["exact_cut_mode_vs_oracle_f32"] = {"max_abs": mx_x, "mean_abs": mean_x, "boundary_pixels_proven": nb_x}
         _write_report()
         assert ok, msg
+        assert ok_x and nb_x <= 4 and nb_x <= nb, ("exact-cut mode", msg_x, nb_x, nb)
         # GATED as on the uncompressed configurations (_full_parity): the target-precision blend -- the destination rounded
         # after every splat, what the reference's blender leaves in an Rgba8Unorm (bin/measure.rs:184) or Rgba16Float
         # (bin/render.rs:154) target -- against the oracle's per-blend modes composited from the library's own records
@@ -433,6 +442,17 @@ def _full_parity(ws, ctx, oracle, tag, rows, cams, viewport):
                      "tile_entries": int(st["num_tile_entries"]),
                      "f32_target_vs_oracle_f32": {"max_abs": mx, "mean_abs": mean, "boundary_pixels_proven": nb,
                                                   "tolerance": {"max_abs": scenes.MAX_ABS, "mean_abs": scenes.MEAN_ABS}}}
+            # GATED, with NO cut-off boundary allowance (round 6): the exact-cut blend mode decides fragments at the cut-off on the
+            # reference's own expression -- every pixel within the plain tolerance, and far inside it (the early-out bound is 6.1e-5)
+            rs["rgba32float"].set_blend_mode("fast_exact_cut")
+            rs["rgba32float"].render(pc)
+            img_exact = rs["rgba32float"].download_target()
+            rs["rgba32float"].set_blend_mode("fast")
+            assert rs["rgba32float"].errors()[0] == 0
+            ok_x, msg_x, mx_x, mean_x, nb_x = scenes.image_close(img_exact, ref, allow_boundary=False)
+            entry["exact_cut_mode_vs_oracle_f32"] = {"max_abs": mx_x, "mean_abs": mean_x, "boundary_pixels": nb_x,
+                                                     "pixels_differing_from_fast_mode": int((img_exact != imgs["rgba32float"]).any(axis=2).sum())}
+            assert ok_x and nb_x == 0 and mx_x <= 5e-4, (tag, vi, "exact-cut mode", msg_x, mx_x)
             # reported, not gated: the reference's per-blend rounding on its f16 / unorm8 targets
             img16 = imgs["rgba16float"].astype(np.float32)
             img8 = imgs["rgba8unorm"].astype(np.float32) / 255.0

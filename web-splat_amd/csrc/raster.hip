@@ -527,13 +527,52 @@ __device__ __forceinline__ BlendRec blend_load_rec(const float4* s_rec, uint32_t
     r.h = *reinterpret_cast<const float4*>(base + SLOTS * 16);
     return r;
 }
+// EXACT (round 6, verdict r05 item 6; ws_renderer_set_blend_mode(r, WS_BLEND_FAST_EXACT_CUT)): the keep / discard decision of a
+// fragment whose a' lies within the rounding band of the cut-off is taken on the ORACLE's expression -- a = |M^-1 (pixel - centre)|^2
+// from the un-prescaled inverse, source order, a > 2 CUTOFF discards (gaussian.wgsl:60-63; oracle/ws_oracle.c wso_render) -- re-derived
+// from the Splat record, which the rare fragment (~1e-5 of them) fetches again through its list entry; exp() keeps the fast form.
+// The image then equals the oracle's to the early-out bound (6.1e-5) with NO cut-off boundary pixel on the uncompressed workloads
+// (profiles/r06/blend_exact_cut_ab.txt); the band test costs two VALU instructions on the taken path of every (wave, record) pair:
+// blend +5 ... +7 %, frames/s -3 %.  A mode, not the default.
+struct BlendExact {
+    const BlendParams* p = nullptr;
+    uint32_t hi = 0u;            // end of the staged batch in the entry list (slot s holds entry hi - 1 - s)
+    float fx = 0.f, fy = 0.f;    // this lane's pixel centre, absolute
+    float W = 0.f, H = 0.f;
+};
+constexpr float CUT_BAND = 4e-6f;  // relative half-width of the band (the tile-local affine form carries ~10 roundings of 6e-8)
+__device__ __forceinline__ bool blend_exact_keep(const BlendExact& e, uint32_t list_off) {
+#pragma clang fp contract(off)
+    const uint32_t slot = (list_off >> 4) & 1023u;
+    const uint32_t idx = e.p->entry_vals[e.hi - 1u - slot];
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(e.p->splats + (size_t)idx * SPLAT_STRIDE);
+    const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2];
+    const float v1x = h2f(w0), v1y = h2f(w0 >> 16), v2x = h2f(w1), v2y = h2f(w1 >> 16);
+    const float m00 = v1x * e.W, m01 = v2x * e.W;
+    const float m10 = -v1y * e.H, m11 = -v2y * e.H;
+    const float det = m00 * m11 - m01 * m10;
+    const float inv = 1.0f / det;
+    const float cx = (h2f(w2) * 0.5f + 0.5f) * e.W;
+    const float cy = (0.5f - h2f(w2 >> 16) * 0.5f) * e.H;
+    const float i00 = m11 * inv, i01 = -m01 * inv, i10 = -m10 * inv, i11 = m00 * inv;
+    const float dx = e.fx - cx, dy = e.fy - cy;
+    const float p0 = i00 * dx + i01 * dy;
+    const float p1 = i10 * dx + i11 * dy;
+    const float a = p0 * p0 + p1 * p1;
+    return a <= CUT_A;
+}
 // One (pixel, splat) pair: gaussian.wgsl:59-66 in the exp2 domain, front-to-back "over".
+template <bool EXACT = false>
 __device__ __forceinline__ void blend_composite(const BlendRec& r, float lx, float ly, float& T, float& cr, float& cg,
-                                                float& cb) {
+                                                float& cb, const BlendExact& ex = BlendExact{}, uint32_t list_off = 0u) {
     const float p0 = fmaf(r.g.x, lx, fmaf(r.g.y, ly, r.g.z));
     const float p1 = fmaf(r.g.w, lx, fmaf(r.h.x, ly, r.h.y));
     const float a = fmaf(p0, p0, p1 * p1);
-    if (a <= CUT_A2) {
+    bool keep = a <= (EXACT ? CUT_A2 * (1.0f + CUT_BAND) : CUT_A2);
+    if (EXACT) {
+        if (__builtin_expect(keep && a >= CUT_A2 * (1.0f - CUT_BAND), 0)) keep = blend_exact_keep(ex, list_off);
+    }
+    if (keep) {
         // b = min(0.99, 2^-a' * alpha), alpha = high half of h.w.  One asm block: gfx950 needs one wait state between
         // a transcendental's result and a VALU instruction reading it, and the compiler does not look inside asm.
         float b;
@@ -578,9 +617,11 @@ __device__ __forceinline__ uint32_t blend_stamp() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return (uint32_t)t;
 }
-template <int FORMAT, int QW, int QH, bool MULTI, bool CAPTURE, bool DMA, bool TIMING = false>
-__global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const BlendParams p, const uint32_t tpw_log2_arg) {
+template <int FORMAT, int QW, int QH, bool MULTI, bool CAPTURE, bool DMA, bool TIMING = false, bool EXACT = false>
+__global__ __launch_bounds__(64 * QW * QH, (EXACT && QW * QH == 16) ? 8 : WS_BLEND_MINWAVES) void k_blend(const BlendParams p,
+                                                                                                    const uint32_t tpw_log2_arg) {
     static_assert(!TIMING || (!MULTI && !DMA && !CAPTURE), "the timing build instruments the production form only");
+    static_assert(!EXACT || (!CAPTURE && !DMA && !TIMING), "the exact cut-off decision belongs to the production launch");
     uint32_t tm[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // TIMING: cycles per phase, this wave (SGPRs)
     uint32_t tm_batches = 0u, tm_real0 = 0u;
     const uint32_t tm_start = blend_stamp<TIMING>();
@@ -844,14 +885,16 @@ __global__ __launch_bounds__(64 * QW * QH, WS_BLEND_MINWAVES) void k_blend(const
                 uint4 on = lp[n4 > 1u ? 1u : 0u];
                 BlendRec cur = blend_load_rec<SLOTS>(s_rec, o.x);
                 for (uint32_t g = 0; g < n4; ++g) {
+                    const BlendExact exact = {&p, hi, tile_x0 + lx, tile_y0 + ly, W, H};  // (EXACT only; dead code otherwise)
                     const BlendRec r1 = blend_load_rec<SLOTS>(s_rec, o.y);
-                    blend_composite(cur, lx, ly, T, cr, cg, cb);
+                    blend_composite<EXACT>(cur, lx, ly, T, cr, cg, cb, exact, o.x);
                     const BlendRec r2 = blend_load_rec<SLOTS>(s_rec, o.z);
-                    blend_composite(r1, lx, ly, T, cr, cg, cb);
+                    blend_composite<EXACT>(r1, lx, ly, T, cr, cg, cb, exact, o.y);
                     const BlendRec r3 = blend_load_rec<SLOTS>(s_rec, o.w);
-                    blend_composite(r2, lx, ly, T, cr, cg, cb);
+                    blend_composite<EXACT>(r2, lx, ly, T, cr, cg, cb, exact, o.z);
+                    const uint32_t off3 = o.w;
                     cur = blend_load_rec<SLOTS>(s_rec, on.x);  // (re-reads a valid record after the last group)
-                    blend_composite(r3, lx, ly, T, cr, cg, cb);
+                    blend_composite<EXACT>(r3, lx, ly, T, cr, cg, cb, exact, off3);
                     // the quadrant is saturated: nothing behind can add more than T_MIN (one compare per four pairs;
                     // on dense tiles this stops the walk well inside the staged batch)
                     if ((CAPTURE && p.debug_walked) || TIMING) dbg_walked += 4u;
@@ -1268,7 +1311,11 @@ static int launch_blend_shape(const BlendParams& p, hipStream_t stream) {
 #endif
 #define WS_LAUNCH_BLEND(FMT)                                                                                              \
     WS_LAUNCH_BLEND_DMA(FMT)                                                                                              \
-    if (capture)                                                                                                          \
+    if (p.exact_cut && !capture && tpw_log2 > 0u)                                                                         \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, false, false, false, true>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);  \
+    else if (p.exact_cut && !capture)                                                                                     \
+        hipLaunchKernelGGL((k_blend<FMT, QW, QH, false, false, false, false, true>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2); \
+    else if (capture)                                                                                                          \
         hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, true, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);    \
     else if (tpw_log2 > 0u)                                                                                               \
         hipLaunchKernelGGL((k_blend<FMT, QW, QH, true, false, false>), dim3(grid), dim3(NT), pad, stream, p, tpw_log2);   \

@@ -916,7 +916,7 @@ int ws_renderer_enable_timers(ws_renderer* r, int enable) {
 
 int ws_renderer_set_blend_mode(ws_renderer* r, int mode) {
     if (!r) return fail(WS_ERR_INVALID, "ws_renderer_set_blend_mode: null renderer");
-    if (mode != WS_BLEND_FAST && mode != WS_BLEND_TARGET_PRECISION)
+    if (mode != WS_BLEND_FAST && mode != WS_BLEND_TARGET_PRECISION && mode != WS_BLEND_FAST_EXACT_CUT)
         return fail(WS_ERR_INVALID, "ws_renderer_set_blend_mode: unknown mode");
     r->blend_mode = mode;
     return WS_OK;
@@ -1488,6 +1488,7 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     bp.tpw_log2 = r->ctx->blend_tpw_log2;
     bp.lds_pad_kb = r->ctx->blend_lds_pad_kb;
     bp.dma = r->ctx->blend_dma;
+    bp.exact_cut = (r->blend_mode == WS_BLEND_FAST_EXACT_CUT && !r->capture && !r->blend_timing) ? 1 : 0;
     bp.async_staging = r->ctx->blend_async < 0 ? WS_BLEND_ASYNC_DEFAULT : (r->ctx->blend_async ? 1 : 0);
     bp.num_cus = r->ctx->num_cus;
     bp.range_row_shift = 0;
@@ -1498,7 +1499,7 @@ int ws_renderer_render(ws_renderer* r, const ws_pointcloud* pc, const float back
     // doubled staging costs more with frames in flight than the finer synchronisation saves.
     const bool split = r->ctx->blend_split >= 0 ? r->ctx->blend_split != 0
                                                  : (r->tiles_x * r->tiles_y < 2u * (uint32_t)r->ctx->num_cus);
-    if (split && bp.qw == 4 && bp.qh == 4 && !r->capture && r->ctx->blend_variant == 0 && r->blend_mode == WS_BLEND_FAST) {
+    if (split && bp.qw == 4 && bp.qh == 4 && !r->capture && r->ctx->blend_variant == 0 && r->blend_mode != WS_BLEND_TARGET_PRECISION) {
         bp.qh = 2;
         bp.tiles_y = (r->vh + 15u) / 16u;
         bp.range_row_shift = 1;

@@ -450,6 +450,7 @@ struct BlendParams {
     int tpw_log2;               // log2(tiles per workgroup), -1 = automatic (blend_tpw_log2)
     int lds_pad_kb;             // tuning: extra (unused) dynamic LDS per workgroup, limits workgroups per CU
     int dma;                    // stage the Splat records with gfx950's LDS-DMA (global_load_lds) instead of through VGPRs
+    int exact_cut;              // WS_BLEND_FAST_EXACT_CUT: the keep / discard decision of fragments at the cut-off on the oracle's expression
     int async_staging;          // k_blend2: double-buffered staging, LDS arrival counters instead of the two barriers per batch
     int num_cus;
     uint32_t bin_tiles_x;       // binning tiles per row at the blend's tile size (the frame may bin at twice that: FrameCounters::bin_shift)

@@ -721,7 +721,7 @@ class GaussianRenderer:
     def set_blend_mode(self, mode="fast"):
         """"fast" (front to back, early-out, one rounding at the store) or "target" (the reference's fixed-function blend
         literally: back to front, the destination rounded to the target's precision after every splat)."""
-        check(lib.ws_renderer_set_blend_mode(self.handle, {"fast": 0, "target": 1}[mode]))
+        check(lib.ws_renderer_set_blend_mode(self.handle, {"fast": 0, "target": 1, "fast_exact_cut": 2}[mode]))
 
     def set_tile_entry_capacity(self, entries: int):
         check(lib.ws_renderer_set_tile_entry_capacity(self.handle, int(entries)))
