@@ -330,3 +330,31 @@ def test_binning_decision_from_k1_sums(ws):
     assert ws.binning_decision(1, [], []) == 0 and ws.binning_decision(1, [0], [0]) == 0   # an empty frame
     assert ws.binning_decision(0, [1000], [100]) == 0 and ws.binning_decision(2, [100], [100]) == 1
     assert ws.binning_decision(1, [4_000_000_000 // 16] * 16, [2_000_000_000 // 16] * 16) == 1   # sums near 2^32
+
+
+def test_context_config_layout_matches_the_c_header(ws, tmp_path):
+    """The ctypes mirror of ws_context_config (and the field order INTEGRATION.md's Rust stub lists) against the C header itself:
+    a C99 program prints sizeof and every field's offset; the Python struct must agree field for field, and
+    ws_context_config_init must fill the documented defaults."""
+    import subprocess
+    from websplat import _lib
+    fields = [n for n, _ in _lib.ws_context_config._fields_]
+    src = ["#include <stdio.h>", "#include <stddef.h>", '#include "websplat.h"', '#include "websplat_env.h"', "int main(void) {",
+           '  printf("sizeof %zu\\n", sizeof(ws_context_config));']
+    src += [f'  printf("{n} %zu\\n", offsetof(ws_context_config, {n}));' for n in fields]
+    src += ["  return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert int(out["sizeof"]) == C.sizeof(_lib.ws_context_config) == 128
+    for n in fields:
+        assert int(out[n]) == getattr(_lib.ws_context_config, n).offset, n
+    cfg = _lib.ws_context_config()
+    ws.lib.ws_context_config_init(C.byref(cfg))
+    got = {n: (list(getattr(cfg, n)) if n == "reserved" else getattr(cfg, n)) for n in fields}
+    want = dict.fromkeys(fields, 0)
+    want.update(struct_size=128, depth_skip_top=1, blend_order=-1, blend_split=-1, bin_request=1, batch_threads=-1, batch_queue_depth=-1,
+                blend_tpw_log2=-1, tile_qw=4, tile_qh=4, exp_batch_k1=1, blend_async=-1, reserved=[0] * 6)
+    assert got == want
