@@ -1163,3 +1163,36 @@ def test_frame_trace_stamps_k1_and_the_blend_on_the_device_clock(ws, ctx, oracle
     finally:
         r.close()
         pc.close()
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_exact_cut_mode_needs_no_boundary_allowance(ws, ctx, oracle, seed):
+    """Round 6: in WS_BLEND_FAST_EXACT_CUT mode the keep / discard decision of a fragment at the cut-off (gaussian.wgsl:61) is the
+    reference's own expression, so the f32 image equals the oracle's within the plain tolerance on EVERY pixel -- no cut-off boundary
+    allowance, no proof -- over seeds, viewports that cut tiles, opaque and transparent clear colours; and the fast mode differs from
+    it only in a handful of pixels, each by less than one boundary fragment's weight."""
+    rng = np.random.default_rng(seed)
+    vp = [(640, 480), (801, 599), (330, 250), (1024, 768), (512, 512), (1280, 720)][seed - 101]
+    n = int(rng.integers(8_000, 60_000))
+    sc = scenes.c1(ws, oracle, n=n, viewport=vp, seed=seed)
+    bg = (0.0, 0.0, 0.0, 0.0) if seed % 2 else (0.2, 0.1, 0.3, 1.0)
+    pc = ws.PointCloud(ctx, sc.gpc)
+    r = ws.GaussianRenderer(ctx, "rgba32float", 3, False)
+    try:
+        r.prepare(pc, sc.args)
+        r.render(pc, background=bg)
+        fast = r.download_target()
+        r.set_blend_mode("fast_exact_cut")
+        r.render(pc, background=bg)
+        exact = r.download_target()
+        r.set_blend_mode("fast")
+        assert r.errors()[0] == 0
+        ref, _ = sc.oracle_image(pc, background=bg)
+        ok, msg, mx, mean, nb = scenes.image_close(exact, ref, allow_boundary=False)
+        assert ok and nb == 0, (msg, mx)
+        assert mx <= 5e-4, mx                                        # (the early-out bound is 6.1e-5 x the colour range)
+        d = np.abs(fast.astype(np.float64) - exact.astype(np.float64)).max(axis=2)
+        assert (d > 0).sum() <= max(8, 4e-5 * d.size) and d.max() <= scenes.BOUNDARY_STEP, ((d > 0).sum(), d.max())
+    finally:
+        r.close()
+        pc.close()
