@@ -962,7 +962,8 @@ int ws_renderer_enable_frame_trace(ws_renderer* r, uint32_t frames) {
         init[4 * i + 1] = init[4 * i + 3] = 0ull;
     }
     WS_HIP(hipMalloc(reinterpret_cast<void**>(&r->frame_trace), init.size() * sizeof(unsigned long long)));
-    WS_HIP(hipMemcpy(r->frame_trace, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    WS_HIP(hipMemcpyAsync(r->frame_trace, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, r->last_stream));
+    WS_HIP(hipStreamSynchronize(r->last_stream));
     r->trace_cap = frames;
     return WS_OK;
 }
@@ -973,9 +974,8 @@ int ws_renderer_download_frame_trace(ws_renderer* r, uint32_t capacity, uint64_t
     if (!stamps) return WS_OK;
     if (capacity < *count) return fail(WS_ERR_INVALID, "ws_renderer_download_frame_trace: capacity smaller than the traced frames");
     if (*count == 0) return WS_OK;
-    WS_HIP(hipStreamSynchronize(r->last_stream));
-    WS_HIP(hipMemcpy(stamps, r->frame_trace, (size_t)*count * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return WS_OK;
+    // (on the renderer's own stream, like every read-back of this library: never the legacy NULL stream)
+    return copy_d2h(stamps, r->frame_trace, (size_t)*count * 4 * sizeof(unsigned long long), r->last_stream);
 }
 
 int ws_renderer_enable_blend_timing(ws_renderer* r, int enable) {
