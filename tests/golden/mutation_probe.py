@@ -38,6 +38,17 @@ MUTATIONS = {
     "K1c dequantise *127. -> *128.": ("preprocess_compressed.wgsl", "v1 = dequantizef4(v1 * 127., quantization.color_dc);",
                                       "v1 = dequantizef4(v1 * 128., quantization.color_dc);", "k1c_"),
     "K1c max(radius, 0.1) -> 0.3": ("preprocess_compressed.wgsl", "let lambda2 = mid - max(radius, 0.1);", "let lambda2 = mid - max(radius, 0.3);", "k1c_"),
+    # round 6: ten more single-edit probes over lines none of the above touches
+    "depth key zfar - z -> zfar + z": ("preprocess.wgsl", "bitcast<u32>(zfar - pos2d.z)", "bitcast<u32>(zfar + pos2d.z)", "k1_"),
+    "eigenvector scale 2.0 -> 2.1": ("preprocess.wgsl", "let v1 = sqrt(2.0 * lambda1) * diagonalVector;", "let v1 = sqrt(2.1 * lambda1) * diagonalVector;", "k1_"),
+    "v2 sign": ("preprocess.wgsl", "vec2<f32>(diagonalVector.y, -diagonalVector.x);", "vec2<f32>(-diagonalVector.y, diagonalVector.x);", "k1_"),
+    "J[0][2] sign": ("preprocess.wgsl", "-(focal.x * camspace.x) / (camspace.z * camspace.z),", "(focal.x * camspace.x) / (camspace.z * camspace.z),", "k1_"),
+    "J[1][1] sign": ("preprocess.wgsl", "-focal.y / camspace.z,", "focal.y / camspace.z,", "k1_"),
+    "mid 0.5 -> 0.51": ("preprocess.wgsl", "let mid = 0.5 * (diagonal1 + diagonal2);", "let mid = 0.51 * (diagonal1 + diagonal2);", "k1_"),
+    "kernel size only on one diagonal": ("preprocess.wgsl", "let diagonal2 = cov[1][1] + kernel_size;", "let diagonal2 = cov[1][1];", "k1_"),
+    "Vrk row swap": ("preprocess.wgsl", "cov_sparse[1], cov_sparse[3], cov_sparse[4],", "cov_sparse[1], cov_sparse[4], cov_sparse[3],", "k1_"),
+    "view direction from the origin": ("preprocess.wgsl", "let dir = normalize(xyz - camera_pos);", "let dir = normalize(xyz);", "k1_"),
+    "SH_C1 sign": ("preprocess.wgsl", "0.4886025119029199", "-0.4886025119029199", "k1_"),
     # the draw (gaussian.wgsl:59-67): fixtures k6_fragments, k6_fragments_opaque, frame, frame_opaque
     "alpha clamp 0.99 -> 0.98": ("gaussian.wgsl", "min(0.99, exp(-a) * in.color.a)", "min(0.98, exp(-a) * in.color.a)", ("k6_", "frame")),
     "cut-off 2 CUTOFF -> 1.9 CUTOFF": ("gaussian.wgsl", "if a > 2. * CUTOFF", "if a > 1.9 * CUTOFF", ("k6_", "frame")),
