@@ -49,9 +49,16 @@ MUTATIONS = {
     "Vrk row swap": ("preprocess.wgsl", "cov_sparse[1], cov_sparse[3], cov_sparse[4],", "cov_sparse[1], cov_sparse[4], cov_sparse[3],", "k1_"),
     "view direction from the origin": ("preprocess.wgsl", "let dir = normalize(xyz - camera_pos);", "let dir = normalize(xyz);", "k1_"),
     "SH_C1 sign": ("preprocess.wgsl", "0.4886025119029199", "-0.4886025119029199", "k1_"),
+    "K1c s2 = scaling_factor (not squared)": ("preprocess_compressed.wgsl", "let s2 = scaling_factor * scaling_factor;", "let s2 = scaling_factor;", "k1c_"),
+    "K1c opacity from byte 1": ("preprocess_compressed.wgsl", "var opacity = dequantize(extractBits(i32(vertex.opacity_scale), 0u * 8u, 8u), quantization.opacity);",
+                                "var opacity = dequantize(extractBits(i32(vertex.opacity_scale), 1u * 8u, 8u), quantization.opacity);", "k1c_"),
+    "K1c Vrk element swap": ("preprocess_compressed.wgsl", "cov1[1], cov2[1], cov3[0],", "cov1[1], cov3[0], cov2[1],", "k1c_"),
     # the draw (gaussian.wgsl:59-67): fixtures k6_fragments, k6_fragments_opaque, frame, frame_opaque
     "alpha clamp 0.99 -> 0.98": ("gaussian.wgsl", "min(0.99, exp(-a) * in.color.a)", "min(0.98, exp(-a) * in.color.a)", ("k6_", "frame")),
     "cut-off 2 CUTOFF -> 1.9 CUTOFF": ("gaussian.wgsl", "if a > 2. * CUTOFF", "if a > 1.9 * CUTOFF", ("k6_", "frame")),
+    "quad half-size CUTOFF -> 0.9 CUTOFF": ("gaussian.wgsl", "let position = vec2<f32>(x, y) * CUTOFF;", "let position = vec2<f32>(x, y) * 0.9 * CUTOFF;", ("k6_", "frame")),
+    "quad offset 2. -> 1.9": ("gaussian.wgsl", "let offset = 2. * mat2x2<f32>(v1, v2) * position;", "let offset = 1.9 * mat2x2<f32>(v1, v2) * position;", ("k6_", "frame")),
+    "premultiplied colour: alpha 1. -> 0.9": ("gaussian.wgsl", "return vec4<f32>(in.color.rgb, 1.) * b;", "return vec4<f32>(in.color.rgb, 0.9) * b;", ("k6_", "frame")),
 }
 # arrays of a fixture that are OUTPUTS of the shader text (inputs -- seeded scenes, uniforms -- cannot move)
 OUTPUT_KEYS = ("splats", "keys", "num_visible", "src_index", "frag_out", "frag_keep", "image", "fragments")
