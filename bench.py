@@ -713,6 +713,11 @@ def main():
                                                   "distinct_images": len(set(got[0]))}
     if rank == 0 and not a.dry_run:
         analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world)
+        if nstreams > 1:
+            try:
+                out["inflight"] = inflight_trace(ws, batch, pc, plan, submit, device_sync, nstreams, min(max(a.steps, 8 * nstreams), 400))
+            except Exception as e:  # noqa: BLE001  (analysis only: never costs the run its result line)
+                out["inflight"] = {"error": repr(e)}
         if world == 1 and a.workload == "hd1m" and not a.no_secondary:
             out["secondary"] = {"c3": secondary(a, ws, ctx, torch, "c3", nstreams)}
     barrier()
@@ -754,6 +759,56 @@ def main():
     if out is not None:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     os.close(result_fd)
+
+
+def inflight_trace(ws, batch, pc, plan, submit, device_sync, nstreams, frames):
+    """What runs beside what with frames in flight, measured ON THE DEVICE behind the timed region (rocprofv3 serialises the hardware
+    queues: DESIGN 3.5): K1 and the compositing kernel of `frames` more frames of the same view batch stamp {first workgroup start, last
+    workgroup end} on the 100-MHz device clock (ws_renderer_enable_frame_trace; costs ~5 % while it is on, which is why it is not inside
+    the timed region).  -> us per frame with >= 2 blends running / one blend beside K1 / ... and the in-flight durations."""
+    import numpy as np
+    per_slot = (frames + nstreams - 1) // nstreams
+    rs = [batch.renderer(s_) for s_ in range(nstreams)]
+    device_sync()
+    for r_ in rs:
+        r_.enable_frame_trace(per_slot)
+    t0 = time.perf_counter()
+    submit(plan(0, frames))
+    device_sync()
+    elapsed = time.perf_counter() - t0
+    tr = [r_.frame_trace().astype(np.float64) / 100.0 for r_ in rs]   # us
+    for r_ in rs:
+        r_.enable_frame_trace(0)
+    k1, bl = [], []
+    for t in tr:
+        n = len(t)
+        lo, hi = n // 10, n - n // 10            # steady state: without the fill and the drain
+        k1 += [(x[0], x[1]) for x in t[lo:hi]]
+        bl += [(x[2], x[3]) for x in t[lo:hi]]
+    a0 = max(min(s_ for s_, _ in k1), min(s_ for s_, _ in bl))
+    b0 = min(max(e for _, e in k1), max(e for _, e in bl))
+    pts = [(s_, 0, 1) for s_, _ in k1] + [(e, 0, -1) for _, e in k1] + [(s_, 1, 1) for s_, _ in bl] + [(e, 1, -1) for _, e in bl]
+    pts.sort()
+    n_run, last, acc = [0, 0], a0, {}
+    for t, which, d in pts:
+        tt = min(max(t, a0), b0)
+        if tt > last:
+            key = (min(n_run[0], 2), min(n_run[1], 2))
+            acc[key] = acc.get(key, 0.0) + (tt - last)
+            last = tt
+        n_run[which] += d
+    nframes = max(sum(1 for s_, e in k1 if a0 <= s_ and e <= b0), 1)
+
+    def share(pred):
+        return sum(v for k, v in acc.items() if pred(*k)) / nframes
+    return {"frames": frames, "frames_per_s_while_traced": frames / elapsed, "us_per_frame": (b0 - a0) / nframes,
+            "k1_in_flight_us": float(np.mean([e - s_ for s_, e in k1])), "blend_in_flight_us": float(np.mean([e - s_ for s_, e in bl])),
+            "us_per_frame_with": {"no K1, no blend": share(lambda k, b: k == 0 and b == 0), "K1 only": share(lambda k, b: k >= 1 and b == 0),
+                                  "one blend, no K1": share(lambda k, b: k == 0 and b == 1), "one blend beside K1": share(lambda k, b: k >= 1 and b == 1),
+                                  "two or more blends": share(lambda k, b: b >= 2)},
+            "note": "device-side stamps of K1 and the compositing kernel (100-MHz clock, first workgroup start / last workgroup end), "
+                    "steady-state frames of a traced batch behind the timed region; with frames in flight the frame period is the sum of the "
+                    "LONE durations of the chip-filling kernels (DESIGN 3.5)"}
 
 
 def secondary(a, ws, ctx, torch, workload, nstreams, frames=200):

@@ -61,6 +61,11 @@ def test_bench_one_rank_rccl_and_contract():
     # (40 frames of c1 last a few milliseconds: CPU time comes in 10-ms ticks, so the busy-cores ratio is null below 0.1 s)
     assert (cfg["host_cores_busy_per_rank"] is None or 0 < cfg["host_cores_busy_per_rank"] < 64) and "host_cpu_quota" in cfg
     assert "secondary" not in out      # (only the default workload carries the c3 block)
+    # round 6: what runs beside what with frames in flight, measured on the device behind the timed region
+    fl = out["inflight"]
+    assert "error" not in fl, fl
+    assert fl["us_per_frame"] > 0 and fl["k1_in_flight_us"] > 0 and fl["blend_in_flight_us"] > 0
+    assert abs(sum(fl["us_per_frame_with"].values()) - fl["us_per_frame"]) < 0.05 * fl["us_per_frame"] + 1.0
 
 
 def _cpu_groups():
