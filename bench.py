@@ -465,6 +465,7 @@ def main():
                          "HBM fractions of the sort and K1 mean something -- for ~200 frames and reports it under "
                          "\"secondary\"; this switch leaves it out")
     ap.add_argument("--no-dist", action="store_true", help="skip the one-rank RCCL communicator at N = 1")
+    ap.add_argument("--no-inflight", action="store_true", help="skip the device-side in-flight trace behind the timed region (the 'inflight' block)")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo: the collectives run on host tensors (tests: several ranks sharing ONE GPU, where RCCL refuses "
                          "two ranks on a device); the rendering path is unchanged")
@@ -713,7 +714,7 @@ def main():
                                                   "distinct_images": len(set(got[0]))}
     if rank == 0 and not a.dry_run:
         analyse(a, ws, ctx, pc, gpc, r, frame, my_views, views, viewport, out, world)
-        if nstreams > 1:
+        if nstreams > 1 and not a.no_inflight:
             try:
                 out["inflight"] = inflight_trace(ws, batch, pc, plan, submit, device_sync, nstreams, min(max(a.steps, 8 * nstreams), 400))
             except Exception as e:  # noqa: BLE001  (analysis only: never costs the run its result line)
