@@ -431,6 +431,11 @@ int ws_debug_footprint(const uint32_t splat[3], float viewport_w, float viewport
 int ws_debug_packed_rect(uint32_t rect, uint32_t* tiles, uint32_t* tiles_coarse, uint32_t* rect_coarse);
 int ws_debug_binning_decision(uint32_t request, const uint32_t* sums, const uint32_t* sums_coarse, uint32_t nslots,
                               uint32_t* shift);
+/* host twin of the depth sort's range decision (ws_internal.h depth_range_decide; CPU unit test, not on any render path): from the
+ * frame's smallest and largest depth key and the radix (256 | 512) -> the base the passes behind the first subtract, whether the
+ * fourth pass is the identity (skip), and the span class the next frame's digit width is chosen by (0 unknown, 1 = < 2^24, 2 = not) */
+int ws_debug_depth_range(uint32_t key_min, uint32_t key_max, int have_keys, uint32_t digits, uint32_t* base, uint32_t* skip,
+                         uint32_t* span_class);
 /* tuning / analysis read-back: per tile LIST (one per binning tile, ws_renderer_binning_tile; row-major over
  * ceil(viewport / binning tile)), the length of the depth-ordered splat list and (capture mode, where the binning tile is
  * the compositing tile) how deep into it the compositing pass read: the position, counted from the near end, of the deepest

@@ -358,3 +358,27 @@ def test_context_config_layout_matches_the_c_header(ws, tmp_path):
     want.update(struct_size=128, depth_skip_top=1, blend_order=-1, blend_split=-1, bin_request=1, batch_threads=-1, batch_queue_depth=-1,
                 blend_tpw_log2=-1, tile_qw=4, tile_qh=4, exp_batch_k1=1, blend_async=-1, reserved=[0] * 6)
     assert got == want
+
+
+def test_depth_sort_range_decision(ws):
+    """ws_internal.h depth_range_decide through its host twin: base = min(key) with the first digit's bits cleared (the first pass runs
+    before anybody knows the base), the fourth pass is the identity iff max - base < radix^3 (2^24 at 8 bits, 2^27 at 9), the span class
+    the next frame's digit width follows is taken on the 8-bit base whatever the radix, no key -> nothing decided, and a frame that
+    holds a key of 0xFFFFFFFF keeps base 0 (the scatter kernels exempt that value -- also their padding key -- from the subtraction,
+    the histogram kernels do not: ADVICE r05)."""
+    def decide(lo, hi, digits, have=1):
+        b, s, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        assert ws.lib.ws_debug_depth_range(lo, hi, have, digits, C.byref(b), C.byref(s), C.byref(c)) == 0
+        return b.value, s.value, c.value
+    assert decide(0, 0, 256, have=0) == (0, 0, 0) and decide(0, 0, 512, have=0) == (0, 0, 0)
+    lo = 0x40801234
+    assert decide(lo, lo + (1 << 24) - 0x35, 256) == (0x40801200, 1, 1)          # span just under 2^24 above the 256-aligned base
+    assert decide(lo, lo + (1 << 24), 256) == (0x40801200, 0, 2)                  # ... one step over: four 8-bit passes
+    assert decide(lo, lo + (1 << 24), 512) == (0x40801200, 1, 2)                  # nine-bit digits: three passes, class says "not < 2^24"
+    assert decide(lo, 0x40801000 + (1 << 27) - 1, 512) == (0x40801200 & ~0x1FF, 1, 2)
+    assert decide(lo, (0x40801200 & ~0x1FF) + (1 << 27), 512)[1] == 0            # beyond 2^27: the fourth 9-bit pass runs
+    assert decide(5, 5, 256) == (0, 1, 1) and decide(0x1FF, 0x200, 512) == (0, 1, 1)
+    assert decide(0xFFFFFF00, 0xFFFFFFFF, 256) == (0, 0, 2)                       # a real key of 0xFFFFFFFF: no base
+    assert decide(0xFFFFFF00, 0xFFFFFFFE, 256) == (0xFFFFFF00, 1, 1)
+    with pytest.raises(ws.WebSplatError):
+        ws.check(ws.lib.ws_debug_depth_range(1, 2, 1, 300, C.byref(C.c_uint32()), C.byref(C.c_uint32()), C.byref(C.c_uint32())))

@@ -555,6 +555,23 @@ int ws_debug_binning_decision(uint32_t request, const uint32_t* sums, const uint
     return WS_OK;
 }
 
+int ws_debug_depth_range(uint32_t key_min, uint32_t key_max, int have_keys, uint32_t digits, uint32_t* base, uint32_t* skip,
+                         uint32_t* span_class) {
+    if (!base || !skip || !span_class || (digits != 256u && digits != 512u))
+        return fail(WS_ERR_INVALID, "ws_debug_depth_range: null argument, or a radix other than 256 / 512");
+    FrameCounters fc;
+    std::memset(&fc, 0, sizeof fc);
+    if (have_keys) {  // what the sort's first histogram kernel leaves in one slot: max(~key) and max(key)
+        fc.tile_sums[5 * TILE_SUM_STRIDE + 2] = ~key_min;
+        fc.tile_sums[5 * TILE_SUM_STRIDE + 3] = key_max;
+    }
+    depth_range_decide(&fc, digits);
+    *base = fc.depth_key_base;
+    *skip = fc.depth_skip_top;
+    *span_class = fc.depth_span_class;
+    return WS_OK;
+}
+
 int ws_debug_footprint(const uint32_t splat[3], float viewport_w, float viewport_h, uint32_t tile_w, uint32_t tile_h,
                        uint32_t capacity, uint32_t* tiles, uint32_t* count) {
     if (!splat || !count || (capacity && !tiles)) return fail(WS_ERR_INVALID, "ws_debug_footprint: null argument");

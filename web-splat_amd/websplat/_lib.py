@@ -177,6 +177,7 @@ SIGNATURES = {
                                        _f32p, _u32p]),
     "ws_debug_packed_rect": (C.c_int, [C.c_uint32, _u32p, _u32p, _u32p]),
     "ws_debug_binning_decision": (C.c_int, [C.c_uint32, _u32p, _u32p, C.c_uint32, _u32p]),
+    "ws_debug_depth_range": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, _u32p, _u32p, _u32p]),
     "ws_debug_footprint": (C.c_int, [_u32p, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p]),
     "ws_sync": (C.c_int, [_P, _P]),
     "ws_context_set_host_wait": (C.c_int, [_P, C.c_int]),
